@@ -1,0 +1,52 @@
+"""Builds csrc/*.hip into the in-tree C-ABI shared library ``csrc/libfbengine.so`` for gfx950 (hipcc cross-compiles
+without a GPU).  The .so is git-ignored but travels with gpurun snapshots."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB = os.path.join(CSRC, "libfbengine.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
+
+
+def needs_build():
+    if not os.path.isfile(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h"))]
+    deps.append(os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "fb_engine.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return LIB
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.rsplit(".", 1)[0] + ".o")
+        cmd = [HIPCC, *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{res.stderr}")
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        objs = list(pool.map(compile_one, sources()))
+    res = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"link failed:\n{res.stderr}")
+    if verbose:
+        print(f"built {LIB}", file=sys.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

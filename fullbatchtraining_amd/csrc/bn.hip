@@ -1,0 +1,259 @@
+// Training-mode BatchNorm pieces around the conv kernels (HBM-bound, NHWC, 16-byte vector lanes over channels).
+//   fwd : conv epilogue partial sums -> fb_bn_fwd_finalize -> fb_bn_apply (normalise + affine + residual + ReLU)
+//   bwd : fb_bn_bwd_reduce (sum dy, sum dy*xhat with the ReLU mask fused) -> fb_bn_bwd_finalize -> fb_bn_bwd_apply
+// All reductions are two-stage with a fixed order (no atomics): results are bit-reproducible run to run, which the
+// finite-difference regulariser relies on (both passes see identically ordered sums).
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void bn_fwd_finalize_kernel(const float* __restrict__ part, int n_mblocks, int blocks_per_group, int C, double inv_count,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta, long long pstride, float eps,
+                                       float* __restrict__ mean_tab, float* __restrict__ var_tab, int ch_total, int ch_off,
+                                       float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ invstd_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    const float* ps = part + ((long long)g * blocks_per_group) * C + c;
+    const float* pq = part + ((long long)n_mblocks + (long long)g * blocks_per_group) * C + c;
+    for (int b = 0; b < blocks_per_group; ++b) { s += (double)ps[(long long)b * C]; q += (double)pq[(long long)b * C]; }
+    const double mean = s * inv_count;
+    double var = q * inv_count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float gm = gamma[(long long)g * pstride + c], bt = beta[(long long)g * pstride + c];
+    const float sc = gm * invstd;
+    mean_tab[(long long)g * ch_total + ch_off + c] = (float)mean;
+    var_tab[(long long)g * ch_total + ch_off + c] = (float)var;
+    scale[(long long)g * C + c] = sc;
+    shift[(long long)g * C + c] = bt - (float)mean * sc;
+    invstd_out[(long long)g * C + c] = invstd;
+}
+
+extern "C" int fb_bn_fwd_finalize(const float* stat_partial, int32_t n_mblocks, int32_t n_groups, int32_t C, double count,
+                                  const float* gamma, const float* beta, int64_t param_group_stride, float eps, float* mean_tab,
+                                  float* var_tab, int32_t ch_total, int32_t ch_off, float* scale, float* shift, float* invstd,
+                                  void* stream) {
+    if (!stat_partial || !gamma || !beta || !mean_tab || !var_tab || !scale || !shift || !invstd) FB_FAIL(FB_ERR_ARG, "fb_bn_fwd_finalize: null pointer");
+    if (n_mblocks % n_groups != 0) FB_FAIL(FB_ERR_SHAPE, "fb_bn_fwd_finalize: %d pixel blocks not divisible by %d groups", n_mblocks, n_groups);
+    dim3 grid((C + 63) / 64, n_groups);
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, grid, dim3(64), 0, (hipStream_t)stream, stat_partial, n_mblocks, n_mblocks / n_groups, C,
+                       1.0 / count, gamma, beta, (long long)param_group_stride, eps, mean_tab, var_tab, ch_total, ch_off, scale, shift, invstd);
+    FB_CHECK_LAUNCH("fb_bn_fwd_finalize");
+    return FB_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, int RES>   // RES: 0 none, 1 plain residual, 2 residual with its own BN affine
+__global__ void bn_apply_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, const float* __restrict__ scale,
+                                const float* __restrict__ shift, const uint4* __restrict__ res, const float* __restrict__ rscale,
+                                const float* __restrict__ rshift, long long n_vec, int cvec, long long vec_per_group, int C, int relu) {
+    constexpr int V = ET<T>::VEC;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (long long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cvec) * V;
+        const long long g = i / vec_per_group;
+        float xv[V], o[V];
+        ET<T>::unpack(x[i], xv);
+        const float* sc = scale + g * C + c0; const float* sh = shift + g * C + c0;
+        float rv[V];
+        if (RES) ET<T>::unpack(res[i], rv);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float v = xv[k] * sc[k] + sh[k];
+            if (RES == 1) v += rv[k];
+            if (RES == 2) v += rv[k] * rscale[g * C + c0 + k] + rshift[g * C + c0 + k];
+            o[k] = relu ? fmaxf(v, 0.f) : v;
+        }
+        y[i] = ET<T>::pack(o);
+    }
+}
+
+template <typename T>
+static void launch_bn_apply(const void* x, void* y, const float* scale, const float* shift, const void* res, const float* rscale,
+                            const float* rshift, int64_t n_pixels, int C, int64_t ppg, int relu, hipStream_t st) {
+    const int cvec = C / ET<T>::VEC;
+    const long long n_vec = n_pixels * cvec, vpg = ppg * cvec;
+    const int blocks = (int)((n_vec + 255) / 256 < 8192 ? (n_vec + 255) / 256 : 8192);
+    if (!res) hipLaunchKernelGGL((bn_apply_kernel<T, 0>), dim3(blocks), dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, nullptr, nullptr, nullptr, n_vec, cvec, vpg, C, relu);
+    else if (!rscale) hipLaunchKernelGGL((bn_apply_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, nullptr, nullptr, n_vec, cvec, vpg, C, relu);
+    else hipLaunchKernelGGL((bn_apply_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, rscale, rshift, n_vec, cvec, vpg, C, relu);
+}
+
+extern "C" int fb_bn_apply(const void* x, void* y, const float* scale, const float* shift, const void* res, const float* rscale,
+                           const float* rshift, int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t relu, int32_t dtype,
+                           void* stream) {
+    if (!x || !y || !scale || !shift) FB_FAIL(FB_ERR_ARG, "fb_bn_apply: null pointer");
+    if (C % 8 != 0) FB_FAIL(FB_ERR_SHAPE, "fb_bn_apply: C=%d must be a multiple of 8", C);
+    if (dtype == FB_F32) launch_bn_apply<float>(x, y, scale, shift, res, rscale, rshift, n_pixels, C, pixels_per_group, relu, (hipStream_t)stream);
+    else launch_bn_apply<bf16_tag>(x, y, scale, shift, res, rscale, rshift, n_pixels, C, pixels_per_group, relu, (hipStream_t)stream);
+    FB_CHECK_LAUNCH("fb_bn_apply");
+    return FB_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void bn_running_update_kernel(float* __restrict__ rm, float* __restrict__ rv, const float* __restrict__ mean0,
+                                         const float* __restrict__ var0, const float* __restrict__ mean1, const float* __restrict__ var1,
+                                         const float* __restrict__ unbias, int n_groups, int ch_total, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ch_total) return;
+    float m = rm[c], v = rv[c];
+    const float ub = unbias[c], keep = 1.f - momentum;
+    for (int g = 0; g < n_groups; ++g) {
+        m = keep * m + momentum * mean0[(long long)g * ch_total + c];
+        v = keep * v + momentum * (var0[(long long)g * ch_total + c] * ub);
+        if (mean1) {
+            m = keep * m + momentum * mean1[(long long)g * ch_total + c];
+            v = keep * v + momentum * (var1[(long long)g * ch_total + c] * ub);
+        }
+    }
+    rm[c] = m; rv[c] = v;
+}
+
+extern "C" int fb_bn_running_update(float* running_mean, float* running_var, const float* mean0, const float* var0, const float* mean1,
+                                    const float* var1, const float* unbias, int32_t n_groups, int32_t ch_total, float momentum,
+                                    void* stream) {
+    if (!running_mean || !running_var || !mean0 || !var0 || !unbias) FB_FAIL(FB_ERR_ARG, "fb_bn_running_update: null pointer");
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3((ch_total + 255) / 256), dim3(256), 0, (hipStream_t)stream, running_mean,
+                       running_var, mean0, var0, mean1, var1, unbias, n_groups, ch_total, momentum);
+    FB_CHECK_LAUNCH("fb_bn_running_update");
+    return FB_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward reduce: block = 128 pixels x all channels.  thread -> (channel vector lane, pixel sub-row)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint4* __restrict__ dout, const uint4* __restrict__ y,
+                                                            const uint4* __restrict__ x, const float* __restrict__ mean_tab,
+                                                            const float* __restrict__ invstd, int ch_total, int ch_off,
+                                                            float* __restrict__ partial, long long n_pixels, int C, long long ppg,
+                                                            int n_mblocks) {
+    constexpr int V = ET<T>::VEC;
+    extern __shared__ float sm[];   // [rows][C][2]
+    const int cvec = C / V;
+    const int rows = 256 / cvec > 0 ? 256 / cvec : 1;      // pixel sub-rows handled in parallel
+    const int lanes = cvec < 256 ? cvec : 256;
+    const long long p0 = (long long)blockIdx.x * 128;
+    const long long g = p0 / ppg;
+    for (int cv = threadIdx.x % lanes; cv < cvec; cv += lanes) {
+        const int row = threadIdx.x / lanes;
+        const int c0 = cv * V;
+        float mu[V], is[V], s1[V], s2[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) { mu[k] = mean_tab[g * ch_total + ch_off + c0 + k]; is[k] = invstd[g * C + c0 + k]; s1[k] = 0.f; s2[k] = 0.f; }
+        if (row < rows) {
+            for (int pr = row; pr < 128; pr += rows) {
+                const long long pidx = p0 + pr;
+                if (pidx >= n_pixels) break;
+                const long long i = pidx * cvec + cv;
+                float d[V], xv[V], yv[V];
+                ET<T>::unpack(dout[i], d); ET<T>::unpack(x[i], xv);
+                if (y) ET<T>::unpack(y[i], yv);
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    const float dy = (y && !(yv[k] > 0.f)) ? 0.f : d[k];
+                    s1[k] += dy; s2[k] += dy * ((xv[k] - mu[k]) * is[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < V; ++k) { sm[(row * C + c0 + k) * 2] = s1[k]; sm[(row * C + c0 + k) * 2 + 1] = s2[k]; }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f, b = 0.f;
+        for (int r = 0; r < rows; ++r) { a += sm[(r * C + c) * 2]; b += sm[(r * C + c) * 2 + 1]; }
+        partial[(long long)blockIdx.x * C + c] = a;
+        partial[((long long)n_mblocks + blockIdx.x) * C + c] = b;
+    }
+}
+
+extern "C" int fb_bn_bwd_reduce(const void* dout, const void* y, const void* x, const float* mean_tab, const float* invstd,
+                                int32_t ch_total, int32_t ch_off, float* partial, int64_t n_pixels, int32_t C,
+                                int64_t pixels_per_group, int32_t dtype, void* stream) {
+    if (!dout || !x || !mean_tab || !invstd || !partial) FB_FAIL(FB_ERR_ARG, "fb_bn_bwd_reduce: null pointer");
+    if (pixels_per_group % 128 != 0) FB_FAIL(FB_ERR_SHAPE, "fb_bn_bwd_reduce: pixels_per_group=%lld must be a multiple of 128", (long long)pixels_per_group);
+    const int V = dtype == FB_F32 ? 4 : 8;
+    if (C % V != 0) FB_FAIL(FB_ERR_SHAPE, "fb_bn_bwd_reduce: C=%d", C);
+    const int cvec = C / V, rows = 256 / cvec > 0 ? 256 / cvec : 1;
+    const int n_mblocks = (int)((n_pixels + 127) / 128);
+    const size_t smem = (size_t)rows * C * 2 * sizeof(float);
+    if (smem > 64 * 1024) FB_FAIL(FB_ERR_UNSUPPORTED, "fb_bn_bwd_reduce: C=%d too large", C);
+    if (dtype == FB_F32)
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<float>), dim3(n_mblocks), dim3(256), smem, (hipStream_t)stream, (const uint4*)dout, (const uint4*)y,
+                           (const uint4*)x, mean_tab, invstd, ch_total, ch_off, partial, (long long)n_pixels, C, (long long)pixels_per_group, n_mblocks);
+    else
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_tag>), dim3(n_mblocks), dim3(256), smem, (hipStream_t)stream, (const uint4*)dout, (const uint4*)y,
+                           (const uint4*)x, mean_tab, invstd, ch_total, ch_off, partial, (long long)n_pixels, C, (long long)pixels_per_group, n_mblocks);
+    FB_CHECK_LAUNCH("fb_bn_bwd_reduce");
+    return FB_OK;
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int n_mblocks, int blocks_per_group, int C, double inv_count,
+                                       const float* __restrict__ scale, const float* __restrict__ mean_tab, const float* __restrict__ invstd,
+                                       int ch_total, int ch_off, float* __restrict__ dgamma, float* __restrict__ dbeta, long long gstride,
+                                       float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    const float* p1 = part + ((long long)g * blocks_per_group) * C + c;
+    const float* p2 = part + ((long long)n_mblocks + (long long)g * blocks_per_group) * C + c;
+    for (int b = 0; b < blocks_per_group; ++b) { s1 += (double)p1[(long long)b * C]; s2 += (double)p2[(long long)b * C]; }
+    dbeta[(long long)g * gstride + c] = (float)s1;
+    dgamma[(long long)g * gstride + c] = (float)s2;
+    // dx = scale*(dy - s1/M - xhat*s2/M) = c_dy*dy + c_x*x + c_0
+    const double sc = scale[(long long)g * C + c], is = invstd[(long long)g * C + c], mu = mean_tab[(long long)g * ch_total + ch_off + c];
+    const double cx = -sc * is * s2 * inv_count;
+    float* o = coef + ((long long)g * C + c) * 3;
+    o[0] = (float)sc; o[1] = (float)cx; o[2] = (float)(-sc * s1 * inv_count - cx * mu);
+}
+
+extern "C" int fb_bn_bwd_finalize(const float* partial, int32_t n_mblocks, int32_t n_groups, int32_t C, double count, const float* scale,
+                                  const float* mean_tab, const float* invstd, int32_t ch_total, int32_t ch_off, float* dgamma,
+                                  float* dbeta, int64_t grad_group_stride, float* coef, void* stream) {
+    if (!partial || !scale || !mean_tab || !invstd || !dgamma || !dbeta || !coef) FB_FAIL(FB_ERR_ARG, "fb_bn_bwd_finalize: null pointer");
+    if (n_mblocks % n_groups != 0) FB_FAIL(FB_ERR_SHAPE, "fb_bn_bwd_finalize: blocks/groups");
+    dim3 grid((C + 63) / 64, n_groups);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, grid, dim3(64), 0, (hipStream_t)stream, partial, n_mblocks, n_mblocks / n_groups, C, 1.0 / count,
+                       scale, mean_tab, invstd, ch_total, ch_off, dgamma, dbeta, (long long)grad_group_stride, coef);
+    FB_CHECK_LAUNCH("fb_bn_bwd_finalize");
+    return FB_OK;
+}
+
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const uint4* __restrict__ dout, const uint4* __restrict__ y, const uint4* __restrict__ x,
+                                    const float* __restrict__ coef, uint4* __restrict__ dx, uint4* __restrict__ dy_out, long long n_vec,
+                                    int cvec, long long vec_per_group, int C) {
+    constexpr int V = ET<T>::VEC;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (long long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cvec) * V;
+        const long long g = i / vec_per_group;
+        float d[V], xv[V], yv[V], o[V], dyv[V];
+        ET<T>::unpack(dout[i], d); ET<T>::unpack(x[i], xv);
+        if (y) ET<T>::unpack(y[i], yv);
+        const float* cf = coef + (g * C + c0) * 3;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float dy = (y && !(yv[k] > 0.f)) ? 0.f : d[k];
+            dyv[k] = dy;
+            o[k] = cf[3 * k] * dy + cf[3 * k + 1] * xv[k] + cf[3 * k + 2];
+        }
+        dx[i] = ET<T>::pack(o);
+        if (dy_out) dy_out[i] = ET<T>::pack(dyv);
+    }
+}
+
+extern "C" int fb_bn_bwd_apply(const void* dout, const void* y, const void* x, const float* coef, void* dx, void* dy_out,
+                               int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t dtype, void* stream) {
+    if (!dout || !x || !coef || !dx) FB_FAIL(FB_ERR_ARG, "fb_bn_bwd_apply: null pointer");
+    const int V = dtype == FB_F32 ? 4 : 8;
+    const int cvec = C / V;
+    const long long n_vec = n_pixels * cvec, vpg = pixels_per_group * cvec;
+    const int blocks = (int)((n_vec + 255) / 256 < 8192 ? (n_vec + 255) / 256 : 8192);
+    if (dtype == FB_F32)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)dout, (const uint4*)y,
+                           (const uint4*)x, coef, (uint4*)dx, (uint4*)dy_out, n_vec, cvec, vpg, C);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_tag>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)dout, (const uint4*)y,
+                           (const uint4*)x, coef, (uint4*)dx, (uint4*)dy_out, n_vec, cvec, vpg, C);
+    FB_CHECK_LAUNCH("fb_bn_bwd_apply");
+    return FB_OK;
+}

@@ -1,0 +1,100 @@
+// Shared device/host helpers for libfbengine (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/fb_engine.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+extern thread_local char fb_err_buf[512];
+#define FB_FAIL(code, ...)                                   \
+    do {                                                     \
+        snprintf(fb_err_buf, sizeof(fb_err_buf), __VA_ARGS__); \
+        return (code);                                       \
+    } while (0)
+#define FB_CHECK_LAUNCH(name)                                                                   \
+    do {                                                                                        \
+        hipError_t e_ = hipGetLastError();                                                      \
+        if (e_ != hipSuccess) FB_FAIL(FB_ERR_LAUNCH, "%s: launch failed: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- bf16 <-> f32 (round to nearest even, NaN preserved) ------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+// Element-type traits.  A "chunk" is 16 bytes: 4 f32 or 8 bf16.
+template <typename T> struct ET;
+template <> struct ET<float> {
+    static constexpr int EB = 4, VEC = 4;
+    __device__ static __forceinline__ void unpack(const uint4& v, float* f) {
+        f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+    }
+    __device__ static __forceinline__ uint4 pack(const float* f) {
+        return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    }
+};
+struct bf16_tag {};
+template <> struct ET<bf16_tag> {
+    static constexpr int EB = 2, VEC = 8;
+    __device__ static __forceinline__ void unpack(const uint4& v, float* f) {
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __uint_as_float(w[i] << 16);
+            f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    __device__ static __forceinline__ uint4 pack(const float* f) {
+        unsigned w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (unsigned)f32_to_bf16(f[2 * i]) | ((unsigned)f32_to_bf16(f[2 * i + 1]) << 16);
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+
+// One 16-byte operand chunk per lane for each of A and B -> accumulate into a 16x16 fp32 fragment.
+//   bf16: one v_mfma_f32_16x16x32_bf16 (lane group g = lane>>4 supplies k = 8g..8g+7)
+//   f32 : four v_mfma_f32_16x16x4_f32 (MFMA e sums k = {4g+e}); exact f32 fma chains.
+template <typename T> __device__ __forceinline__ f32x4_t mma_chunk(const uint4& a, const uint4& b, f32x4_t c);
+template <> __device__ __forceinline__ f32x4_t mma_chunk<bf16_tag>(const uint4& a, const uint4& b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4_t mma_chunk<float>(const uint4& a, const uint4& b, f32x4_t c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    return c;
+}
+
+// deterministic block reduction of `NV` values per thread (sum), result valid on thread 0; smem >= NV*nwaves floats
+template <int NV> __device__ __forceinline__ void block_reduce_sum(float (&v)[NV], float* smem) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_xor(v[i], off);
+    }
+    if (lane == 0)
+        for (int i = 0; i < NV; ++i) smem[i * nw + wave] = v[i];
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int i = 0; i < NV; ++i) {
+            float s = 0.f;
+            for (int w = 0; w < nw; ++w) s += smem[i * nw + w];
+            v[i] = s;
+        }
+    __syncthreads();
+}

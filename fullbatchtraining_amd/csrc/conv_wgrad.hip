@@ -1,0 +1,261 @@
+// Weight-gradient convolution on MFMA for gfx950:  dW[co][tap][ci] = sum_p dY[p][co] * X[src(p,tap)][ci]  per chunk.
+//
+// GEMM view: M = co, N = ci, K = pixels.  Both operands arrive pixel-major (NHWC rows), i.e. K is the *strided*
+// dimension, so the MFMA fragments are read transposed out of LDS:
+//   bf16: ds_read_b64_tr_b16 (hardware 4x16 transpose read) -- two reads give the 8 k-values a lane needs
+//   f32 : ds_read_b32 per element (v_mfma_f32_16x16x4_f32 takes one f32 per lane)
+// Every wave owns a 64x64 (co x ci) accumulator tile; the template chooses how the 4 waves are arranged:
+//   <WM=1,WN=1,WK=4>: one 64x64 tile per block, waves split the pixel range (reduced through LDS in fixed order)
+//   <WM=2,WN=2,WK=1>: 128x128 tile per block
+// Grid: x = tile, y = tap, z = group * split_k.  Output: fp32 slabs [group][split][co][tap][ci], no atomics, so the
+// sum order is fixed and identical for the two passes of the finite-difference regulariser.
+#include "common.h"
+
+struct WgradParams {
+    const char* x; const char* dy; float* out;
+    int n_img, Hs, Ws, Cs, Hd, Wd, Cd;
+    int R, S, stride, pad;
+    int imgs_per_group, split_k, px_per_group, px_per_split;
+};
+
+template <typename T> struct WG;
+template <> struct WG<bf16_tag> { static constexpr int PAD = 16; };
+template <> struct WG<float> { static constexpr int PAD = 64; };
+
+// transposed fragment: for channels c0..c0+15 (lane&15) and pixels pb + 8*(lane>>4) .. +7 (bf16) -> one 16-byte chunk
+template <typename T> __device__ __forceinline__ void load_frag_t(const char* tile, int row_bytes, int pb, int c0, int lane, uint4 (&out)[2]);
+template <> __device__ __forceinline__ void load_frag_t<bf16_tag>(const char* tile, int row_bytes, int pb, int c0, int lane, uint4 (&out)[2]) {
+    // 32 pixels x 16 channels -> bf16x8 per lane: k = 8*(lane>>4)+e, e=0..7 ; out[1] unused
+    const int t = lane & 15, g = lane >> 4;
+    const char* a0 = tile + (pb + g * 8 + (t >> 2)) * row_bytes + (c0 + (t & 3) * 4) * 2;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0 + 4 * row_bytes));
+    out[0] = make_uint4(((unsigned)(unsigned short)lo[0]) | ((unsigned)(unsigned short)lo[1] << 16),
+                        ((unsigned)(unsigned short)lo[2]) | ((unsigned)(unsigned short)lo[3] << 16),
+                        ((unsigned)(unsigned short)hi[0]) | ((unsigned)(unsigned short)hi[1] << 16),
+                        ((unsigned)(unsigned short)hi[2]) | ((unsigned)(unsigned short)hi[3] << 16));
+}
+template <> __device__ __forceinline__ void load_frag_t<float>(const char* tile, int row_bytes, int pb, int c0, int lane, uint4 (&out)[2]) {
+    // 32 pixels x 16 channels -> 8 floats per lane: out[h] element e <-> pixel pb + 16h + 4e + (lane>>4)
+    const int t = lane & 15, g = lane >> 4;
+    const char* a0 = tile + (pb + g) * row_bytes + (c0 + t) * 4;
+    unsigned v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = *(const unsigned*)(a0 + 4 * e * row_bytes);
+    out[0] = make_uint4(v[0], v[1], v[2], v[3]);
+    out[1] = make_uint4(v[4], v[5], v[6], v[7]);
+}
+
+template <typename T, int WM, int WN, int WK, int KREP, int NJ>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+    constexpr int EB = ET<T>::EB;
+    constexpr int TM = 64 * WM, TN = 16 * NJ * WN;     // block tile (co x ci); wave tile 64 x 16*NJ
+    constexpr int KPX = 32 * WK * KREP;                // pixels per block K-step
+    constexpr int ROW_A = TM * EB + WG<T>::PAD, ROW_B = TN * EB + WG<T>::PAD;
+    constexpr int CH_A = TM * EB / 16, CH_B = TN * EB / 16;   // 16-byte chunks per row
+    constexpr int LD_A = KPX * CH_A / 256, LD_B = KPX * CH_B / 256;   // chunks per thread
+    static_assert(KPX * CH_A % 256 == 0 && KPX * CH_B % 256 == 0, "tile/threads");
+    constexpr int TILE_BYTES = KPX * (ROW_A + ROW_B);
+    constexpr int RED_BYTES = (WK > 1) ? WK * 64 * 16 * NJ * 4 : 0;
+    constexpr int LDS_BYTES = TILE_BYTES > RED_BYTES ? TILE_BYTES : RED_BYTES;
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    char* tileA = lds;
+    char* tileB = lds + KPX * ROW_A;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
+    const int tiles_n = p.Cs / TN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int tap = blockIdx.y, r = tap / p.S, s = tap % p.S;
+    const int group = blockIdx.z / p.split_k, split = blockIdx.z % p.split_k;
+    const int HWd = p.Hd * p.Wd;
+    const long long gp0 = (long long)group * p.px_per_group;       // first output pixel of the group
+    const int k_begin = split * p.px_per_split;
+    const int k_end = min(k_begin + p.px_per_split, p.px_per_group);
+
+    f32x4_t acc[4][NJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[LD_A], rb[LD_B];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < LD_A; ++i) {
+            const int id = tid + 256 * i, row = id / CH_A, ch = id % CH_A;
+            const int k = k0 + row;
+            ra[i] = make_uint4(0, 0, 0, 0);
+            if (k < k_end) ra[i] = *(const uint4*)(p.dy + ((gp0 + k) * p.Cd + tile_m * TM) * EB + ch * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < LD_B; ++i) {
+            const int id = tid + 256 * i, row = id / CH_B, ch = id % CH_B;
+            const int k = k0 + row;
+            rb[i] = make_uint4(0, 0, 0, 0);
+            if (k < k_end) {
+                const long long gp = gp0 + k;
+                const int n = (int)(gp / HWd), rem = (int)(gp - (long long)n * HWd), oy = rem / p.Wd, ox = rem - oy * p.Wd;
+                const int sy = oy * p.stride - p.pad + r, sx = ox * p.stride - p.pad + s;
+                if ((unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws)
+                    rb[i] = *(const uint4*)(p.x + ((((long long)n * p.Hs + sy) * p.Ws + sx) * p.Cs + tile_n * TN) * EB + ch * 16);
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < LD_A; ++i) { const int id = tid + 256 * i, row = id / CH_A, ch = id % CH_A; *(uint4*)(tileA + row * ROW_A + ch * 16) = ra[i]; }
+#pragma unroll
+        for (int i = 0; i < LD_B; ++i) { const int id = tid + 256 * i, row = id / CH_B, ch = id % CH_B; *(uint4*)(tileB + row * ROW_B + ch * 16) = rb[i]; }
+    };
+
+    if (k_begin < k_end) gload(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += KPX) {
+        __syncthreads();           // previous step's fragment reads are done
+        lstore();
+        __syncthreads();
+        if (k0 + KPX < k_end) gload(k0 + KPX);
+#pragma unroll
+        for (int rep = 0; rep < KREP; ++rep) {
+            const int pb = (wk * KREP + rep) * 32;
+            uint4 af[4][2], bf[NJ][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) load_frag_t<T>(tileA, ROW_A, pb, wm * 64 + i * 16, lane, af[i]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) load_frag_t<T>(tileB, ROW_B, pb, wn * 16 * NJ + j * 16, lane, bf[j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    acc[i][j] = mma_chunk<T>(af[i][0], bf[j][0], acc[i][j]);
+                    if constexpr (EB == 4) acc[i][j] = mma_chunk<T>(af[i][1], bf[j][1], acc[i][j]);
+                }
+        }
+    }
+
+    // ---- output: [group][split][co][tap][ci] -------------------------------------------------------------------------
+    const int taps = p.R * p.S;
+    float* out = p.out + ((long long)(group * p.split_k + split) * p.Cd) * taps * p.Cs;
+    if constexpr (WK > 1) {
+        constexpr int WN_ = 16 * NJ;
+        float* red = (float*)lds;   // [WK][64][16*NJ]
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) red[(wk * 64 + i * 16 + (lane >> 4) * 4 + q) * WN_ + j * 16 + (lane & 15)] = acc[i][j][q];
+        __syncthreads();
+        for (int e = tid; e < 64 * WN_; e += 256) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < WK; ++w) v += red[w * 64 * WN_ + e];
+            const int co = tile_m * TM + e / WN_, ci = tile_n * TN + e % WN_;
+            out[((long long)co * taps + tap) * p.Cs + ci] = v;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = tile_m * TM + wm * 64 + i * 16 + (lane >> 4) * 4 + q;
+                    const int ci = tile_n * TN + wn * 16 * NJ + j * 16 + (lane & 15);
+                    out[((long long)co * taps + tap) * p.Cs + ci] = acc[i][j][q];
+                }
+    }
+}
+
+extern "C" int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream) {
+    if (!a || !a->x || !a->dy || !a->dw_partial) FB_FAIL(FB_ERR_ARG, "fb_conv2d_wgrad: null pointer");
+    if (a->Cs % 32 != 0 || a->Cd % 64 != 0) FB_FAIL(FB_ERR_SHAPE, "fb_conv2d_wgrad: Cs=%d must be a multiple of 32, Cd=%d of 64", a->Cs, a->Cd);
+    if (a->n_img % a->imgs_per_group != 0) FB_FAIL(FB_ERR_SHAPE, "fb_conv2d_wgrad: n_img %% imgs_per_group != 0");
+    if (a->split_k < 1) FB_FAIL(FB_ERR_ARG, "fb_conv2d_wgrad: split_k < 1");
+    WgradParams p;
+    p.x = (const char*)a->x; p.dy = (const char*)a->dy; p.out = a->dw_partial;
+    p.n_img = a->n_img; p.Hs = a->Hs; p.Ws = a->Ws; p.Cs = a->Cs; p.Hd = a->Hd; p.Wd = a->Wd; p.Cd = a->Cd;
+    p.R = a->R; p.S = a->S; p.stride = a->stride; p.pad = a->pad;
+    p.imgs_per_group = a->imgs_per_group; p.split_k = a->split_k;
+    p.px_per_group = a->imgs_per_group * a->Hd * a->Wd;
+    const int n_groups = a->n_img / a->imgs_per_group;
+    hipStream_t st = (hipStream_t)stream;
+    const bool big = (a->Cs % 128 == 0) && (a->Cd % 128 == 0) && (a->Cs >= 256 || a->Cd >= 256);
+    const int kstep = big ? (a->dtype == FB_F32 ? 32 : 64) : 128;
+    p.px_per_split = (int)(ceil_div64(ceil_div64(p.px_per_group, a->split_k), kstep) * kstep);
+    if ((long long)(a->split_k - 1) * p.px_per_split >= p.px_per_group && a->split_k > 1)
+        FB_FAIL(FB_ERR_ARG, "fb_conv2d_wgrad: split_k=%d leaves empty slices for %d pixels", a->split_k, p.px_per_group);
+    const int taps = a->R * a->S;
+    if (big) {
+        dim3 grid((a->Cd / 128) * (a->Cs / 128), taps, n_groups * a->split_k);
+        if (a->dtype == FB_F32) hipLaunchKernelGGL((conv_wgrad_kernel<float, 2, 2, 1, 1, 4>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_tag, 2, 2, 1, 2, 4>), grid, dim3(256), 0, st, p);
+    } else if (a->Cs % 64 == 0) {
+        dim3 grid((a->Cd / 64) * (a->Cs / 64), taps, n_groups * a->split_k);
+        if (a->dtype == FB_F32) hipLaunchKernelGGL((conv_wgrad_kernel<float, 1, 1, 4, 1, 4>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_tag, 1, 1, 4, 1, 4>), grid, dim3(256), 0, st, p);
+    } else {   // Cs multiple of 32 only (pre-gathered stem patches): 64 x 32 tiles
+        dim3 grid((a->Cd / 64) * (a->Cs / 32), taps, n_groups * a->split_k);
+        if (a->dtype == FB_F32) hipLaunchKernelGGL((conv_wgrad_kernel<float, 1, 1, 4, 1, 2>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_tag, 1, 1, 4, 1, 2>), grid, dim3(256), 0, st, p);
+    }
+    FB_CHECK_LAUNCH("fb_conv2d_wgrad");
+    return FB_OK;
+}
+
+// ---- split-K slab reduction + channel-padding drop -------------------------------------------------------------------
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long long out_group_stride,
+                                    int split_k, long long rows, int Cs_pad, int Cs_real) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over rows*Cs_real
+    const int g = blockIdx.y;
+    if (idx >= rows * Cs_real) return;
+    const long long row = idx / Cs_real; const int ci = (int)(idx - row * Cs_real);
+    const float* src = part + ((long long)g * split_k) * rows * Cs_pad + row * Cs_pad + ci;
+    float v = 0.f;
+    for (int s = 0; s < split_k; ++s) v += src[(long long)s * rows * Cs_pad];
+    out[(long long)g * out_group_stride + idx] = v;
+}
+
+extern "C" int fb_wgrad_reduce(const float* dw_partial, float* out, int64_t out_group_stride, int32_t n_groups, int32_t split_k,
+                               int32_t Cd, int32_t taps, int32_t Cs_pad, int32_t Cs_real, void* stream) {
+    if (!dw_partial || !out) FB_FAIL(FB_ERR_ARG, "fb_wgrad_reduce: null pointer");
+    const long long rows = (long long)Cd * taps, total = rows * Cs_real;
+    dim3 grid((unsigned)ceil_div64(total, 256), n_groups);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, dw_partial, out, (long long)out_group_stride,
+                       split_k, rows, Cs_pad, Cs_real);
+    FB_CHECK_LAUNCH("fb_wgrad_reduce");
+    return FB_OK;
+}
+
+// ---- master KRSC fp32 -> compute copies ------------------------------------------------------------------------------
+template <typename T>
+__global__ void weight_prep_kernel(const float* __restrict__ master, long long wset_stride_in, int Cout, int taps, int Cin_real,
+                                   int Cin_pad, T* __restrict__ w_fwd, T* __restrict__ w_dgrad) {
+    const long long per_set = (long long)Cout * taps * Cin_pad;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ws = blockIdx.y;
+    if (idx >= per_set) return;
+    const int ci = (int)(idx % Cin_pad); const long long rt = idx / Cin_pad; const int t = (int)(rt % taps); const int co = (int)(rt / taps);
+    float v = 0.f;
+    if (ci < Cin_real) v = master[(long long)ws * wset_stride_in + ((long long)co * taps + t) * Cin_real + ci];
+    T o;
+    if constexpr (sizeof(T) == 4) o = v; else o = f32_to_bf16(v);
+    w_fwd[(long long)ws * per_set + idx] = o;
+    if (w_dgrad) w_dgrad[(long long)ws * per_set + ((long long)ci * taps + t) * Cout + co] = o;
+}
+
+extern "C" int fb_weight_prep(const float* master, int64_t wset_stride_in, int32_t n_wsets, int32_t Cout, int32_t taps, int32_t Cin_real,
+                              int32_t Cin_pad, void* w_fwd, void* w_dgrad, int32_t dtype, void* stream) {
+    if (!master || !w_fwd) FB_FAIL(FB_ERR_ARG, "fb_weight_prep: null pointer");
+    const long long per_set = (long long)Cout * taps * Cin_pad;
+    dim3 grid((unsigned)ceil_div64(per_set, 256), n_wsets);
+    if (dtype == FB_F32)
+        hipLaunchKernelGGL((weight_prep_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, master, (long long)wset_stride_in, Cout,
+                           taps, Cin_real, Cin_pad, (float*)w_fwd, (float*)w_dgrad);
+    else
+        hipLaunchKernelGGL((weight_prep_kernel<unsigned short>), grid, dim3(256), 0, (hipStream_t)stream, master,
+                           (long long)wset_stride_in, Cout, taps, Cin_real, Cin_pad, (unsigned short*)w_fwd, (unsigned short*)w_dgrad);
+    FB_CHECK_LAUNCH("fb_weight_prep");
+    return FB_OK;
+}

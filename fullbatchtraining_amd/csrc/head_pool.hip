@@ -1,0 +1,271 @@
+// Pooling layers and the classifier head (global average pool, fc, log-softmax, NLL, argmax) with explicit backward.
+// These are small, HBM/latency-bound kernels; the loss/accuracy reductions are sequential per chunk so their order is
+// fixed (bit-reproducible).
+#include "common.h"
+
+// ---- AvgPool2d(2,2) forward (shortcut 'C', reference resnets.py:149); backward is fused into the dgrad epilogue ------
+template <typename T>
+__global__ void avgpool2_fwd_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int n_img, int H, int W, int cvec) {
+    constexpr int V = ET<T>::VEC;
+    const int Ho = H / 2, Wo = W / 2;
+    const long long total = (long long)n_img * Ho * Wo * cvec;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % cvec); long long r = i / cvec;
+        const int ox = (int)(r % Wo); r /= Wo; const int oy = (int)(r % Ho); const long long n = r / Ho;
+        float a[V], acc[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                ET<T>::unpack(x[(((n * H + 2 * oy + dy) * W) + 2 * ox + dx) * cvec + cv], a);
+#pragma unroll
+                for (int k = 0; k < V; ++k) acc[k] += a[k];
+            }
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] *= 0.25f;
+        y[i] = ET<T>::pack(acc);
+    }
+}
+
+extern "C" int fb_avgpool2_fwd(const void* x, void* y, int32_t n_img, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
+    if (!x || !y) FB_FAIL(FB_ERR_ARG, "fb_avgpool2_fwd: null pointer");
+    if ((H & 1) || (W & 1)) FB_FAIL(FB_ERR_SHAPE, "fb_avgpool2_fwd: odd spatial size");
+    const int V = dtype == FB_F32 ? 4 : 8, cvec = C / V;
+    const long long total = (long long)n_img * (H / 2) * (W / 2) * cvec;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (dtype == FB_F32) hipLaunchKernelGGL((avgpool2_fwd_kernel<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (uint4*)y, n_img, H, W, cvec);
+    else hipLaunchKernelGGL((avgpool2_fwd_kernel<bf16_tag>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (uint4*)y, n_img, H, W, cvec);
+    FB_CHECK_LAUNCH("fb_avgpool2_fwd");
+    return FB_OK;
+}
+
+// ---- MaxPool2d(3, stride 2, pad 1) of the 'standard' stem (reference resnets.py:78) ------------------------------------
+template <typename T>
+__global__ void maxpool3s2_fwd_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int n_img, int H, int W, int cvec) {
+    constexpr int V = ET<T>::VEC;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long long total = (long long)n_img * Ho * Wo * cvec;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % cvec); long long r = i / cvec;
+        const int ox = (int)(r % Wo); r /= Wo; const int oy = (int)(r % Ho); const long long n = r / Ho;
+        float a[V], m[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) m[k] = -INFINITY;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int sy = 2 * oy + dy, sx = 2 * ox + dx;
+                if ((unsigned)sy >= (unsigned)H || (unsigned)sx >= (unsigned)W) continue;
+                ET<T>::unpack(x[((n * H + sy) * W + sx) * cvec + cv], a);
+#pragma unroll
+                for (int k = 0; k < V; ++k) m[k] = fmaxf(m[k], a[k]);
+            }
+        y[i] = ET<T>::pack(m);
+    }
+}
+// backward: dx[p] = sum over windows containing p whose argmax (first maximum in row-major window order, torch CPU
+// max_pool2d semantics) is p.
+template <typename T>
+__global__ void maxpool3s2_bwd_kernel(const uint4* __restrict__ x, const uint4* __restrict__ dy, uint4* __restrict__ dx, int n_img, int H,
+                                      int W, int cvec) {
+    constexpr int V = ET<T>::VEC;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long long total = (long long)n_img * H * W * cvec;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % cvec); long long r = i / cvec;
+        const int px = (int)(r % W); r /= W; const int py = (int)(r % H); const long long n = r / H;
+        float acc[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] = 0.f;
+        for (int oy = (py - 1 + 1) / 2; oy <= (py + 1) / 2 && oy < Ho; ++oy)
+            for (int ox = (px - 1 + 1) / 2; ox <= (px + 1) / 2 && ox < Wo; ++ox) {
+                if (oy < 0 || ox < 0) continue;
+                // argmax of window (oy, ox)
+                float best[V]; int bidx[V];
+#pragma unroll
+                for (int k = 0; k < V; ++k) { best[k] = -INFINITY; bidx[k] = -1; }
+                for (int dyy = -1; dyy <= 1; ++dyy)
+                    for (int dxx = -1; dxx <= 1; ++dxx) {
+                        const int sy = 2 * oy + dyy, sx = 2 * ox + dxx;
+                        if ((unsigned)sy >= (unsigned)H || (unsigned)sx >= (unsigned)W) continue;
+                        float a[V];
+                        ET<T>::unpack(x[((n * H + sy) * W + sx) * cvec + cv], a);
+#pragma unroll
+                        for (int k = 0; k < V; ++k) if (a[k] > best[k] || bidx[k] < 0) { best[k] = a[k]; bidx[k] = sy * W + sx; }
+                    }
+                float g[V];
+                ET<T>::unpack(dy[((n * Ho + oy) * Wo + ox) * cvec + cv], g);
+#pragma unroll
+                for (int k = 0; k < V; ++k) if (bidx[k] == py * W + px) acc[k] += g[k];
+            }
+        dx[i] = ET<T>::pack(acc);
+    }
+}
+
+extern "C" int fb_maxpool3s2_fwd(const void* x, void* y, int32_t n_img, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
+    if (!x || !y) FB_FAIL(FB_ERR_ARG, "fb_maxpool3s2_fwd: null pointer");
+    const int V = dtype == FB_F32 ? 4 : 8, cvec = C / V;
+    const long long total = (long long)n_img * ((H + 1) / 2) * ((W + 1) / 2) * cvec;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (dtype == FB_F32) hipLaunchKernelGGL((maxpool3s2_fwd_kernel<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (uint4*)y, n_img, H, W, cvec);
+    else hipLaunchKernelGGL((maxpool3s2_fwd_kernel<bf16_tag>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (uint4*)y, n_img, H, W, cvec);
+    FB_CHECK_LAUNCH("fb_maxpool3s2_fwd");
+    return FB_OK;
+}
+extern "C" int fb_maxpool3s2_bwd(const void* x, const void* dy, void* dx, int32_t n_img, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                                 void* stream) {
+    if (!x || !dy || !dx) FB_FAIL(FB_ERR_ARG, "fb_maxpool3s2_bwd: null pointer");
+    const int V = dtype == FB_F32 ? 4 : 8, cvec = C / V;
+    const long long total = (long long)n_img * H * W * cvec;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (dtype == FB_F32) hipLaunchKernelGGL((maxpool3s2_bwd_kernel<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (const uint4*)dy, (uint4*)dx, n_img, H, W, cvec);
+    else hipLaunchKernelGGL((maxpool3s2_bwd_kernel<bf16_tag>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (const uint4*)dy, (uint4*)dx, n_img, H, W, cvec);
+    FB_CHECK_LAUNCH("fb_maxpool3s2_bwd");
+    return FB_OK;
+}
+
+// ---- global average pool -> fp32 features ------------------------------------------------------------------------------
+template <typename T>
+__global__ void head_pool_kernel(const uint4* __restrict__ a, float* __restrict__ feat, int n_img, int HW, int cvec) {
+    constexpr int V = ET<T>::VEC;
+    const long long total = (long long)n_img * cvec;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cv = (int)(i % cvec); const long long n = i / cvec;
+    float acc[V], v[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.f;
+    for (int p = 0; p < HW; ++p) {
+        ET<T>::unpack(a[(n * HW + p) * cvec + cv], v);
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] += v[k];
+    }
+    const float inv = 1.f / (float)HW;
+#pragma unroll
+    for (int k = 0; k < V; ++k) feat[n * (long long)cvec * V + cv * V + k] = acc[k] * inv;
+}
+
+extern "C" int fb_head_pool(const void* a, float* feat, int32_t n_img, int32_t HW, int32_t C, int32_t dtype, void* stream) {
+    if (!a || !feat) FB_FAIL(FB_ERR_ARG, "fb_head_pool: null pointer");
+    const int V = dtype == FB_F32 ? 4 : 8, cvec = C / V;
+    const long long total = (long long)n_img * cvec;
+    if (dtype == FB_F32) hipLaunchKernelGGL((head_pool_kernel<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)a, feat, n_img, HW, cvec);
+    else hipLaunchKernelGGL((head_pool_kernel<bf16_tag>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)a, feat, n_img, HW, cvec);
+    FB_CHECK_LAUNCH("fb_head_pool");
+    return FB_OK;
+}
+
+// ---- fc + log-softmax + NLL(mean) + argmax ------------------------------------------------------------------------------
+// grid (imgs_per_group, n_groups) for the logits; one wave per image computes all classes.
+__global__ void head_logits_kernel(const float* __restrict__ feat, const float* __restrict__ W, const float* __restrict__ b, long long pstride,
+                                   float* __restrict__ logits, int ipg, int C, int classes) {
+    const int n = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
+    const float* f = feat + ((long long)g * ipg + n) * C;
+    const float* Wg = W + (long long)g * pstride; const float* bg = b + (long long)g * pstride;
+    for (int j = 0; j < classes; ++j) {
+        float acc = 0.f;
+        for (int c = lane; c < C; c += 64) acc += f[c] * Wg[(long long)j * C + c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if (lane == 0) logits[((long long)g * ipg + n) * classes + j] = acc + bg[j];
+    }
+}
+// one block per group: per-image log-softmax (thread per image), then a fixed-order sum of the per-image losses.
+__global__ void head_loss_kernel(const float* __restrict__ logits, const long long* __restrict__ labels, float* __restrict__ dlogits,
+                                 float* __restrict__ loss, float* __restrict__ correct, int ipg, int classes) {
+    extern __shared__ float sm[];   // [ipg] losses, [ipg] corrects
+    const int g = blockIdx.x;
+    for (int n = threadIdx.x; n < ipg; n += blockDim.x) {
+        const float* z = logits + ((long long)g * ipg + n) * classes;
+        float* dz = dlogits + ((long long)g * ipg + n) * classes;
+        const int label = (int)labels[(long long)g * ipg + n];
+        float m = z[0]; int am = 0;
+        for (int j = 1; j < classes; ++j) if (z[j] > m) { m = z[j]; am = j; }   // first maximum, as torch.argmax
+        float se = 0.f;
+        for (int j = 0; j < classes; ++j) se += expf(z[j] - m);
+        const float lse = logf(se);
+        const float inv_n = 1.f / (float)ipg;
+        for (int j = 0; j < classes; ++j) dz[j] = (expf(z[j] - m - lse) - (j == label ? 1.f : 0.f)) * inv_n;
+        sm[n] = -(z[label] - m - lse);
+        sm[ipg + n] = (am == label) ? 1.f : 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float l = 0.f, c = 0.f;
+        for (int n = 0; n < ipg; ++n) { l += sm[n]; c += sm[ipg + n]; }
+        loss[g] = l / (float)ipg; correct[g] = c;
+    }
+}
+
+extern "C" int fb_head_loss(const float* feat, const float* fc_w, const float* fc_b, int64_t param_group_stride, const int64_t* labels,
+                            float* logits, float* dlogits, float* loss, float* correct, int32_t n_groups, int32_t imgs_per_group,
+                            int32_t C, int32_t classes, void* stream) {
+    if (!feat || !fc_w || !fc_b || !labels || !logits || !dlogits || !loss || !correct) FB_FAIL(FB_ERR_ARG, "fb_head_loss: null pointer");
+    hipLaunchKernelGGL(head_logits_kernel, dim3(imgs_per_group, n_groups), dim3(64), 0, (hipStream_t)stream, feat, fc_w, fc_b,
+                       (long long)param_group_stride, logits, imgs_per_group, C, classes);
+    hipLaunchKernelGGL(head_loss_kernel, dim3(n_groups), dim3(128), (size_t)2 * imgs_per_group * sizeof(float), (hipStream_t)stream, logits,
+                       (const long long*)labels, dlogits, loss, correct, imgs_per_group, classes);
+    FB_CHECK_LAUNCH("fb_head_loss");
+    return FB_OK;
+}
+
+// ---- head backward ---------------------------------------------------------------------------------------------------
+// dW[g][j][c] = sum_n dlogits[n][j]*feat[n][c] (fixed order over n); db[g][j] = sum_n dlogits[n][j]
+__global__ void head_bwd_w_kernel(const float* __restrict__ feat, const float* __restrict__ dlogits, float* __restrict__ dW, float* __restrict__ db,
+                                  long long gstride, int ipg, int C, int classes) {
+    const int g = blockIdx.y;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over classes*C
+    if (idx < (long long)classes * C) {
+        const int j = (int)(idx / C), c = (int)(idx % C);
+        float acc = 0.f;
+        for (int n = 0; n < ipg; ++n) acc += dlogits[((long long)g * ipg + n) * classes + j] * feat[((long long)g * ipg + n) * C + c];
+        dW[(long long)g * gstride + idx] = acc;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < classes) {
+        for (int j = threadIdx.x; j < classes; j += blockDim.x) {
+            float acc = 0.f;
+            for (int n = 0; n < ipg; ++n) acc += dlogits[((long long)g * ipg + n) * classes + j];
+            db[(long long)g * gstride + j] = acc;
+        }
+    }
+}
+template <typename T>
+__global__ void head_bwd_a_kernel(const float* __restrict__ dlogits, const float* __restrict__ W, long long pstride, uint4* __restrict__ d_a,
+                                  int ipg, int HW, int C, int classes) {
+    constexpr int V = ET<T>::VEC;
+    const int cvec = C / V;
+    const long long n = blockIdx.x;   // image
+    const int g = (int)(n / ipg);
+    const float* Wg = W + (long long)g * pstride;
+    const float* dz = dlogits + n * classes;
+    for (int cv = threadIdx.x; cv < cvec; cv += blockDim.x) {
+        float acc[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] = 0.f;
+        for (int j = 0; j < classes; ++j) {
+            const float d = dz[j];
+#pragma unroll
+            for (int k = 0; k < V; ++k) acc[k] += d * Wg[(long long)j * C + cv * V + k];
+        }
+        const float inv = 1.f / (float)HW;
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] *= inv;
+        const uint4 o = ET<T>::pack(acc);
+        for (int p = 0; p < HW; ++p) d_a[(n * HW + p) * cvec + cv] = o;
+    }
+}
+
+extern "C" int fb_head_bwd(const float* feat, const float* dlogits, const float* fc_w, int64_t param_group_stride, float* dfc_w, float* dfc_b,
+                           int64_t grad_group_stride, void* d_a, int32_t n_groups, int32_t imgs_per_group, int32_t HW, int32_t C,
+                           int32_t classes, int32_t dtype, void* stream) {
+    if (!feat || !dlogits || !fc_w || !dfc_w || !dfc_b || !d_a) FB_FAIL(FB_ERR_ARG, "fb_head_bwd: null pointer");
+    const long long total = (long long)classes * C;
+    hipLaunchKernelGGL(head_bwd_w_kernel, dim3((unsigned)((total + 255) / 256), n_groups), dim3(256), 0, (hipStream_t)stream, feat, dlogits, dfc_w,
+                       dfc_b, (long long)grad_group_stride, imgs_per_group, C, classes);
+    const int n_img = n_groups * imgs_per_group;
+    if (dtype == FB_F32) hipLaunchKernelGGL((head_bwd_a_kernel<float>), dim3(n_img), dim3(128), 0, (hipStream_t)stream, dlogits, fc_w, (long long)param_group_stride, (uint4*)d_a, imgs_per_group, HW, C, classes);
+    else hipLaunchKernelGGL((head_bwd_a_kernel<bf16_tag>), dim3(n_img), dim3(128), 0, (hipStream_t)stream, dlogits, fc_w, (long long)param_group_stride, (uint4*)d_a, imgs_per_group, HW, C, classes);
+    FB_CHECK_LAUNCH("fb_head_bwd");
+    return FB_OK;
+}

@@ -1,0 +1,233 @@
+// Fused multi-tensor passes over the flat fp32 parameter / gradient arena (P ~ 11.17 M floats for ResNet-18).
+// Pure HBM streaming: float4 lanes, grid-stride, FB_MT_BLOCKS blocks; every reduction is two-stage with a fixed
+// order.  Replaces the torch._foreach_* / pow(2).sum() / SGD loops of reference training.py:45-47,162,198-211,
+// modules.py:215-240 and torch.optim.SGD.step.
+#include "common.h"
+
+static inline int mt_blocks(int64_t n) {
+    const int64_t b = (n / 4 + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > FB_MT_BLOCKS ? FB_MT_BLOCKS : b));
+}
+
+// second stage: out[g*NV + v] = sum_b ws[(g*NV+v)*FB_MT_BLOCKS + b] in double, fixed order
+__global__ void mt_finalize_kernel(const float* __restrict__ ws, float* __restrict__ out, int nblocks, int count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += (double)ws[(long long)i * FB_MT_BLOCKS + b];
+    out[i] = (float)s;
+}
+
+// ---- |scale*x[g]|^2 -----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mt_sqnorm_kernel(const float* __restrict__ x, long long gstride, long long n, float scale, float* __restrict__ ws) {
+    __shared__ float sm[8];
+    const int g = blockIdx.y;
+    const float* xg = x + (long long)g * gstride;
+    float acc[1] = {0.f};
+    const long long n4 = n / 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 v = ((const float4*)xg)[i];
+        const float a = v.x * scale, b = v.y * scale, c = v.z * scale, d = v.w * scale;
+        acc[0] += a * a + b * b + c * c + d * d;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) for (long long i = n4 * 4; i < n; ++i) { const float a = xg[i] * scale; acc[0] += a * a; }
+    block_reduce_sum<1>(acc, sm);
+    if (threadIdx.x == 0) ws[(long long)g * FB_MT_BLOCKS + blockIdx.x] = acc[0];
+}
+
+extern "C" int fb_mt_sqnorm(const float* x, int64_t group_stride, int32_t n_groups, int64_t n, float scale, float* out, float* ws, void* stream) {
+    if (!x || !out || !ws) FB_FAIL(FB_ERR_ARG, "fb_mt_sqnorm: null pointer");
+    if (((uintptr_t)x & 15) || (group_stride & 3)) FB_FAIL(FB_ERR_ARG, "fb_mt_sqnorm: 16-byte alignment required");
+    const int nb = mt_blocks(n);
+    hipLaunchKernelGGL(mt_sqnorm_kernel, dim3(nb, n_groups), dim3(256), 0, (hipStream_t)stream, x, (long long)group_stride, (long long)n, scale, ws);
+    hipLaunchKernelGGL(mt_finalize_kernel, dim3((n_groups + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, out, nb, n_groups);
+    FB_CHECK_LAUNCH("fb_mt_sqnorm");
+    return FB_OK;
+}
+
+// ---- running mean over the chunks of a group batch (+ fused per-chunk squared norms) --------------------------------------
+// Up to 8 chunks per launch are folded into the running mean in registers (static unroll keeps the per-chunk norm
+// accumulators out of scratch); the host wrapper walks larger batches 8 at a time.
+template <bool SQ>
+__global__ __launch_bounds__(256) void mt_accumulate_kernel(float* __restrict__ avg, const float* __restrict__ g, long long gstride, int n_groups,
+                                                            long long n, int counter0, float* __restrict__ ws) {
+    constexpr int NG = 8;
+    __shared__ float sm[8 * NG];
+    const long long n4 = n / 4;
+    float sq[NG], inv[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) { sq[j] = 0.f; inv[j] = (float)(1.0 / (double)(counter0 + j + 1)); }
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 a = ((float4*)avg)[i];
+#pragma unroll
+        for (int j = 0; j < NG; ++j)
+            if (j < n_groups) {
+                const float4 v = ((const float4*)(g + (long long)j * gstride))[i];
+                if (SQ) sq[j] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                a.x += (v.x - a.x) * inv[j]; a.y += (v.y - a.y) * inv[j]; a.z += (v.z - a.z) * inv[j]; a.w += (v.w - a.w) * inv[j];
+            }
+        ((float4*)avg)[i] = a;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (long long i = n4 * 4; i < n; ++i) {
+            float a = avg[i];
+#pragma unroll
+            for (int j = 0; j < NG; ++j)
+                if (j < n_groups) {
+                    const float v = g[(long long)j * gstride + i];
+                    if (SQ) sq[j] += v * v;
+                    a += (v - a) * inv[j];
+                }
+            avg[i] = a;
+        }
+    if (SQ) {
+        block_reduce_sum<NG>(sq, sm);
+        if (threadIdx.x == 0)
+#pragma unroll
+            for (int j = 0; j < NG; ++j)
+                if (j < n_groups) ws[(long long)j * FB_MT_BLOCKS + blockIdx.x] = sq[j];
+    }
+}
+
+extern "C" int fb_mt_accumulate(float* avg, const float* g, int64_t group_stride, int32_t n_groups, int64_t n, int32_t counter0, float* sq_out,
+                                float* ws, void* stream) {
+    if (!avg || !g) FB_FAIL(FB_ERR_ARG, "fb_mt_accumulate: null pointer");
+    if (sq_out && !ws) FB_FAIL(FB_ERR_ARG, "fb_mt_accumulate: workspace required for norms");
+    if (((uintptr_t)avg & 15) || ((uintptr_t)g & 15) || (group_stride & 3)) FB_FAIL(FB_ERR_ARG, "fb_mt_accumulate: 16-byte alignment required");
+    const int nb = mt_blocks(n);
+    for (int j0 = 0; j0 < n_groups; j0 += 8) {
+        const int ng = n_groups - j0 < 8 ? n_groups - j0 : 8;
+        const float* gj = g + (long long)j0 * group_stride;
+        if (sq_out)
+            hipLaunchKernelGGL((mt_accumulate_kernel<true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, avg, gj, (long long)group_stride, ng,
+                               (long long)n, counter0 + j0, ws + (long long)j0 * FB_MT_BLOCKS);
+        else
+            hipLaunchKernelGGL((mt_accumulate_kernel<false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, avg, gj, (long long)group_stride, ng,
+                               (long long)n, counter0 + j0, ws);
+    }
+    if (sq_out) hipLaunchKernelGGL(mt_finalize_kernel, dim3((n_groups + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, sq_out, nb, n_groups);
+    FB_CHECK_LAUNCH("fb_mt_accumulate");
+    return FB_OK;
+}
+
+// ---- finite-difference perturbation: theta[g] = theta0 + sign*eps_n[g]*(s*g[g]) -------------------------------------------
+__global__ void mt_epsn_kernel(const float* __restrict__ vnorm2, float eps, float* __restrict__ eps_n, int n_groups) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n_groups) eps_n[g] = eps / sqrtf(vnorm2[g]);
+}
+__global__ __launch_bounds__(256) void mt_fd_perturb_kernel(const float* __restrict__ theta0, const float* __restrict__ g, long long gstride,
+                                                            long long n, float s, float sign, const float* __restrict__ eps_n,
+                                                            float* __restrict__ out) {
+    const int grp = blockIdx.y;
+    const float alpha = sign * eps_n[grp];
+    const float* gg = g + (long long)grp * gstride; float* og = out + (long long)grp * gstride;
+    const long long n4 = n / 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 t = ((const float4*)theta0)[i], v = ((const float4*)gg)[i];
+        ((float4*)og)[i] = make_float4(t.x + alpha * (s * v.x), t.y + alpha * (s * v.y), t.z + alpha * (s * v.z), t.w + alpha * (s * v.w));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) for (long long i = n4 * 4; i < n; ++i) og[i] = theta0[i] + alpha * (s * gg[i]);
+}
+
+extern "C" int fb_mt_fd_perturb(const float* theta0, const float* g, int64_t group_stride, int32_t n_groups, int64_t n, float s, float eps,
+                                float sign, const float* vnorm2, float* eps_n, float* theta_out, void* stream) {
+    if (!theta0 || !g || !vnorm2 || !eps_n || !theta_out) FB_FAIL(FB_ERR_ARG, "fb_mt_fd_perturb: null pointer");
+    hipLaunchKernelGGL(mt_epsn_kernel, dim3((n_groups + 63) / 64), dim3(64), 0, (hipStream_t)stream, vnorm2, eps, eps_n, n_groups);
+    hipLaunchKernelGGL(mt_fd_perturb_kernel, dim3(mt_blocks(n), n_groups), dim3(256), 0, (hipStream_t)stream, theta0, g, (long long)group_stride,
+                       (long long)n, s, sign, eps_n, theta_out);
+    FB_CHECK_LAUNCH("fb_mt_fd_perturb");
+    return FB_OK;
+}
+
+// ---- vhp = (ga-gb)/eps_n ; gt = g + cf*vhp ; running mean ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mt_fd_combine_kernel(float* __restrict__ avg, const float* __restrict__ g, const float* __restrict__ ga,
+                                                            const float* __restrict__ gb, long long gstride, int n_groups, long long n,
+                                                            const float* __restrict__ eps_n, float cf, int counter0) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float a = avg[i];
+        for (int j = 0; j < n_groups; ++j) {
+            const long long o = (long long)j * gstride + i;
+            const float vhp = (ga[o] - gb[o]) / eps_n[j];
+            const float gt = g[o] + cf * vhp;
+            a += (gt - a) * (float)(1.0 / (double)(counter0 + j + 1));
+        }
+        avg[i] = a;
+    }
+}
+
+extern "C" int fb_mt_fd_combine_accumulate(float* avg, const float* g, const float* ga, const float* gb, int64_t group_stride, int32_t n_groups,
+                                           int64_t n, const float* eps_n, float cf, int32_t counter0, void* stream) {
+    if (!avg || !g || !ga || !gb || !eps_n) FB_FAIL(FB_ERR_ARG, "fb_mt_fd_combine_accumulate: null pointer");
+    const int64_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(mt_fd_combine_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, (hipStream_t)stream, avg, g, ga, gb,
+                       (long long)group_stride, n_groups, (long long)n, eps_n, cf, counter0);
+    FB_CHECK_LAUNCH("fb_mt_fd_combine_accumulate");
+    return FB_OK;
+}
+
+// ---- |a|^2 and |b|^2 ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mt_norms2_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, float* __restrict__ ws) {
+    __shared__ float sm[16];
+    float acc[2] = {0.f, 0.f};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float x = a[i]; acc[0] += x * x;
+        if (b) { const float y = b[i]; acc[1] += y * y; }
+    }
+    block_reduce_sum<2>(acc, sm);
+    if (threadIdx.x == 0) { ws[blockIdx.x] = acc[0]; ws[FB_MT_BLOCKS + blockIdx.x] = acc[1]; }
+}
+
+extern "C" int fb_mt_norms2(const float* a, const float* b, int64_t n, float* out, float* ws, void* stream) {
+    if (!a || !out || !ws) FB_FAIL(FB_ERR_ARG, "fb_mt_norms2: null pointer");
+    const int64_t want = (n + 255) / 256;
+    const int nb = (int)(want < 1 ? 1 : (want > FB_MT_BLOCKS ? FB_MT_BLOCKS : want));
+    hipLaunchKernelGGL(mt_norms2_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, b, (long long)n, ws);
+    hipLaunchKernelGGL(mt_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ws, out, nb, 2);
+    FB_CHECK_LAUNCH("fb_mt_norms2");
+    return FB_OK;
+}
+
+// ---- clip + SGD (weight decay, momentum, dampening, Nesterov) ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void mt_clip_sgd_kernel(float* __restrict__ theta, float* __restrict__ grad, float* __restrict__ mom, long long n,
+                                                          const float* __restrict__ gnorm2, float grad_clip, float lr, float wd, float mu,
+                                                          float damp, int nesterov, int first) {
+    float coef = 1.f;
+    if (grad_clip >= 0.f) {
+        const float norm = sqrtf(gnorm2[0]);
+        if (norm > grad_clip) coef = grad_clip / (norm + 1e-6f);
+    }
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float p = theta[i];
+        float gr = grad[i];
+        if (coef != 1.f) { gr *= coef; grad[i] = gr; }
+        float d = gr + wd * p;
+        if (mu != 0.f) {
+            const float buf = first ? d : mu * mom[i] + (1.f - damp) * d;
+            mom[i] = buf;
+            d = nesterov ? d + mu * buf : buf;
+        }
+        theta[i] = p - lr * d;
+    }
+}
+
+extern "C" int fb_mt_clip_sgd(float* theta, float* grad, float* mom, int64_t n, const float* gnorm2, float grad_clip, float lr,
+                              float weight_decay, float momentum, float dampening, int32_t nesterov, int32_t first_step, void* stream) {
+    if (!theta || !grad || (!mom && momentum != 0.f)) FB_FAIL(FB_ERR_ARG, "fb_mt_clip_sgd: null pointer");
+    if (grad_clip >= 0.f && !gnorm2) FB_FAIL(FB_ERR_ARG, "fb_mt_clip_sgd: clipping needs the device norm");
+    const int64_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(mt_clip_sgd_kernel, dim3((unsigned)(nb < 4096 ? (nb < 1 ? 1 : nb) : 4096)), dim3(256), 0, (hipStream_t)stream, theta, grad, mom,
+                       (long long)n, gnorm2, grad_clip, lr, weight_decay, momentum, dampening, nesterov, first_step);
+    FB_CHECK_LAUNCH("fb_mt_clip_sgd");
+    return FB_OK;
+}
+
+__global__ void mt_scale_kernel(float* __restrict__ x, long long n, float a) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) x[i] *= a;
+}
+extern "C" int fb_mt_scale(float* x, int64_t n, float a, void* stream) {
+    if (!x) FB_FAIL(FB_ERR_ARG, "fb_mt_scale: null pointer");
+    const int64_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(mt_scale_kernel, dim3((unsigned)(nb < 4096 ? (nb < 1 ? 1 : nb) : 4096)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, a);
+    FB_CHECK_LAUNCH("fb_mt_scale");
+    return FB_OK;
+}

@@ -1,0 +1,153 @@
+/* fb_engine.h -- C ABI of libfbengine.so, the MI355X (gfx950) device side of the full-batch GD hot path.
+ *
+ * The reference (JonasGeiping/fullbatchtraining) has no FFI: its device work is whatever PyTorch dispatches from
+ *   fullbatch/training/training.py:76-83   (_compute_batched_gradient: model fwd, CE, autograd.grad)
+ *   fullbatch/models/resnets.py:179-230,296-316 (conv / BN / ReLU / pool / fc graph)
+ *   fullbatch/models/modules.py:211-300    (GradRegularizer finite differences: foreach mul/add/sub/div, norms)
+ *   fullbatch/training/training.py:45-47   (_stable_mean_accumulation), :162 (per-chunk squared norm)
+ *   fullbatch/training/training.py:198-211 (global-norm clip)  +  torch.optim.SGD.step (optimizers.py:28)
+ * Each entry point below names the reference call it replaces.  A maintainer binds these with ctypes
+ * (see INTEGRATION.md); no torch types cross this boundary.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch caching allocator); nothing here allocates
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), never synchronises
+ *   - return 0 on success, a negative fb_status otherwise; fb_last_error_string() describes the last failure of the
+ *     calling thread; no other global mutable state, re-entrant, one host thread per GPU
+ *   - activations are NHWC ("pixel-major"): [image][y][x][channel], channel counts multiples of 32
+ *   - `dtype`: FB_F32 (exact f32 MFMA 16x16x4) or FB_BF16 (bf16 MFMA 16x16x32, fp32 accumulate)
+ *   - a launch processes `n_groups` chunks at once ("chunk group"); a chunk is the reference's unit of
+ *     BN statistics / loss mean / gradient (training.py:150-168).  Per-chunk quantities are indexed [group][...]
+ *   - conv weights live in K-contiguous "KRSC" form: [Cout][R*S][Cin]; per-chunk weight sets (finite-difference
+ *     second pass, modules.py:226) are selected by image index / imgs_per_wset
+ */
+#ifndef FB_ENGINE_H
+#define FB_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { FB_OK = 0, FB_ERR_ARG = -1, FB_ERR_SHAPE = -2, FB_ERR_LAUNCH = -3, FB_ERR_UNSUPPORTED = -4 } fb_status;
+typedef enum { FB_F32 = 0, FB_BF16 = 1 } fb_dtype;
+
+const char* fb_last_error_string(void);
+int fb_abi_version(void);
+
+/* ---------------------------------------------------------------- convolution ------------------------------------ */
+/* Implicit-GEMM convolution on MFMA.  mode 0: forward  y = conv(x, w)        (ATen convolution, resnets.py:69,206,209,150)
+ *                                      mode 1: dgrad    dx = conv_input_grad   (ATen convolution_backward, input part)
+ * src  [n_img][Hs][Ws][Cs]   dst [n_img][Hd][Wd][Cd]
+ * wgt  [n_wsets][Cd][R*S][Cs] (for mode 1 the caller passes the transposed set produced by fb_weight_prep)
+ * addend (optional, mode 1): dst += addend            (addend_mode 1: same shape)
+ *                            dst += 0.25*addend[y/2][x/2] (addend_mode 2: gradient of AvgPool2d(2,2), resnets.py:149)
+ * stat_partial (optional, mode 0): [2][ceil(M/128)][Cd] per-128-pixel-block channel sums / sums of squares of the fp32
+ *   accumulators, consumed by fb_bn_fwd_finalize (training-mode BatchNorm statistics, resnets.py:71). */
+typedef struct {
+    const void* src; const void* wgt; void* dst; const void* addend; float* stat_partial;
+    int32_t n_img, Hs, Ws, Cs, Hd, Wd, Cd;
+    int32_t R, S, stride, pad, mode;
+    int32_t imgs_per_wset; int64_t wset_stride;   /* elements between weight sets; 0 = shared */
+    int32_t addend_mode; int32_t dtype;
+} fb_conv_args;
+int fb_conv2d(const fb_conv_args* a, void* stream);
+
+/* wgrad: dw[g][split][Cd][R*S][Cs] (fp32 partial slabs) = sum over the pixels of chunk g (split-K slice `split`) of
+ * dy[p][Cd] (x) x[src(p,tap)][Cs]        (ATen convolution_backward, weight part).  Deterministic: no atomics. */
+typedef struct {
+    const void* x; const void* dy; float* dw_partial;
+    int32_t n_img, Hs, Ws, Cs, Hd, Wd, Cd;
+    int32_t R, S, stride, pad;
+    int32_t imgs_per_group; int32_t split_k; int32_t dtype;
+} fb_wgrad_args;
+int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream);
+/* sums the split_k slabs in fixed order, drops channel padding (Cs_pad -> Cs_real), writes [g][Cd][R*S][Cs_real]
+ * at out + g*out_group_stride */
+int fb_wgrad_reduce(const float* dw_partial, float* out, int64_t out_group_stride, int32_t n_groups, int32_t split_k,
+                    int32_t Cd, int32_t taps, int32_t Cs_pad, int32_t Cs_real, void* stream);
+/* master fp32 KRSC weights [n_wsets][Cout][taps][Cin_real] (stride wset_stride_in floats, 0 = one shared set) ->
+ * w_fwd [n_wsets][Cout][taps][Cin_pad] and (optional) w_dgrad [n_wsets][Cin_pad][taps][Cout] in `dtype` */
+int fb_weight_prep(const float* master, int64_t wset_stride_in, int32_t n_wsets, int32_t Cout, int32_t taps, int32_t Cin_real,
+                   int32_t Cin_pad, void* w_fwd, void* w_dgrad, int32_t dtype, void* stream);
+
+/* ---------------------------------------------------------------- batch norm ------------------------------------- */
+/* Per (group, channel): mean, biased var from the partial sums; writes mean/var rows into the [n_groups][ch_total]
+ * statistics tables at column ch_off, and scale = gamma*invstd, shift = beta - mean*scale  ([n_groups][C]). */
+int fb_bn_fwd_finalize(const float* stat_partial, int32_t n_mblocks, int32_t n_groups, int32_t C, double count,
+                       const float* gamma, const float* beta, int64_t param_group_stride, float eps,
+                       float* mean_tab, float* var_tab, int32_t ch_total, int32_t ch_off,
+                       float* scale, float* shift, float* invstd, void* stream);
+/* y = relu?(x*scale[g][c] + shift[g][c] + residual)  residual: none | res | res*rscale[g][c]+rshift[g][c]
+ * (BatchNorm2d + ReLU(inplace) + `out += identity`, resnets.py:217-228) */
+int fb_bn_apply(const void* x, void* y, const float* scale, const float* shift, const void* res, const float* rscale,
+                const float* rshift, int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t relu, int32_t dtype,
+                void* stream);
+/* sequential running-stat EMA for every BN channel of the network in one launch (momentum 0.1, unbiased var,
+ * torch BatchNorm2d).  Update order: for g in groups: table0[g] then (if table1) table1[g]  (SURVEY T6). */
+int fb_bn_running_update(float* running_mean, float* running_var, const float* mean0, const float* var0,
+                         const float* mean1, const float* var1, const float* unbias, int32_t n_groups, int32_t ch_total,
+                         float momentum, void* stream);
+/* backward: partial sums of dy and dy*xhat with dy = dout * (y > 0) when y != NULL (threshold_backward). */
+int fb_bn_bwd_reduce(const void* dout, const void* y, const void* x, const float* mean_tab, const float* invstd,
+                     int32_t ch_total, int32_t ch_off, float* partial, int64_t n_pixels, int32_t C,
+                     int64_t pixels_per_group, int32_t dtype, void* stream);
+/* dgamma/dbeta -> gradient arena (per group), coefficients for fb_bn_bwd_apply */
+int fb_bn_bwd_finalize(const float* partial, int32_t n_mblocks, int32_t n_groups, int32_t C, double count,
+                       const float* scale, const float* mean_tab, const float* invstd, int32_t ch_total, int32_t ch_off,
+                       float* dgamma, float* dbeta, int64_t grad_group_stride, float* coef, void* stream);
+/* dx = c_dy*dy + c_x*x + c_0 ; optionally also stores dy (masked gradient, used by the shortcut branch) */
+int fb_bn_bwd_apply(const void* dout, const void* y, const void* x, const float* coef, void* dx, void* dy_out,
+                    int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t dtype, void* stream);
+
+/* ---------------------------------------------------------------- pooling / head --------------------------------- */
+int fb_avgpool2_fwd(const void* x, void* y, int32_t n_img, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
+/* MaxPool2d(3,2,1) of the 'standard' stem (resnets.py:78); bwd scatters through recomputed argmax */
+int fb_maxpool3s2_fwd(const void* x, void* y, int32_t n_img, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
+int fb_maxpool3s2_bwd(const void* x, const void* dy, void* dx, int32_t n_img, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                      void* stream);
+/* AdaptiveAvgPool2d(1) + flatten (resnets.py:185-186): feat[n][C] fp32 */
+int fb_head_pool(const void* a, float* feat, int32_t n_img, int32_t HW, int32_t C, int32_t dtype, void* stream);
+/* fc + log_softmax + nll (mean over the chunk) + argmax-correct (training.py:78-80): logits, dlogits [n][classes],
+ * loss[g], correct[g] */
+int fb_head_loss(const float* feat, const float* fc_w, const float* fc_b, int64_t param_group_stride, const int64_t* labels,
+                 float* logits, float* dlogits, float* loss, float* correct, int32_t n_groups, int32_t imgs_per_group,
+                 int32_t C, int32_t classes, void* stream);
+/* dW_fc[g], db_fc[g] into the gradient arena and d_a = (dlogits @ W)/HW broadcast over the HW pixels */
+int fb_head_bwd(const float* feat, const float* dlogits, const float* fc_w, int64_t param_group_stride, float* dfc_w,
+                float* dfc_b, int64_t grad_group_stride, void* d_a, int32_t n_groups, int32_t imgs_per_group, int32_t HW,
+                int32_t C, int32_t classes, int32_t dtype, void* stream);
+
+/* ---------------------------------------------------------------- multi-tensor (flat fp32 arena) ------------------ */
+/* out[g] = sum_i (scale*x[g][i])^2, deterministic two-stage.  ws: n_groups*FB_MT_BLOCKS floats.
+ * (g.pow(2).sum() stack-sum, training.py:162 / modules.py:223) */
+#define FB_MT_BLOCKS 1024
+int fb_mt_sqnorm(const float* x, int64_t group_stride, int32_t n_groups, int64_t n, float scale, float* out, float* ws,
+                 void* stream);
+/* running mean over chunks (_stable_mean_accumulation, training.py:45-47): for j: avg += (g[j]-avg)/(counter0+j+1).
+ * If sq_out != NULL also writes sq_out[j] = |g[j]|^2 (fused, one pass). */
+int fb_mt_accumulate(float* avg, const float* g, int64_t group_stride, int32_t n_groups, int64_t n, int32_t counter0,
+                     float* sq_out, float* ws, void* stream);
+/* eps_n[g] = eps / sqrt(vnorm2[g]);  theta_out[g] = theta0 + (sign*eps_n[g]) * (s*g[g])   (modules.py:217-226) */
+int fb_mt_fd_perturb(const float* theta0, const float* g, int64_t group_stride, int32_t n_groups, int64_t n, float s,
+                     float eps, float sign, const float* vnorm2, float* eps_n, float* theta_out, void* stream);
+/* vhp = (ga - gb)/eps_n[g]; gt = g + cf*vhp; avg += (gt-avg)/(counter0+j+1)   (modules.py:232-240 + training.py:45-47) */
+int fb_mt_fd_combine_accumulate(float* avg, const float* g, const float* ga, const float* gb, int64_t group_stride,
+                                int32_t n_groups, int64_t n, const float* eps_n, float cf, int32_t counter0, void* stream);
+/* out[0] = |a|^2, out[1] = |b|^2 over [0,n) (grad norm for clipping, training.py:202-204; param_norm, :92) */
+int fb_mt_norms2(const float* a, const float* b, int64_t n, float* out, float* ws, void* stream);
+/* clip (training.py:206-207) + torch.optim.SGD step with weight decay, momentum, dampening, Nesterov.
+ * gnorm2: device scalar |grad|^2 (whole vector); grad_clip < 0 disables clipping.  Operates on [0,n) of the
+ * pointers given (callers pass shard offsets for the sharded multi-GPU update).  grad is overwritten with the
+ * clipped gradient (the closure contract exposes p.grad). */
+int fb_mt_clip_sgd(float* theta, float* grad, float* mom, int64_t n, const float* gnorm2, float grad_clip, float lr,
+                   float weight_decay, float momentum, float dampening, int32_t nesterov, int32_t first_step, void* stream);
+/* y = a*x (+ y*b)  flat helpers used by the sharded path (scale local mean by K_r/K) */
+int fb_mt_scale(float* x, int64_t n, float a, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FB_ENGINE_H */

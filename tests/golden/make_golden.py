@@ -1,0 +1,229 @@
+"""Generate golden vectors by running the REAL reference (``/root/reference``) on CPU.
+
+Runs only in the build container (the reference never travels to the GPU box).  It follows the harness recipe of
+SURVEY.md Appendix A: stub the absent optional imports, restore torch-1.9 foreach semantics, build cfg
+with this repo's composer, call ``fullbatch.models.construct_model`` and ``fullbatch.training.train`` directly.
+
+Outputs (committed, data only -- tensors, scalars, key lists):
+  tests/golden/scenarios.npz      per-scenario stats, per-chunk internals, sampled/summarised parameter state
+  tests/golden/meta.json          LR sequences, state_dict key/shape lists, checkpoint structure, scenario table
+
+Usage:  python tests/golden/make_golden.py
+"""
+import json
+import logging.config  # noqa: F401  (reference utils.get_log uses logging.config without importing it)
+import os
+import sys
+import tempfile
+from unittest import mock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+SAMPLE_STRIDE = 997  # every 997th element of each flat tensor is kept verbatim
+
+
+def import_reference():
+    for name in ["torchvision", "torchvision.transforms", "torchvision.datasets", "torchvision.datasets.utils",
+                 "torchvision.models", "torchvision.models.densenet", "hydra", "hydra.core",
+                 "hydra.core.hydra_config", "hydra.utils", "omegaconf", "lmdb"]:
+        sys.modules[name] = mock.MagicMock(name=name)
+
+    class _DL(torch.nn.Module):
+        pass
+
+    sys.modules["torchvision"].models.densenet._DenseLayer = _DL
+    sys.modules["torchvision.models.densenet"]._DenseLayer = _DL
+    sys.modules["omegaconf"].OmegaConf.to_container = lambda c, resolve=True: c
+    for n in ["_foreach_add_", "_foreach_sub_", "_foreach_div_", "_foreach_mul_"]:
+        setattr(torch, n, torch.no_grad()(getattr(torch, n)))
+    sys.path.insert(0, "/root/reference")
+    import fullbatch  # noqa
+
+    return fullbatch
+
+
+def summarise(tensors):
+    """Per-tensor (sum, sqnorm, absmax) + a strided sample of the concatenation."""
+    flat = torch.cat([t.detach().reshape(-1).double() for t in tensors])
+    per = np.array([[float(t.double().sum()), float(t.double().pow(2).sum()), float(t.abs().max())] for t in tensors])
+    return per, flat[::SAMPLE_STRIDE].numpy()
+
+
+def make_data(n, pixels=32, classes=10, seed=1234):
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, 3, pixels, pixels, generator=gen)
+    y = torch.randint(0, classes, (n,), generator=gen)
+    return x, y
+
+
+def loaders(x, y, batch):
+    ds = torch.utils.data.TensorDataset(x, y)
+    sampler = torch.utils.data.SequentialSampler(ds)
+    sampler.set_epoch = lambda *a, **k: None
+    train = torch.utils.data.DataLoader(ds, batch_size=min(batch, len(ds)), sampler=sampler, drop_last=True)
+    valid = torch.utils.data.DataLoader(ds, batch_size=min(batch, len(ds)), shuffle=False, drop_last=False)
+    return train, valid
+
+
+SCENARIOS = {
+    # name: (N, pixels, overrides, model_seed)
+    "fb_plain": (512, 32, ["hyp=fb1", "hyp.steps=2", "hyp.warmup=0"], 0),
+    "fb_gradreg": (512, 32, ["hyp=fb1", "hyp.steps=2", "hyp.warmup=0", "hyp.grad_reg.block_strength=0.5"], 0),
+    "fb_clip_warm": (256, 32, ["hyp=fbclip", "hyp.steps=3", "hyp.warmup=2", "data.batch_size=64", "hyp.sub_batch=64"], 3),
+    "fb_gradreg_c32": (128, 32, ["hyp=gradreg", "hyp.steps=3", "hyp.warmup=1", "data.batch_size=32", "hyp.sub_batch=32"], 5),
+    "fb_central": (128, 16, ["hyp=fb1", "hyp.steps=2", "hyp.warmup=0", "hyp.grad_reg.block_strength=0.5",
+                             "hyp.grad_reg.implementation=central-differences", "data.batch_size=64",
+                             "hyp.sub_batch=64"], 7),
+    "fb_legacy": (128, 16, ["hyp=fb1", "hyp.steps=2", "hyp.warmup=0", "hyp.grad_reg.block_strength=0.5",
+                            "hyp.grad_reg.implementation=forward-differences-legacy", "data.batch_size=64",
+                            "hyp.sub_batch=64"], 7),
+}
+
+
+def run_scenario(fullbatch, compose, scen, out, dtype=torch.float):
+    n, pixels, overrides, mseed = SCENARIOS[scen]
+    name = scen if dtype == torch.float else f"{scen}@f64"
+    tmp = tempfile.mkdtemp()
+    cfg = compose(overrides + ["impl.validate_every_nth_step=1000", f"data.pixels={pixels}"], original_cwd=tmp,
+                  name=name, seed=mseed)
+    x, y = make_data(n, pixels)
+    trainloader, validloader = loaders(x, y, cfg.data.batch_size)
+    setup = dict(device=torch.device("cpu"), dtype=dtype, memory_format=torch.contiguous_format)
+    x = x.to(dtype)
+    torch.manual_seed(mseed)
+    model = fullbatch.models.construct_model(cfg.model, 3, 10)
+    model.to(**setup)
+    init_state = {k: v.clone() for k, v in model.state_dict().items()}
+    per, samp = summarise([v.to(dtype) for v in init_state.values()])
+    out[f"{name}/init_per"], out[f"{name}/init_sample"] = per, samp
+
+    # per-chunk internals at the initial parameters, using the reference's own model + GradRegularizer objects
+    chunk = min(cfg.data.batch_size, cfg.hyp.sub_batch)
+    probe = fullbatch.models.construct_model(cfg.model, 3, 10)
+    probe.to(**setup)
+    probe.load_state_dict(init_state)
+    probe.train()
+    lr_probe = 0.1
+    opt = torch.optim.SGD(probe.parameters(), lr=lr_probe)
+    loss_fn = torch.nn.CrossEntropyLoss()
+    greg = fullbatch.models.modules.GradRegularizer(probe, opt, loss_fn, **cfg.hyp.grad_reg, mixed_precision=False)
+    for k in range(2):
+        xk, yk = x[k * chunk:(k + 1) * chunk], y[k * chunk:(k + 1) * chunk]
+        outputs = probe(xk)
+        loss = loss_fn(outputs, yk)
+        correct = (outputs.argmax(dim=-1) == yk).float().sum()
+        grads = torch.autograd.grad(loss, probe.parameters())
+        grads = [g.clone() for g in grads]
+        if k == 0 and dtype == torch.double:
+            out[f"{name}/chunk0_raw_fc_weight"] = grads[-2].numpy().copy()
+            out[f"{name}/chunk0_raw_stem_weight"] = grads[0].numpy().copy()
+        per, samp = summarise(grads)
+        out[f"{name}/chunk{k}_raw_per"], out[f"{name}/chunk{k}_raw_sample"] = per, samp
+        out[f"{name}/chunk{k}_scalars"] = np.array([float(loss.detach()), float(correct), float(sum(g.pow(2).sum() for g in grads))])
+        if k == 0:
+            out[f"{name}/chunk0_logits"] = outputs.detach().numpy()
+        grads = greg(grads, xk, yk, None)
+        per, samp = summarise(grads)
+        out[f"{name}/chunk{k}_reg_per"], out[f"{name}/chunk{k}_reg_sample"] = per, samp
+    per, samp = summarise([v.to(dtype) for v in probe.state_dict().values()])
+    out[f"{name}/probe_state_per"], out[f"{name}/probe_state_sample"] = per, samp
+
+    stats = fullbatch.training.train(model, trainloader, validloader, setup, cfg)
+    keys = sorted(k for k in stats if k != "train_time")
+    out[f"{name}/stat_keys"] = np.array(keys)
+    for k in keys:
+        out[f"{name}/stat/{k}"] = np.array(stats[k], dtype=np.float64)
+    final = model.state_dict()
+    per, samp = summarise([v.to(dtype) for v in final.values()])
+    out[f"{name}/final_per"], out[f"{name}/final_sample"] = per, samp
+    out[f"{name}/final_fc_bias"] = final["fc.bias"].numpy()
+    out[f"{name}/final_stem_running_mean"] = final["stem.1.running_mean"].numpy()
+    out[f"{name}/final_num_batches_tracked"] = np.array([int(final["stem.1.num_batches_tracked"])])
+    print(name, {k: stats[k] for k in ("train_loss", "full_loss", "grad_norm", "train_acc")})
+    return cfg, model
+
+
+def lr_sequences(fullbatch, compose):
+    seqs = {}
+    for hyp, count in (("fb1", 300), ("fb2", 3000), ("fbclip", 3000), ("gradreg", 3000)):
+        cfg = compose([f"hyp={hyp}"])
+        model = torch.nn.Linear(2, 2)
+        optimizer, scheduler = fullbatch.training.optimizers.optim_interface(model, cfg.hyp)
+        seq = []
+        for _ in range(count):
+            seq.append(optimizer.param_groups[0]["lr"])
+            optimizer.step()
+            scheduler.step()
+        seqs[hyp] = seq
+    return seqs
+
+
+def checkpoint_structure(fullbatch, compose):
+    """Key layout of the 5-list checkpoint (reference training/utils.py:43-51) for ResNet-18 after one SGD step."""
+    cfg = compose(["hyp=gradreg"])
+    torch.manual_seed(0)
+    model = fullbatch.models.construct_model(cfg.model, 3, 10)
+    optimizer, scheduler = fullbatch.training.optimizers.optim_interface(model, cfg.hyp)
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    optimizer.step()
+    scheduler.step()
+
+    class Counter:
+        step = 1
+
+    path = os.path.join(tempfile.mkdtemp(), "ck.pth")
+    fullbatch.training.utils._save_to_checkpoint(model, optimizer, scheduler, None, Counter, file=path)
+    optim_state, model_state, sched_state, scaler_state, step = torch.load(path, weights_only=False)
+
+    def describe(obj):
+        if torch.is_tensor(obj):
+            return {"tensor": list(obj.shape), "dtype": str(obj.dtype)}
+        if isinstance(obj, dict):
+            return {str(k): describe(v) for k, v in obj.items()}
+        if isinstance(obj, (list, tuple)):
+            return [describe(v) for v in obj] if len(obj) < 8 else {"list_len": len(obj), "first": describe(obj[0])}
+        return repr(obj) if not isinstance(obj, (int, float, bool, type(None), str)) else obj
+
+    return dict(
+        model_state={k: [list(v.shape), str(v.dtype)] for k, v in model_state.items()},
+        optim_state=dict(param_groups=describe(optim_state["param_groups"]),
+                         state0=describe(optim_state["state"][0]), n_state=len(optim_state["state"])),
+        scheduler_state=describe(sched_state), scaler_state=scaler_state, step=step,
+    )
+
+
+def main():
+    torch.set_num_threads(8)
+    fullbatch = import_reference()
+    from fullbatchtraining_amd.cfg import compose
+
+    out = {}
+    for name in SCENARIOS:
+        run_scenario(fullbatch, compose, name, out)
+        run_scenario(fullbatch, compose, name, out, dtype=torch.double)
+    np.savez_compressed(os.path.join(HERE, "scenarios.npz"), **out)
+
+    meta = dict(sample_stride=SAMPLE_STRIDE, scenarios={k: dict(n=v[0], pixels=v[1], overrides=v[2], model_seed=v[3])
+                                                        for k, v in SCENARIOS.items()})
+    meta["lr"] = {k: [v[i] for i in list(range(0, 12)) + list(range(395, 410)) + [1000, 2000, 2999] if i < len(v)]
+                  for k, v in lr_sequences(fullbatch, compose).items()}
+    meta["lr_index"] = list(range(0, 12)) + list(range(395, 410)) + [1000, 2000, 2999]
+    meta["checkpoint"] = checkpoint_structure(fullbatch, compose)
+    cfg152 = compose(["model=resnet152"])
+    torch.manual_seed(0)
+    m152 = fullbatch.models.construct_model(cfg152.model, 3, 10)
+    meta["resnet152_keys"] = {k: list(v.shape) for k, v in m152.state_dict().items()}
+    meta["resnet152_nparams"] = sum(p.numel() for p in m152.parameters())
+    with open(os.path.join(HERE, "meta.json"), "w") as handle:
+        json.dump(meta, handle, indent=1)
+    print("wrote", os.path.join(HERE, "scenarios.npz"), os.path.join(HERE, "meta.json"))
+
+
+if __name__ == "__main__":
+    main()

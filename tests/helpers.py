@@ -1,0 +1,31 @@
+"""Shared test helpers: synthetic data (same generator recipe as tests/golden/make_golden.py) and summaries."""
+import numpy as np
+import torch
+
+SAMPLE_STRIDE = 997
+
+
+def make_data(n, pixels=32, classes=10, seed=1234):
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, 3, pixels, pixels, generator=gen)
+    y = torch.randint(0, classes, (n,), generator=gen)
+    return x, y
+
+
+def summarise(tensors):
+    flat = torch.cat([t.detach().reshape(-1).double() for t in tensors])
+    per = np.array([[float(t.double().sum()), float(t.double().pow(2).sum()), float(t.abs().max())] for t in tensors])
+    return per, flat[::SAMPLE_STRIDE].numpy()
+
+
+def hyp_from_cfg(cfg):
+    """Flatten the cfg.hyp keys the oracle's step consumes."""
+    o = cfg.hyp.optim
+    return dict(lr=o.lr, weight_decay=o.weight_decay, momentum=o.momentum, nesterov=o.nesterov, dampening=o.dampening,
+                block_strength=cfg.hyp.grad_reg.block_strength, eps=cfg.hyp.grad_reg.eps,
+                implementation=cfg.hyp.grad_reg.implementation, grad_clip=cfg.hyp.grad_clip)
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
