@@ -90,30 +90,28 @@ extern "C" int fb_bn_apply(const void* x, void* y, const float* scale, const flo
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void bn_running_update_kernel(float* __restrict__ rm, float* __restrict__ rv, const float* __restrict__ mean0,
-                                         const float* __restrict__ var0, const float* __restrict__ mean1, const float* __restrict__ var1,
+__global__ void bn_running_update_kernel(float* __restrict__ rm, float* __restrict__ rv, const float* __restrict__ mean_tab,
+                                         const float* __restrict__ var_tab, int n_passes, long long pass_stride,
                                          const float* __restrict__ unbias, int n_groups, int ch_total, float momentum) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ch_total) return;
     float m = rm[c], v = rv[c];
     const float ub = unbias[c], keep = 1.f - momentum;
-    for (int g = 0; g < n_groups; ++g) {
-        m = keep * m + momentum * mean0[(long long)g * ch_total + c];
-        v = keep * v + momentum * (var0[(long long)g * ch_total + c] * ub);
-        if (mean1) {
-            m = keep * m + momentum * mean1[(long long)g * ch_total + c];
-            v = keep * v + momentum * (var1[(long long)g * ch_total + c] * ub);
+    for (int g = 0; g < n_groups; ++g)
+        for (int p = 0; p < n_passes; ++p) {
+            const long long o = p * pass_stride + (long long)g * ch_total + c;
+            m = keep * m + momentum * mean_tab[o];
+            v = keep * v + momentum * (var_tab[o] * ub);
         }
-    }
     rm[c] = m; rv[c] = v;
 }
 
-extern "C" int fb_bn_running_update(float* running_mean, float* running_var, const float* mean0, const float* var0, const float* mean1,
-                                    const float* var1, const float* unbias, int32_t n_groups, int32_t ch_total, float momentum,
+extern "C" int fb_bn_running_update(float* running_mean, float* running_var, const float* mean_tab, const float* var_tab, int32_t n_passes,
+                                    int64_t pass_stride, const float* unbias, int32_t n_groups, int32_t ch_total, float momentum,
                                     void* stream) {
-    if (!running_mean || !running_var || !mean0 || !var0 || !unbias) FB_FAIL(FB_ERR_ARG, "fb_bn_running_update: null pointer");
+    if (!running_mean || !running_var || !mean_tab || !var_tab || !unbias) FB_FAIL(FB_ERR_ARG, "fb_bn_running_update: null pointer");
     hipLaunchKernelGGL(bn_running_update_kernel, dim3((ch_total + 255) / 256), dim3(256), 0, (hipStream_t)stream, running_mean,
-                       running_var, mean0, var0, mean1, var1, unbias, n_groups, ch_total, momentum);
+                       running_var, mean_tab, var_tab, n_passes, (long long)pass_stride, unbias, n_groups, ch_total, momentum);
     FB_CHECK_LAUNCH("fb_bn_running_update");
     return FB_OK;
 }

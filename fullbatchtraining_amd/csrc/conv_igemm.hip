@@ -9,6 +9,7 @@
 // Zero padding and stride-2 dgrad parity classes are resolved in the gather (invalid rows load zeros; taps that are
 // invalid for a whole parity class are skipped, so no MFMA work is wasted on structural zeros).
 #include "common.h"
+#include "profile.h"
 
 struct ConvParams {
     const char* src; const char* wgt; char* dst; const char* addend; float* stat;
@@ -247,7 +248,9 @@ extern "C" int fb_conv2d(const fb_conv_args* a, void* stream) {
     p.M = a->n_img * p.qH * p.qW;
     p.n_mblocks = ((p.M + 127) / 128) * classes;
     hipStream_t st = (hipStream_t)stream;
+    const int prof = fb_prof_begin(a->mode == 0 ? FB_PROF_IGEMM_FWD : FB_PROF_IGEMM_DGRAD, st);
     if (a->dtype == FB_F32) launch_conv<float>(p, classes, st); else launch_conv<bf16_tag>(p, classes, st);
+    fb_prof_end(prof, st);
     FB_CHECK_LAUNCH("fb_conv2d");
     return FB_OK;
 }

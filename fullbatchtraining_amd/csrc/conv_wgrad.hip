@@ -10,6 +10,7 @@
 // Grid: x = tile, y = tap, z = group * split_k.  Output: fp32 slabs [group][split][co][tap][ci], no atomics, so the
 // sum order is fixed and identical for the two passes of the finite-difference regulariser.
 #include "common.h"
+#include "profile.h"
 
 struct WgradParams {
     const char* x; const char* dy; float* out;
@@ -184,9 +185,8 @@ extern "C" int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream) {
     const bool big = (a->Cs % 128 == 0) && (a->Cd % 128 == 0) && (a->Cs >= 256 || a->Cd >= 256);
     const int kstep = big ? (a->dtype == FB_F32 ? 32 : 64) : 128;
     p.px_per_split = (int)(ceil_div64(ceil_div64(p.px_per_group, a->split_k), kstep) * kstep);
-    if ((long long)(a->split_k - 1) * p.px_per_split >= p.px_per_group && a->split_k > 1)
-        FB_FAIL(FB_ERR_ARG, "fb_conv2d_wgrad: split_k=%d leaves empty slices for %d pixels", a->split_k, p.px_per_group);
     const int taps = a->R * a->S;
+    const int prof = fb_prof_begin(FB_PROF_WGRAD, st);
     if (big) {
         dim3 grid((a->Cd / 128) * (a->Cs / 128), taps, n_groups * a->split_k);
         if (a->dtype == FB_F32) hipLaunchKernelGGL((conv_wgrad_kernel<float, 2, 2, 1, 1, 4>), grid, dim3(256), 0, st, p);
@@ -200,6 +200,7 @@ extern "C" int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream) {
         if (a->dtype == FB_F32) hipLaunchKernelGGL((conv_wgrad_kernel<float, 1, 1, 4, 1, 2>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_tag, 1, 1, 4, 1, 2>), grid, dim3(256), 0, st, p);
     }
+    fb_prof_end(prof, st);
     FB_CHECK_LAUNCH("fb_conv2d_wgrad");
     return FB_OK;
 }
@@ -230,8 +231,8 @@ extern "C" int fb_wgrad_reduce(const float* dw_partial, float* out, int64_t out_
 
 // ---- master KRSC fp32 -> compute copies ------------------------------------------------------------------------------
 template <typename T>
-__global__ void weight_prep_kernel(const float* __restrict__ master, long long wset_stride_in, int Cout, int taps, int Cin_real,
-                                   int Cin_pad, T* __restrict__ w_fwd, T* __restrict__ w_dgrad) {
+__global__ void weight_prep_kernel(const float* __restrict__ master, long long wset_stride_in, long long wset_stride_out, int Cout, int taps,
+                                   int Cin_real, int Cin_pad, T* __restrict__ w_fwd, T* __restrict__ w_dgrad) {
     const long long per_set = (long long)Cout * taps * Cin_pad;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int ws = blockIdx.y;
@@ -241,21 +242,22 @@ __global__ void weight_prep_kernel(const float* __restrict__ master, long long w
     if (ci < Cin_real) v = master[(long long)ws * wset_stride_in + ((long long)co * taps + t) * Cin_real + ci];
     T o;
     if constexpr (sizeof(T) == 4) o = v; else o = f32_to_bf16(v);
-    w_fwd[(long long)ws * per_set + idx] = o;
-    if (w_dgrad) w_dgrad[(long long)ws * per_set + ((long long)ci * taps + t) * Cout + co] = o;
+    w_fwd[(long long)ws * wset_stride_out + idx] = o;
+    if (w_dgrad) w_dgrad[(long long)ws * wset_stride_out + ((long long)ci * taps + t) * Cout + co] = o;
 }
 
-extern "C" int fb_weight_prep(const float* master, int64_t wset_stride_in, int32_t n_wsets, int32_t Cout, int32_t taps, int32_t Cin_real,
-                              int32_t Cin_pad, void* w_fwd, void* w_dgrad, int32_t dtype, void* stream) {
+extern "C" int fb_weight_prep(const float* master, int64_t wset_stride_in, int64_t wset_stride_out, int32_t n_wsets, int32_t Cout, int32_t taps,
+                              int32_t Cin_real, int32_t Cin_pad, void* w_fwd, void* w_dgrad, int32_t dtype, void* stream) {
     if (!master || !w_fwd) FB_FAIL(FB_ERR_ARG, "fb_weight_prep: null pointer");
     const long long per_set = (long long)Cout * taps * Cin_pad;
     dim3 grid((unsigned)ceil_div64(per_set, 256), n_wsets);
     if (dtype == FB_F32)
-        hipLaunchKernelGGL((weight_prep_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, master, (long long)wset_stride_in, Cout,
-                           taps, Cin_real, Cin_pad, (float*)w_fwd, (float*)w_dgrad);
+        hipLaunchKernelGGL((weight_prep_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, master, (long long)wset_stride_in,
+                           (long long)wset_stride_out, Cout, taps, Cin_real, Cin_pad, (float*)w_fwd, (float*)w_dgrad);
     else
         hipLaunchKernelGGL((weight_prep_kernel<unsigned short>), grid, dim3(256), 0, (hipStream_t)stream, master,
-                           (long long)wset_stride_in, Cout, taps, Cin_real, Cin_pad, (unsigned short*)w_fwd, (unsigned short*)w_dgrad);
+                           (long long)wset_stride_in, (long long)wset_stride_out, Cout, taps, Cin_real, Cin_pad, (unsigned short*)w_fwd,
+                           (unsigned short*)w_dgrad);
     FB_CHECK_LAUNCH("fb_weight_prep");
     return FB_OK;
 }

@@ -1,0 +1,58 @@
+// Error string + optional per-kernel-class timing with HIP events on the launch stream (used by bench.py's roofline leg).
+#include <vector>
+
+#include "common.h"
+#include "profile.h"
+
+thread_local char fb_err_buf[512] = "";
+extern "C" const char* fb_last_error_string(void) { return fb_err_buf; }
+extern "C" int fb_abi_version(void) { return 1; }
+
+namespace {
+struct Pair { hipEvent_t a, b; int cls; };
+bool g_on = false;
+std::vector<Pair> g_pool;
+size_t g_used = 0;
+long long g_dropped[FB_PROF_CLASSES] = {0};
+}  // namespace
+
+extern "C" int fb_profile_enable(int on, int capacity) {
+    if (on && g_pool.size() < (size_t)capacity) {
+        const size_t old = g_pool.size();
+        g_pool.resize(capacity);
+        for (size_t i = old; i < g_pool.size(); ++i) {
+            if (hipEventCreate(&g_pool[i].a) != hipSuccess || hipEventCreate(&g_pool[i].b) != hipSuccess)
+                FB_FAIL(FB_ERR_LAUNCH, "fb_profile_enable: hipEventCreate failed");
+        }
+    }
+    g_on = on != 0;
+    g_used = 0;
+    for (int c = 0; c < FB_PROF_CLASSES; ++c) g_dropped[c] = 0;
+    return FB_OK;
+}
+
+int fb_prof_begin(int cls, hipStream_t st) {
+    if (!g_on) return -1;
+    if (g_used >= g_pool.size()) { g_dropped[cls]++; return -1; }
+    const int id = (int)g_used++;
+    g_pool[id].cls = cls;
+    hipEventRecord(g_pool[id].a, st);
+    return id;
+}
+void fb_prof_end(int id, hipStream_t st) {
+    if (id >= 0) hipEventRecord(g_pool[id].b, st);
+}
+
+// Sums elapsed ms and launch counts per class for everything recorded since the last read; blocks until those launches finish.
+extern "C" int fb_profile_read(double* ms, int64_t* launches, int64_t* dropped) {
+    for (int c = 0; c < FB_PROF_CLASSES; ++c) { ms[c] = 0.0; launches[c] = 0; dropped[c] = g_dropped[c]; g_dropped[c] = 0; }
+    for (size_t i = 0; i < g_used; ++i) {
+        if (hipEventSynchronize(g_pool[i].b) != hipSuccess) FB_FAIL(FB_ERR_LAUNCH, "fb_profile_read: event sync failed");
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_pool[i].a, g_pool[i].b) != hipSuccess) FB_FAIL(FB_ERR_LAUNCH, "fb_profile_read: elapsed failed");
+        ms[g_pool[i].cls] += t;
+        launches[g_pool[i].cls] += 1;
+    }
+    g_used = 0;
+    return FB_OK;
+}

@@ -1,0 +1,578 @@
+"""Host-side schedule of the full-batch gradient hot path on one MI355X.
+
+This is the device counterpart of the reference's chunk loop
+(``fullbatch/training/training.py:121-185`` with ``_compute_batched_gradient`` :76-83, ``GradRegularizer`` in
+``fullbatch/models/modules.py:211-300`` and ``_stable_mean_accumulation`` :45-47): the network is a fixed DAG, so forward,
+dgrad and wgrad are hand-scheduled as calls into ``libfbengine.so`` (no autograd).  ``G`` chunks ("chunk group") are
+processed per launch; each chunk keeps its own BatchNorm statistics, loss mean and gradient exactly like the
+reference's sequential loop, and the running mean over chunks is folded in the reference's order.
+
+Memory (HBM): one flat fp32 arena per quantity -- theta (master parameters), momentum, averaged gradient, per-chunk
+gradients ``g[G][P]`` (+ a second/third set and per-chunk perturbed parameters for the finite-difference passes) --
+with conv weights in KRSC order ``[Cout][R*S][Cin]``; NHWC activations in the compute dtype (bf16 or f32).
+"""
+import math
+
+import torch
+
+from . import lib
+from .lib import call, _ptr
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class ConvBN:
+    """One convolution with the BatchNorm that follows it."""
+
+    def __init__(self, conv_name, bn_name, cin_real, cout, k, stride, pad, hin, win, patches=False):
+        self.conv_name, self.bn_name = conv_name, bn_name
+        self.k_orig, self.stride_orig, self.pad_orig = k, stride, pad
+        self.hout = (hin + 2 * pad - k) // stride + 1
+        self.wout = (win + 2 * pad - k) // stride + 1
+        self.patches = patches
+        if patches:  # stem: pre-gathered k*k*cin patches, executed as a 1x1 convolution
+            self.R = self.S = 1
+            self.stride, self.pad = 1, 0
+            self.cin_real = k * k * cin_real
+            self.hin, self.win = self.hout, self.wout
+        else:
+            self.R = self.S = k
+            self.stride, self.pad = stride, pad
+            self.cin_real = cin_real
+            self.hin, self.win = hin, win
+        self.cin_pad = _round_up(self.cin_real, 32)
+        self.cout = cout
+        self.taps = self.R * self.S
+        self.w_numel = cout * self.taps * self.cin_real
+        self.wc_numel = cout * self.taps * self.cin_pad
+
+
+class Block:
+    def __init__(self, convs, shortcut, stride, cin, hin, win):
+        self.convs, self.shortcut, self.stride, self.cin, self.hin, self.win = convs, shortcut, stride, cin, hin, win
+
+
+class Plan:
+    """Static layer plan + arena offsets derived from the parameter container (``fullbatchtraining_amd.models.ResNet``)."""
+
+    def __init__(self, model, pixels):
+        self.kind, self.stem_kind, self.classes, self.channels = model.kind, model.stem_kind, model.classes, model.channels
+        self.pixels = pixels
+        named = dict(model.named_parameters())
+        self.param_names = [k for k, _ in model.named_parameters()]
+        self.param_shapes = {k: tuple(v.shape) for k, v in named.items()}
+        # arena offsets (each tensor 16-byte aligned)
+        self.offsets, off = {}, 0
+        for name in self.param_names:
+            self.offsets[name] = off
+            off = _round_up(off + named[name].numel(), 4)
+        self.P = _round_up(off, 64)
+        self.n_params = sum(v.numel() for v in named.values())
+        # layers
+        if self.stem_kind == "CIFAR":
+            self.stem = ConvBN("stem.0", "stem.1", self.channels, 64, 3, 1, 1, pixels, pixels, patches=True)
+            h = self.stem.hout
+            self.stem_pool = False
+        else:
+            self.stem = ConvBN("stem.0", "stem.1", self.channels, 64, 7, 2, 3, pixels, pixels, patches=True)
+            h = (self.stem.hout + 2 - 3) // 2 + 1
+            self.stem_pool = True
+        self.blocks = []
+        cin = 64
+        for si, stage in enumerate(model.layers):
+            for bi, blk in enumerate(stage):
+                p = f"layers.{si}.{bi}"
+                stride = blk.stride
+                planes = blk.conv1.out_channels
+                if self.kind == "basic":
+                    c1 = ConvBN(f"{p}.conv1", f"{p}.bn1", cin, planes, 3, stride, 1, h, h)
+                    c2 = ConvBN(f"{p}.conv2", f"{p}.bn2", planes, planes, 3, 1, 1, c1.hout, c1.wout)
+                    convs, cout = [c1, c2], planes
+                else:
+                    c1 = ConvBN(f"{p}.conv1", f"{p}.bn1", cin, planes, 1, 1, 0, h, h)
+                    c2 = ConvBN(f"{p}.conv2", f"{p}.bn2", planes, planes, 3, stride, 1, h, h)
+                    c3 = ConvBN(f"{p}.conv3", f"{p}.bn3", planes, planes * 4, 1, 1, 0, c2.hout, c2.wout)
+                    convs, cout = [c1, c2, c3], planes * 4
+                shortcut = None
+                if blk.downsample is not None:
+                    hs = h // stride
+                    shortcut = ConvBN(f"{p}.downsample.1", f"{p}.downsample.2", cin, cout, 1, 1, 0, hs, hs)
+                self.blocks.append(Block(convs, shortcut, stride, cin, h, h))
+                cin, h = cout, convs[-1].hout
+        self.feat, self.h_final = cin, h
+        self.layers = [self.stem] + [c for b in self.blocks for c in b.convs + ([b.shortcut] if b.shortcut else [])]
+        # execution-order independent tables: BN channel table follows state_dict order of BN modules
+        order = {name: i for i, name in enumerate(self.param_names)}
+        self.layers_by_param = sorted(self.layers, key=lambda L: order[f"{L.conv_name}.weight"])
+        ch, wc = 0, 0
+        for L in self.layers_by_param:
+            L.w_off = self.offsets[f"{L.conv_name}.weight"]
+            L.g_off = self.offsets[f"{L.bn_name}.weight"]
+            L.b_off = self.offsets[f"{L.bn_name}.bias"]
+            L.ch_off, L.wc_off = ch, wc
+            ch += L.cout
+            wc += L.wc_numel
+        self.ch_total, self.wc_total = ch, _round_up(wc, 64)
+        self.fcw_off, self.fcb_off = self.offsets["fc.weight"], self.offsets["fc.bias"]
+
+
+def stem_patches(x_nchw, layer, dtype):
+    """[N,C,H,W] fp32 -> [N,Ho,Wo,cin_pad] patches in tap-major (kh,kw,c) order matching KRSC weights (data staging)."""
+    n, c, _, _ = x_nchw.shape
+    k, s, p = layer.k_orig, layer.stride_orig, layer.pad_orig
+    cols = torch.nn.functional.unfold(x_nchw.float(), kernel_size=k, padding=p, stride=s)  # [N, c*k*k, L], (c,kh,kw) major
+    cols = cols.view(n, c, k * k, layer.hout * layer.wout).permute(0, 3, 2, 1).reshape(n, layer.hout, layer.wout, k * k * c)
+    out = torch.zeros(n, layer.hout, layer.wout, layer.cin_pad, device=x_nchw.device, dtype=dtype)
+    out[..., : k * k * c] = cols.to(dtype)
+    return out
+
+
+class _Pool:
+    """Stream-ordered scratch reuse keyed by element count."""
+
+    def __init__(self, device, dtype):
+        self.device, self.dtype, self.free = device, dtype, {}
+
+    def get(self, shape):
+        numel = math.prod(shape)
+        lst = self.free.get(numel)
+        if lst:
+            return lst.pop().view(shape)
+        return torch.empty(shape, device=self.device, dtype=self.dtype)
+
+    def put(self, *tensors):
+        for t in tensors:
+            if t is not None:
+                self.free.setdefault(t.numel(), []).append(t)
+
+
+class Engine:
+    def __init__(self, model, pixels, chunk, max_groups, compute_dtype=torch.bfloat16, device="cuda", fd_sets=0):
+        """``fd_sets``: extra per-chunk gradient/parameter sets for finite differences (0 none, 1 forward, 2 central)."""
+        lib.load()
+        if not torch.cuda.is_available():
+            raise lib.EngineError("Engine needs an MI355X: no HIP device visible (there is no CPU path).")
+        self.device = torch.device(device)
+        self.dt = compute_dtype
+        self.dtc = lib.dtype_code(compute_dtype)
+        self.plan = Plan(model, pixels)
+        self.chunk, self.G = chunk, max_groups
+        P = self.plan.P
+        f32 = dict(device=self.device, dtype=torch.float32)
+        self.theta = torch.zeros(P, **f32)
+        self.mom = torch.zeros(P, **f32)
+        self.avg = torch.zeros(P, **f32)
+        self.g = torch.zeros(self.G, P, **f32)
+        self.fd_sets = fd_sets
+        self.g_fd = [torch.zeros(self.G, P, **f32) for _ in range(fd_sets)]
+        self.theta_k = torch.zeros(self.G, P, **f32) if fd_sets else None
+        self.running_mean = torch.zeros(self.plan.ch_total, **f32)
+        self.running_var = torch.ones(self.plan.ch_total, **f32)
+        self.num_batches_tracked = 0
+        self.first_step = True
+        # compute-dtype weight copies: [0] one shared set (base pass), [1] one set per chunk (finite-difference passes)
+        self.w_fwd = [torch.zeros(1, self.plan.wc_total, device=self.device, dtype=self.dt), None]
+        self.w_dgrad = [torch.zeros(1, self.plan.wc_total, device=self.device, dtype=self.dt), None]
+        if fd_sets:
+            self.w_fwd[1] = torch.zeros(self.G, self.plan.wc_total, device=self.device, dtype=self.dt)
+            self.w_dgrad[1] = torch.zeros(self.G, self.plan.wc_total, device=self.device, dtype=self.dt)
+        self.n_passes = 1 + fd_sets
+        self.mean_tab = torch.zeros(self.n_passes, self.G, self.plan.ch_total, **f32)
+        self.var_tab = torch.zeros(self.n_passes, self.G, self.plan.ch_total, **f32)
+        unbias = torch.ones(self.plan.ch_total)
+        for L in self.plan.layers:
+            m = chunk * L.hout * L.wout
+            unbias[L.ch_off:L.ch_off + L.cout] = m / (m - 1)
+        self.unbias = unbias.to(self.device)
+        self._alloc_activations()
+        self.mt_ws = torch.zeros(max(self.G, 2) * lib.MT_BLOCKS, **f32)
+        self.sq = torch.zeros(self.G, **f32)
+        self.vnorm2 = torch.zeros(self.G, **f32)
+        self.eps_n = torch.zeros(self.G, **f32)
+        self.norms2 = torch.zeros(2, **f32)
+        self.pool = _Pool(self.device, self.dt)
+        self.load_from_model(model)
+
+    # ------------------------------------------------------------------------------------------------------ buffers --
+    def _alloc_activations(self):
+        n, dev, dt = self.G * self.chunk, self.device, self.dt
+        f32 = dict(device=dev, dtype=torch.float32)
+        max_part, max_slab = 0, 0
+        for L in self.plan.layers:
+            L.x = torch.empty(n, L.hout, L.wout, L.cout, device=dev, dtype=dt)   # raw conv output (pre-BN)
+            L.scale = torch.empty(self.G, L.cout, **f32)
+            L.shift = torch.empty(self.G, L.cout, **f32)
+            L.invstd = torch.empty(self.G, L.cout, **f32)
+            L.coef = torch.empty(self.G, L.cout, 3, **f32)
+            px = n * L.hout * L.wout
+            max_part = max(max_part, 2 * _round_up(px, 128) // 128 * L.cout * 4)  # x4: stride-2 dgrad classes never stat
+            L.split_k = self._choose_split(L)
+            max_slab = max(max_slab, self.G * L.split_k * L.cout * L.taps * L.cin_pad)
+        self.stat_ws = torch.empty(max_part, **f32)
+        self.slab_ws = torch.empty(max_slab, **f32)
+        self.stem_out = torch.empty(n, self.plan.stem.hout, self.plan.stem.wout, 64, device=dev, dtype=dt)
+        if self.plan.stem_pool:
+            hp = (self.plan.stem.hout + 1) // 2
+            self.stem_pooled = torch.empty(n, hp, hp, 64, device=dev, dtype=dt)
+        for b in self.plan.blocks:
+            b.mids = [torch.empty_like(c.x) for c in b.convs[:-1]]              # post BN-ReLU activations inside the block
+            b.out = torch.empty_like(b.convs[-1].x)                              # block output (post add + ReLU)
+            b.pooled = None
+            if b.shortcut is not None and b.stride == 2:
+                b.pooled = torch.empty(n, b.hin // 2, b.win // 2, b.cin, device=dev, dtype=dt)
+        self.feat = torch.empty(n, self.plan.feat, **f32)
+        self.logits = torch.empty(n, self.plan.classes, **f32)
+        self.dlogits = torch.empty(n, self.plan.classes, **f32)
+        self.loss = torch.zeros(self.G, **f32)
+        self.correct = torch.zeros(self.G, **f32)
+
+    def _choose_split(self, L):
+        """Split the pixel reduction of wgrad so that >= ~1000 workgroups exist; slices are multiples of the K-step."""
+        big = L.cin_pad % 128 == 0 and L.cout % 128 == 0 and (L.cin_pad >= 256 or L.cout >= 256)
+        tile = 128 if big else 64
+        tiles = (L.cout // tile) * max(L.cin_pad // tile, 1) * L.taps
+        px = self.chunk * L.hout * L.wout
+        kstep = (32 if self.dt == torch.float32 else 64) if big else 128
+        want = max(1, 1024 // max(tiles * self.G, 1))
+        split = max(1, min(want, px // (kstep * 4)))
+        while split > 1 and (split - 1) * (_round_up(-(-px // split), kstep)) >= px:
+            split -= 1
+        return split
+
+    # ------------------------------------------------------------------------------------------- parameter exchange --
+    def _krsc(self, L, w):
+        return w.permute(0, 2, 3, 1).reshape(-1)
+
+    def load_from_model(self, model):
+        """Mirror parameters/buffers of the container into the arena (KRSC permutation for conv weights)."""
+        named = dict(model.named_parameters())
+        flat = torch.zeros(self.plan.P)
+        conv_names = {f"{L.conv_name}.weight" for L in self.plan.layers}
+        for name in self.plan.param_names:
+            w = named[name].detach().float().cpu()
+            v = w.permute(0, 2, 3, 1).reshape(-1) if name in conv_names else w.reshape(-1)
+            flat[self.plan.offsets[name]:self.plan.offsets[name] + v.numel()] = v
+        self.theta.copy_(flat)
+        bufs = dict(model.named_buffers())
+        rm, rv = torch.zeros(self.plan.ch_total), torch.ones(self.plan.ch_total)
+        for L in self.plan.layers:
+            rm[L.ch_off:L.ch_off + L.cout] = bufs[f"{L.bn_name}.running_mean"].detach().float().cpu()
+            rv[L.ch_off:L.ch_off + L.cout] = bufs[f"{L.bn_name}.running_var"].detach().float().cpu()
+        self.running_mean.copy_(rm)
+        self.running_var.copy_(rv)
+        self.num_batches_tracked = int(bufs[f"{self.plan.stem.bn_name}.num_batches_tracked"])
+
+    def _unflatten(self, flat, name):
+        shape = self.plan.param_shapes[name]
+        v = flat[self.plan.offsets[name]:self.plan.offsets[name] + math.prod(shape)]
+        if len(shape) == 4:
+            co, ci, kh, kw = shape
+            return v.view(co, kh, kw, ci).permute(0, 3, 1, 2).contiguous()
+        return v.view(shape).clone()
+
+    def store_to_model(self, model, with_grad=False):
+        """Write arena parameters / BN buffers (and optionally ``p.grad`` = averaged gradient) back into the container."""
+        flat = self.theta.detach().cpu()
+        gflat = self.avg.detach().cpu() if with_grad else None
+        with torch.no_grad():
+            for name, p in model.named_parameters():
+                p.copy_(self._unflatten(flat, name).to(p.dtype))
+                if with_grad:
+                    p.grad = self._unflatten(gflat, name).to(p.dtype).to(p.device)
+            bufs = dict(model.named_buffers())
+            rm, rv = self.running_mean.cpu(), self.running_var.cpu()
+            for L in self.plan.layers:
+                bufs[f"{L.bn_name}.running_mean"].copy_(rm[L.ch_off:L.ch_off + L.cout])
+                bufs[f"{L.bn_name}.running_var"].copy_(rv[L.ch_off:L.ch_off + L.cout])
+                bufs[f"{L.bn_name}.num_batches_tracked"].fill_(self.num_batches_tracked)
+
+    def momentum_state(self):
+        flat = self.mom.detach().cpu()
+        return [self._unflatten(flat, name) for name in self.plan.param_names]
+
+    def load_momentum(self, tensors):
+        flat = torch.zeros(self.plan.P)
+        for name, t in zip(self.plan.param_names, tensors):
+            v = t.detach().float().cpu()
+            v = v.permute(0, 2, 3, 1).reshape(-1) if v.dim() == 4 else v.reshape(-1)
+            flat[self.plan.offsets[name]:self.plan.offsets[name] + v.numel()] = v
+        self.mom.copy_(flat)
+        self.first_step = False
+
+    # --------------------------------------------------------------------------------------------------- primitives --
+    def prep_weights(self, theta, nsets, per_chunk=False):
+        """fp32 master (one shared set or one per chunk) -> compute-dtype forward and transposed dgrad copies."""
+        slot = 1 if per_chunk else 0
+        wf, wd = self.w_fwd[slot], self.w_dgrad[slot]
+        es = wf.element_size()
+        for L in self.plan.layers:
+            dst_d = wd.data_ptr() + es * L.wc_off if L is not self.plan.stem else None
+            call("fb_weight_prep", theta.data_ptr() + 4 * L.w_off, self.plan.P, self.plan.wc_total, nsets, L.cout, L.taps, L.cin_real,
+                 L.cin_pad, wf.data_ptr() + es * L.wc_off, dst_d, self.dtc)
+
+    def _conv_bn_fwd(self, L, src, G, wsets, theta, pidx):
+        n = G * self.chunk
+        wf = self.w_fwd[1 if wsets > 1 else 0]
+        wptr = wf.data_ptr() + wf.element_size() * L.wc_off
+        evalm = getattr(self, "_eval", False)
+        a = lib.ConvArgs(src.data_ptr(), wptr, L.x.data_ptr(), None, None if evalm else self.stat_ws.data_ptr(), n, L.hin, L.win, L.cin_pad, L.hout, L.wout,
+                         L.cout, L.R, L.S, L.stride, L.pad, 0, self.chunk if wsets > 1 else n, self.plan.wc_total if wsets > 1 else 0,
+                         0, self.dtc)
+        call("fb_conv2d", lib.C.byref(a))
+        if evalm:
+            return
+        px = n * L.hout * L.wout
+        n_mblocks = (px + 127) // 128
+        pstride = self.plan.P if wsets > 1 else 0
+        call("fb_bn_fwd_finalize", self.stat_ws.data_ptr(), n_mblocks, G, L.cout, float(self.chunk * L.hout * L.wout),
+             theta.data_ptr() + 4 * L.g_off, theta.data_ptr() + 4 * L.b_off, pstride, BN_EPS,
+             self.mean_tab[pidx].data_ptr(), self.var_tab[pidx].data_ptr(), self.plan.ch_total, L.ch_off,
+             L.scale.data_ptr(), L.shift.data_ptr(), L.invstd.data_ptr())
+
+    def _bn_apply(self, L, out, G, relu=True, res=None, resL=None):
+        px = G * self.chunk * L.hout * L.wout
+        call("fb_bn_apply", L.x.data_ptr(), out.data_ptr(), L.scale.data_ptr(), L.shift.data_ptr(), _ptr(res),
+             resL.scale.data_ptr() if resL is not None else None, resL.shift.data_ptr() if resL is not None else None,
+             px, L.cout, self.chunk * L.hout * L.wout, 1 if relu else 0, self.dtc)
+
+    def _sl(self, t, G):
+        return t[: G * self.chunk]
+
+    # ------------------------------------------------------------------------------------------------------ forward --
+    def forward(self, patches, labels, G, wsets, theta, pidx):
+        """patches: [G*chunk, H, W, cin_pad] stem patches; labels int64 [G*chunk].  Fills loss/correct/dlogits."""
+        plan = self.plan
+        self._conv_bn_fwd(plan.stem, patches, G, wsets, theta, pidx)
+        self._bn_apply(plan.stem, self.stem_out, G)
+        a = self.stem_out
+        if plan.stem_pool:
+            s = plan.stem
+            call("fb_maxpool3s2_fwd", a.data_ptr(), self.stem_pooled.data_ptr(), G * self.chunk, s.hout, s.wout, 64, self.dtc)
+            a = self.stem_pooled
+        for b in plan.blocks:
+            a0 = a
+            cur = a0
+            for i, L in enumerate(b.convs):
+                self._conv_bn_fwd(L, cur, G, wsets, theta, pidx)
+                if i < len(b.convs) - 1:
+                    self._bn_apply(L, b.mids[i], G)
+                    cur = b.mids[i]
+            last = b.convs[-1]
+            if b.shortcut is not None:
+                src = a0
+                if b.pooled is not None:
+                    call("fb_avgpool2_fwd", a0.data_ptr(), b.pooled.data_ptr(), G * self.chunk, b.hin, b.win, b.cin, self.dtc)
+                    src = b.pooled
+                self._conv_bn_fwd(b.shortcut, src, G, wsets, theta, pidx)
+                self._bn_apply(last, b.out, G, res=b.shortcut.x, resL=b.shortcut)
+            else:
+                self._bn_apply(last, b.out, G, res=a0)
+            a = b.out
+        n = G * self.chunk
+        hw = plan.h_final * plan.h_final
+        call("fb_head_pool", a.data_ptr(), self.feat.data_ptr(), n, hw, plan.feat, self.dtc)
+        pstride = plan.P if wsets > 1 else 0
+        call("fb_head_loss", self.feat.data_ptr(), theta.data_ptr() + 4 * plan.fcw_off, theta.data_ptr() + 4 * plan.fcb_off, pstride,
+             labels.data_ptr(), self.logits.data_ptr(), self.dlogits.data_ptr(), self.loss.data_ptr(), self.correct.data_ptr(), G,
+             self.chunk, plan.feat, plan.classes)
+        return a
+
+    # ----------------------------------------------------------------------------------------------------- backward --
+    def _bn_bwd(self, L, dout, mask, G, gout, pidx, want_dy):
+        """BN (+ReLU mask) backward.  Returns (dx, dy_or_None); dgamma/dbeta go to gout[g] at the layer's arena offsets."""
+        n = G * self.chunk
+        px = n * L.hout * L.wout
+        ppg = self.chunk * L.hout * L.wout
+        n_mblocks = (px + 127) // 128
+        call("fb_bn_bwd_reduce", dout.data_ptr(), _ptr(mask), L.x.data_ptr(), self.mean_tab[pidx].data_ptr(), L.invstd.data_ptr(),
+             self.plan.ch_total, L.ch_off, self.stat_ws.data_ptr(), px, L.cout, ppg, self.dtc)
+        call("fb_bn_bwd_finalize", self.stat_ws.data_ptr(), n_mblocks, G, L.cout, float(ppg), L.scale.data_ptr(),
+             self.mean_tab[pidx].data_ptr(), L.invstd.data_ptr(), self.plan.ch_total, L.ch_off,
+             gout.data_ptr() + 4 * L.g_off, gout.data_ptr() + 4 * L.b_off, self.plan.P, L.coef.data_ptr())
+        dx = self.pool.get((n, L.hout, L.wout, L.cout))
+        dy = self.pool.get((n, L.hout, L.wout, L.cout)) if want_dy else None
+        call("fb_bn_bwd_apply", dout.data_ptr(), _ptr(mask), L.x.data_ptr(), L.coef.data_ptr(), dx.data_ptr(), _ptr(dy), px, L.cout, ppg,
+             self.dtc)
+        return dx, dy
+
+    def _wgrad(self, L, src, dx, G, gout):
+        n = G * self.chunk
+        a = lib.WgradArgs(src.data_ptr(), dx.data_ptr(), self.slab_ws.data_ptr(), n, L.hin, L.win, L.cin_pad, L.hout, L.wout, L.cout,
+                          L.R, L.S, L.stride, L.pad, self.chunk, L.split_k, self.dtc)
+        call("fb_conv2d_wgrad", lib.C.byref(a))
+        call("fb_wgrad_reduce", self.slab_ws.data_ptr(), gout.data_ptr() + 4 * L.w_off, self.plan.P, G, L.split_k, L.cout, L.taps,
+             L.cin_pad, L.cin_real)
+
+    def _dgrad(self, L, dx, G, wsets, addend=None, addend_mode=0):
+        n = G * self.chunk
+        out = self.pool.get((n, L.hin, L.win, L.cin_pad))
+        wd = self.w_dgrad[1 if wsets > 1 else 0]
+        wptr = wd.data_ptr() + wd.element_size() * L.wc_off
+        a = lib.ConvArgs(dx.data_ptr(), wptr, out.data_ptr(), _ptr(addend), None, n, L.hout, L.wout, L.cout, L.hin, L.win, L.cin_pad,
+                         L.R, L.S, L.stride, L.pad, 1, self.chunk if wsets > 1 else n, self.plan.wc_total if wsets > 1 else 0,
+                         addend_mode, self.dtc)
+        call("fb_conv2d", lib.C.byref(a))
+        return out
+
+    def backward(self, patches, G, wsets, theta, gout, pidx):
+        """Explicit backward through the DAG; per-chunk gradients are written to ``gout[g]`` (shape [G, P])."""
+        plan, pool = self.plan, self.pool
+        n = G * self.chunk
+        hw = plan.h_final * plan.h_final
+        pstride = plan.P if wsets > 1 else 0
+        d = pool.get((n, plan.h_final, plan.h_final, plan.feat))
+        call("fb_head_bwd", self.feat.data_ptr(), self.dlogits.data_ptr(), theta.data_ptr() + 4 * plan.fcw_off, pstride,
+             gout.data_ptr() + 4 * plan.fcw_off, gout.data_ptr() + 4 * plan.fcb_off, plan.P, d.data_ptr(), G, self.chunk, hw, plan.feat,
+             plan.classes, self.dtc)
+        for bi in range(len(plan.blocks) - 1, -1, -1):
+            b = plan.blocks[bi]
+            a0 = plan.blocks[bi - 1].out if bi > 0 else (self.stem_pooled if plan.stem_pool else self.stem_out)
+            last = b.convs[-1]
+            dx, dy = self._bn_bwd(last, d, b.out, G, gout, pidx, want_dy=True)   # dy = d * (out > 0)
+            pool.put(d)
+            srcs = [a0] + b.mids
+            cur_dx = dx
+            for i in range(len(b.convs) - 1, -1, -1):
+                L = b.convs[i]
+                self._wgrad(L, srcs[i], cur_dx, G, gout)
+                if i > 0:
+                    d_mid = self._dgrad(L, cur_dx, G, wsets)
+                    pool.put(cur_dx)
+                    cur_dx, _ = self._bn_bwd(b.convs[i - 1], d_mid, b.mids[i - 1], G, gout, pidx, want_dy=False)
+                    pool.put(d_mid)
+            first = b.convs[0]
+            if b.shortcut is not None:
+                S = b.shortcut
+                dxs, _ = self._bn_bwd(S, dy, None, G, gout, pidx, want_dy=False)
+                src = b.pooled if b.pooled is not None else a0
+                self._wgrad(S, src, dxs, G, gout)
+                d_p = self._dgrad(S, dxs, G, wsets)
+                pool.put(dxs)
+                d = self._dgrad(first, cur_dx, G, wsets, addend=d_p, addend_mode=2 if b.pooled is not None else 1)
+                pool.put(d_p)
+            else:
+                d = self._dgrad(first, cur_dx, G, wsets, addend=dy, addend_mode=1)
+            pool.put(cur_dx, dy)
+        S = plan.stem
+        if plan.stem_pool:
+            d_r = pool.get((n, S.hout, S.wout, 64))
+            call("fb_maxpool3s2_bwd", self.stem_out.data_ptr(), d.data_ptr(), d_r.data_ptr(), n, S.hout, S.wout, 64, self.dtc)
+            pool.put(d)
+            d = d_r
+        dx, _ = self._bn_bwd(S, d, self.stem_out, G, gout, pidx, want_dy=False)
+        pool.put(d)
+        self._wgrad(S, patches, dx, G, gout)
+        pool.put(dx)
+
+    # ------------------------------------------------------------------------------------------- chunk-group gradient --
+    def group_gradient(self, patches, labels, G, gout, wsets=1, theta=None, pidx=0):
+        """fwd + bwd for ``G`` chunks: per-chunk raw gradients in gout[:G], losses/corrects in self.loss/self.correct."""
+        theta = self.theta if theta is None else theta
+        self.forward(patches, labels, G, wsets, theta, pidx)
+        self.backward(patches, G, wsets, theta, gout, pidx)
+
+    # --------------------------------------------------------------------------------------- full-batch gradient + step --
+    def full_gradient(self, patches, labels, lr, block_strength=0.0, eps=1e-2, implementation="forward-differences",
+                      chunk_ids=None, counter0=0):
+        """Accumulate the regularised gradient over chunks (reference training.py:144-174) into ``self.avg``.
+
+        ``patches``/``labels`` hold the whole resident dataset; chunk k = rows [k*chunk, (k+1)*chunk).  ``chunk_ids``
+        must be a contiguous range (this rank's shard).  Returns device tensors (loss_k, correct_k, n_k) for the chunks.
+        """
+        chunk, P, G = self.chunk, self.plan.P, self.G
+        n_chunks = patches.shape[0] // chunk if chunk_ids is None else len(chunk_ids)
+        k_first = 0 if chunk_ids is None else chunk_ids[0]
+        f32 = dict(device=self.device, dtype=torch.float32)
+        loss_all, correct_all, sq_all = torch.empty(n_chunks, **f32), torch.empty(n_chunks, **f32), torch.empty(n_chunks, **f32)
+        fd = block_strength != 0
+        if fd:
+            if implementation not in ("forward-differences", "forward-differences-legacy", "central-differences"):
+                raise NotImplementedError(f"grad_reg.implementation={implementation!r} needs double backward; the engine implements the "
+                                          "finite-difference variants only")
+            need = 2 if implementation == "central-differences" else 1
+            if self.fd_sets < need:
+                raise lib.EngineError(f"Engine was built with fd_sets={self.fd_sets}; {implementation} needs {need}")
+        if counter0 == 0:
+            self.avg.zero_()
+        self.prep_weights(self.theta, 1)
+        done = 0
+        while done < n_chunks:
+            g_n = min(G, n_chunks - done)
+            lo = (k_first + done) * chunk
+            xb, yb = patches[lo:lo + g_n * chunk], labels[lo:lo + g_n * chunk]
+            self.group_gradient(xb, yb, g_n, self.g, 1, self.theta, 0)
+            loss_all[done:done + g_n].copy_(self.loss[:g_n])
+            correct_all[done:done + g_n].copy_(self.correct[:g_n])
+            n_passes = 1
+            if not fd:
+                call("fb_mt_accumulate", self.avg.data_ptr(), self.g.data_ptr(), P, g_n, P, counter0 + done, self.sq.data_ptr(),
+                     self.mt_ws.data_ptr())
+            else:
+                legacy = implementation == "forward-differences-legacy"
+                central = implementation == "central-differences"
+                s = 1.0 if legacy else float(block_strength)
+                cf = lr / 4 * (block_strength if legacy else 1.0)
+                call("fb_mt_sqnorm", self.g.data_ptr(), P, g_n, P, 1.0, self.sq.data_ptr(), self.mt_ws.data_ptr())
+                call("fb_mt_sqnorm", self.g.data_ptr(), P, g_n, P, s, self.vnorm2.data_ptr(), self.mt_ws.data_ptr())
+                call("fb_mt_fd_perturb", self.theta.data_ptr(), self.g.data_ptr(), P, g_n, P, s, float(eps), 0.5 if central else 1.0,
+                     self.vnorm2.data_ptr(), self.eps_n.data_ptr(), self.theta_k.data_ptr())
+                self.prep_weights(self.theta_k, g_n, per_chunk=True)
+                self.group_gradient(xb, yb, g_n, self.g_fd[0], 2, self.theta_k, 1)
+                n_passes = 2
+                if central:
+                    call("fb_mt_fd_perturb", self.theta.data_ptr(), self.g.data_ptr(), P, g_n, P, s, float(eps), -0.5,
+                         self.vnorm2.data_ptr(), self.eps_n.data_ptr(), self.theta_k.data_ptr())
+                    self.prep_weights(self.theta_k, g_n, per_chunk=True)
+                    self.group_gradient(xb, yb, g_n, self.g_fd[1], 2, self.theta_k, 2)
+                    n_passes = 3
+                    call("fb_mt_fd_combine_accumulate", self.avg.data_ptr(), self.g.data_ptr(), self.g_fd[0].data_ptr(),
+                         self.g_fd[1].data_ptr(), P, g_n, P, self.eps_n.data_ptr(), cf, counter0 + done)
+                else:
+                    call("fb_mt_fd_combine_accumulate", self.avg.data_ptr(), self.g.data_ptr(), self.g_fd[0].data_ptr(),
+                         self.g.data_ptr(), P, g_n, P, self.eps_n.data_ptr(), cf, counter0 + done)
+            sq_all[done:done + g_n].copy_(self.sq[:g_n])
+            call("fb_bn_running_update", self.running_mean.data_ptr(), self.running_var.data_ptr(), self.mean_tab.data_ptr(),
+                 self.var_tab.data_ptr(), n_passes, self.G * self.plan.ch_total, self.unbias.data_ptr(), g_n, self.plan.ch_total,
+                 BN_MOMENTUM)
+            self.num_batches_tracked += g_n * n_passes
+            done += g_n
+        return loss_all, correct_all, sq_all
+
+    def grad_and_param_sqnorm(self):
+        """Device tensor [|avg|^2, |theta|^2] (clip norm, reference training.py:202-204; param_norm, :92)."""
+        call("fb_mt_norms2", self.avg.data_ptr(), self.theta.data_ptr(), self.plan.P, self.norms2.data_ptr(), self.mt_ws.data_ptr())
+        return self.norms2
+
+    def sgd_step(self, lr, weight_decay, momentum, dampening, nesterov, grad_clip=None, lo=0, n=None):
+        """Clip by the global norm in ``self.norms2[0]`` and apply the Nesterov-SGD update on arena range [lo, lo+n)."""
+        n = self.plan.P - lo if n is None else n
+        call("fb_mt_clip_sgd", self.theta.data_ptr() + 4 * lo, self.avg.data_ptr() + 4 * lo, self.mom.data_ptr() + 4 * lo, n,
+             self.norms2.data_ptr(), -1.0 if grad_clip is None else float(grad_clip), float(lr), float(weight_decay), float(momentum),
+             float(dampening), 1 if nesterov else 0, 1 if self.first_step else 0)
+        self.first_step = False
+
+    # ------------------------------------------------------------------------------------------------------ evaluation --
+    def evaluate_batch(self, patches, labels):
+        """BN in eval mode (running statistics), mean CE and #correct of one batch of <= G*chunk images
+        (reference training.py:365-380).  Returns python floats (loss_mean, n_correct)."""
+        n = patches.shape[0]
+        if n > self.G * self.chunk:
+            raise lib.EngineError("evaluate_batch: batch larger than the engine's activation buffers")
+        self.prep_weights(self.theta, 1)
+        for L in self.plan.layers:
+            gamma, beta = self.theta[L.g_off:L.g_off + L.cout], self.theta[L.b_off:L.b_off + L.cout]
+            rm, rv = self.running_mean[L.ch_off:L.ch_off + L.cout], self.running_var[L.ch_off:L.ch_off + L.cout]
+            sc = gamma * torch.rsqrt(rv + BN_EPS)
+            L.scale[0].copy_(sc)
+            L.shift[0].copy_(beta - rm * sc)
+        chunk, self.chunk, self._eval = self.chunk, n, True
+        try:
+            self.forward(patches, labels, 1, 1, self.theta, 0)
+        finally:
+            self.chunk, self._eval = chunk, False
+        return float(self.loss[0]), float(self.correct[0])

@@ -1,0 +1,158 @@
+"""ctypes binding of ``libfbengine.so`` (C ABI declared in ``include/fb_engine.h``).
+
+There is no CPU fallback: importing this module without the built library, or calling into it without a GPU, raises.
+Wrappers take ``torch`` tensors only to read ``data_ptr()`` -- memory and streams are PyTorch-ROCm plumbing.
+"""
+import ctypes as C
+import os
+
+import torch
+
+FB_F32, FB_BF16 = 0, 1
+MT_BLOCKS = 1024
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libfbengine.so")
+
+c_void_p, c_int, c_i64, c_float, c_double = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("src", c_void_p), ("wgt", c_void_p), ("dst", c_void_p), ("addend", c_void_p), ("stat_partial", c_void_p),
+                ("n_img", c_int), ("Hs", c_int), ("Ws", c_int), ("Cs", c_int), ("Hd", c_int), ("Wd", c_int), ("Cd", c_int),
+                ("R", c_int), ("S", c_int), ("stride", c_int), ("pad", c_int), ("mode", c_int),
+                ("imgs_per_wset", c_int), ("wset_stride", c_i64), ("addend_mode", c_int), ("dtype", c_int)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("x", c_void_p), ("dy", c_void_p), ("dw_partial", c_void_p),
+                ("n_img", c_int), ("Hs", c_int), ("Ws", c_int), ("Cs", c_int), ("Hd", c_int), ("Wd", c_int), ("Cd", c_int),
+                ("R", c_int), ("S", c_int), ("stride", c_int), ("pad", c_int),
+                ("imgs_per_group", c_int), ("split_k", c_int), ("dtype", c_int)]
+
+
+_SIGS = {
+    "fb_conv2d": [C.POINTER(ConvArgs), c_void_p],
+    "fb_conv2d_wgrad": [C.POINTER(WgradArgs), c_void_p],
+    "fb_wgrad_reduce": [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "fb_weight_prep": [c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
+    "fb_bn_fwd_finalize": [c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_i64, c_float, c_void_p, c_void_p, c_int,
+                           c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "fb_bn_apply": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_int, c_void_p],
+    "fb_bn_running_update": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_void_p, c_int, c_int, c_float, c_void_p],
+    "fb_bn_bwd_reduce": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_i64, c_int, c_i64, c_int, c_void_p],
+    "fb_bn_bwd_finalize": [c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                           c_i64, c_void_p, c_void_p],
+    "fb_bn_bwd_apply": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_void_p],
+    "fb_avgpool2_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "fb_maxpool3s2_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "fb_maxpool3s2_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "fb_head_pool": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "fb_head_loss": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                     c_void_p],
+    "fb_head_bwd": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                    c_void_p],
+    "fb_mt_sqnorm": [c_void_p, c_i64, c_int, c_i64, c_float, c_void_p, c_void_p, c_void_p],
+    "fb_mt_accumulate": [c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_void_p, c_void_p, c_void_p],
+    "fb_mt_fd_perturb": [c_void_p, c_void_p, c_i64, c_int, c_i64, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
+    "fb_mt_fd_combine_accumulate": [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_void_p, c_float, c_int, c_void_p],
+    "fb_mt_norms2": [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p],
+    "fb_mt_clip_sgd": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_float, c_float, c_float, c_float, c_float, c_int, c_int, c_void_p],
+    "fb_mt_scale": [c_void_p, c_i64, c_float, c_void_p],
+}
+EXPORTS = tuple(_SIGS) + ("fb_last_error_string", "fb_abi_version", "fb_profile_enable", "fb_profile_read")
+PROF_CLASSES = ("igemm_fwd", "igemm_dgrad", "wgrad")
+
+
+def profile_enable(on, capacity=32768):
+    lib = load()
+    lib.fb_profile_enable.argtypes, lib.fb_profile_enable.restype = [c_int, c_int], c_int
+    if lib.fb_profile_enable(1 if on else 0, capacity) != 0:
+        raise EngineError(lib.fb_last_error_string().decode())
+
+
+def profile_read():
+    """-> {class: (ms, launches, dropped)} for launches recorded since the previous read (synchronises on them)."""
+    lib = load()
+    lib.fb_profile_read.argtypes = [C.POINTER(c_double), C.POINTER(c_i64), C.POINTER(c_i64)]
+    ms, n, d = (c_double * 3)(), (c_i64 * 3)(), (c_i64 * 3)()
+    if lib.fb_profile_read(ms, n, d) != 0:
+        raise EngineError(lib.fb_last_error_string().decode())
+    return {k: (ms[i], n[i], d[i]) for i, k in enumerate(PROF_CLASSES)}
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (no compute).  Raises if it has not been built -- there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(_LIB_PATH):
+            raise EngineError(f"{_LIB_PATH} is missing: run `python -m fullbatchtraining_amd.build` (needs hipcc). "
+                              "The engine has no CPU or PyTorch fallback.")
+        lib = C.CDLL(_LIB_PATH)
+        for name, sig in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.argtypes, fn.restype = sig, c_int
+        lib.fb_last_error_string.restype = C.c_char_p
+        lib.fb_abi_version.restype = c_int
+        _lib = lib
+    return _lib
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Invoke an entry point on torch's current stream; raises EngineError on a non-zero status."""
+    lib = load()
+    status = getattr(lib, name)(*args, _stream())
+    if status != 0:
+        raise EngineError(f"{name} failed ({status}): {lib.fb_last_error_string().decode()}")
+
+
+def dtype_code(dtype):
+    if dtype == torch.float32:
+        return FB_F32
+    if dtype == torch.bfloat16:
+        return FB_BF16
+    raise EngineError(f"unsupported compute dtype {dtype}")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# thin tensor-level wrappers (shapes are read from the tensors; NHWC activations)
+# ---------------------------------------------------------------------------------------------------------------------
+def conv2d(src, wgt, dst, R, S, stride, pad, mode, addend=None, addend_mode=0, stat_partial=None, imgs_per_wset=0, wset_stride=0):
+    n, hs, ws, cs = src.shape
+    _, hd, wd, cd = dst.shape
+    a = ConvArgs(_ptr(src), _ptr(wgt), _ptr(dst), _ptr(addend), _ptr(stat_partial), n, hs, ws, cs, hd, wd, cd, R, S, stride, pad, mode,
+                 imgs_per_wset, wset_stride, addend_mode, dtype_code(src.dtype))
+    call("fb_conv2d", C.byref(a))
+
+
+def conv2d_wgrad(x, dy, dw_partial, R, S, stride, pad, imgs_per_group, split_k):
+    n, hs, ws, cs = x.shape
+    _, hd, wd, cd = dy.shape
+    a = WgradArgs(_ptr(x), _ptr(dy), _ptr(dw_partial), n, hs, ws, cs, hd, wd, cd, R, S, stride, pad, imgs_per_group, split_k,
+                  dtype_code(x.dtype))
+    call("fb_conv2d_wgrad", C.byref(a))
+
+
+def wgrad_reduce(dw_partial, out, out_group_stride, n_groups, split_k, Cd, taps, Cs_pad, Cs_real):
+    call("fb_wgrad_reduce", _ptr(dw_partial), _ptr(out), out_group_stride, n_groups, split_k, Cd, taps, Cs_pad, Cs_real)
+
+
+def weight_prep(master, wset_stride_in, wset_stride_out, n_wsets, Cout, taps, Cin_real, Cin_pad, w_fwd, w_dgrad, dtype):
+    call("fb_weight_prep", _ptr(master), wset_stride_in, wset_stride_out, n_wsets, Cout, taps, Cin_real, Cin_pad, _ptr(w_fwd),
+         _ptr(w_dgrad), dtype_code(dtype))

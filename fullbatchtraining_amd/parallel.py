@@ -1,0 +1,130 @@
+"""Data-parallel sharding of the full-batch gradient over the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+Reference behaviour being replaced: ``DistributedSampler`` + per-rank running mean pre-divided by the world size + one
+flat ``all_reduce`` (``fullbatch/training/utils.py:31-41``, ``training.py:168,179-180``).  That scheme is *not* the exact
+mean and changes chunk composition; here the 1-process semantics are kept:
+
+  * chunk k is always samples [k*chunk, (k+1)*chunk); rank r owns a contiguous range of chunks (``ShardPlan``)
+  * each rank folds its chunks into a local running mean, scales it by K_r/K, and ONE reduce-scatter(SUM) yields the
+    exact global mean, sharded;  the global clip norm needs one 4-byte all-reduce;  clip + Nesterov-SGD run on the
+    local shard with sharded momentum (ZeRO-1 style);  ONE all-gather republishes the updated parameters
+  * BN running statistics: the sequential EMA is linear in the per-chunk batch statistics, so rank-local EMA
+    contributions are recombined exactly (``combine_running_stats``)
+  * per-chunk stats (loss, #correct, squared norms) are all-gathered (K floats each) so every rank logs full stats
+
+The collective wiring is independent of the compute backend: ``ShardOps`` supplies scale / squared-norm / update
+callables (HIP kernels in the product, CPU stand-ins in the gloo tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+class ShardPlan:
+    """Contiguous chunk ranges: the first ``K % world`` ranks own one chunk more."""
+
+    def __init__(self, n_chunks, world, rank):
+        q, r = divmod(n_chunks, world)
+        self.n_chunks, self.world, self.rank = n_chunks, world, rank
+        self.counts = [q + (1 if i < r else 0) for i in range(world)]
+        self.firsts = [sum(self.counts[:i]) for i in range(world)]
+        self.first, self.count = self.firsts[rank], self.counts[rank]
+
+
+def _reduce_scatter_sum(out_shard, full, group=None):
+    if dist.get_backend(group) == "gloo":      # gloo has no reduce_scatter: all-reduce and keep the local shard
+        dist.all_reduce(full, group=group)
+        n = out_shard.numel()
+        out_shard.copy_(full[dist.get_rank(group) * n:(dist.get_rank(group) + 1) * n])
+    else:
+        dist.reduce_scatter_tensor(out_shard, full, op=dist.ReduceOp.SUM, group=group)
+
+
+class ShardOps:
+    """Compute callbacks used by ``reduce_scatter_update_all_gather``."""
+
+    def __init__(self, scale, sqnorm, update):
+        self.scale, self.sqnorm, self.update = scale, sqnorm, update
+
+
+def reduce_scatter_update_all_gather(avg, theta, plan, ops, group=None):
+    """avg: this rank's local running mean (flat, numel divisible by world); theta: replicated parameters (flat).
+
+    On return ``theta`` holds the updated parameters on every rank, ``avg[lo:hi]`` the (clipped) global mean shard.
+    Returns the global squared gradient norm (0-d tensor on avg's device)."""
+    world, rank = plan.world, plan.rank
+    P = avg.numel()
+    assert P % world == 0, "arena must be padded to a multiple of the world size"
+    n = P // world
+    lo = rank * n
+    ops.scale(avg, plan.count / plan.n_chunks)
+    shard = torch.empty(n, device=avg.device, dtype=avg.dtype)
+    _reduce_scatter_sum(shard, avg, group)
+    avg[lo:lo + n].copy_(shard)
+    gnorm2 = ops.sqnorm(avg[lo:lo + n]).reshape(1).clone()
+    dist.all_reduce(gnorm2, group=group)
+    ops.update(lo, n, gnorm2)
+    new_shard = theta[lo:lo + n].clone()
+    dist.all_gather_into_tensor(theta, new_shard, group=group)
+    return gnorm2[0]
+
+
+def all_gather_chunk_stats(local, plan, group=None):
+    """local: [count_r] per-chunk values of this rank -> [K] in chunk order on every rank."""
+    width = max(plan.counts)
+    padded = torch.zeros(width, device=local.device, dtype=local.dtype)
+    padded[:local.numel()] = local
+    out = torch.empty(plan.world * width, device=local.device, dtype=local.dtype)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    return torch.cat([out[r * width:r * width + plan.counts[r]] for r in range(plan.world)])
+
+
+def combine_running_stats(r0, r_local, plan, updates_per_chunk, momentum=0.1, group=None):
+    """Exact recombination of rank-local sequential EMAs.
+
+    r_local = keep^{n_r} r0 + S_r with n_r = updates of rank r; the 1-process result is
+    keep^{N} r0 + sum_r keep^{(updates after rank r)} S_r.  r0/r_local: [2, ch] (mean row, var row)."""
+    keep = 1.0 - momentum
+    n_r = [c * updates_per_chunk for c in plan.counts]
+    s_local = r_local - (keep ** n_r[plan.rank]) * r0
+    gathered = torch.empty(plan.world * s_local.numel(), device=s_local.device, dtype=s_local.dtype)
+    dist.all_gather_into_tensor(gathered, s_local.reshape(-1).contiguous(), group=group)
+    gathered = gathered.view(plan.world, *s_local.shape)
+    out = (keep ** sum(n_r)) * r0
+    for r in range(plan.world):
+        after = sum(n_r[r + 1:])
+        out = out + (keep ** after) * gathered[r]
+    return out
+
+
+def sharded_update(trainer, loss_k, correct_k, sq_k, lr):
+    """Product wiring of the above for ``FullBatchTrainer`` (HIP kernels as ShardOps)."""
+    from .lib import call
+    eng, hyp, plan = trainer.engine, trainer.cfg.hyp, trainer.shard
+    o = hyp.optim
+    P = eng.plan.P
+
+    def scale(t, a):
+        call("fb_mt_scale", t.data_ptr(), t.numel(), float(a))
+
+    def sqnorm(t):
+        call("fb_mt_norms2", t.data_ptr(), None, t.numel(), eng.norms2.data_ptr(), eng.mt_ws.data_ptr())
+        return eng.norms2[0]
+
+    def update(lo, n, gnorm2):
+        eng.norms2[0:1].copy_(gnorm2)
+        eng.sgd_step(lr, o.weight_decay, o.momentum, o.dampening, o.nesterov, hyp.grad_clip, lo=lo, n=n)
+
+    # parameter norm of the (replicated) pre-update parameters for the stats
+    call("fb_mt_norms2", eng.theta.data_ptr(), None, P, eng.norms2.data_ptr(), eng.mt_ws.data_ptr())
+    pnorm2 = eng.norms2[0].clone()
+    gnorm2 = reduce_scatter_update_all_gather(eng.avg, eng.theta, plan, ShardOps(scale, sqnorm, update))
+    eng.norms2[0] = gnorm2
+    eng.norms2[1] = pnorm2
+    # BN running statistics: recombine the rank-local EMAs
+    passes = 1 + (0 if hyp.grad_reg.block_strength == 0 else (2 if hyp.grad_reg.implementation == "central-differences" else 1))
+    r_local = torch.stack([eng.running_mean, eng.running_var])
+    combined = combine_running_stats(trainer._running0, r_local, plan, passes)
+    eng.running_mean.copy_(combined[0])
+    eng.running_var.copy_(combined[1])
+    eng.num_batches_tracked += (plan.n_chunks - plan.count) * passes
+    return (all_gather_chunk_stats(loss_k, plan), all_gather_chunk_stats(correct_k, plan), all_gather_chunk_stats(sq_k, plan))

@@ -1,0 +1,337 @@
+"""Drop-in counterpart of the reference's full-batch branch of ``fullbatch.training.train``.
+
+Mirrors, for ``hyp.train_stochastic=False``:
+  train                      reference fullbatch/training/training.py:50-75, 217-239, 288-340
+  gradient_evaluation        :226-234   (closure: accumulate, stats, clip)          -> Engine.full_gradient / sgd_step
+  _accumulate_full_gradient  :121-185
+  _record_stats              :85-119    (same keys, same formulas)
+  _modify_gradient_params    :187-215   (global-norm clip; norm-bias and gradient noise are off-path -> NotImplementedError)
+  evaluate                   :343-388
+  get_loss_fn                :391-413   (default CrossEntropyLoss only; it is fused into the head kernel)
+  optim_interface            fullbatch/training/optimizers.py:10-93 (Gradient Descent / line_search none; cosine-*, warm-up)
+  _save_to_checkpoint / _load_from_checkpoint   fullbatch/training/utils.py:43-70 (same 5-list layout)
+
+All arithmetic of a step runs in ``libfbengine.so`` on the GPU; torch optimizers/schedulers are instantiated only as
+*state containers* so that ``optimizer.state_dict()`` / ``scheduler.state_dict()`` in checkpoints have the reference's
+exact layout and the LR sequence is produced by the same torch code the reference calls.
+"""
+import logging
+import os
+import time
+from collections import defaultdict
+
+import torch
+from torch.optim.lr_scheduler import _LRScheduler
+
+from .engine import Engine, stem_patches
+
+log = logging.getLogger("fullbatchtraining_amd")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# LR schedule objects (state containers; reference optimizers.py:69-93, additional_optimizers/scheduler.py:32-111)
+# ----------------------------------------------------------------------------------------------------------------------
+class GradualWarmupScheduler(_LRScheduler):
+    """Linear warm-up from 0 (multiplier 1.0) to the base lr over ``total_epoch`` steps, then hands over to
+    ``after_scheduler``.  Attribute names and ``state_dict`` layout follow the reference so checkpoints interchange."""
+
+    def __init__(self, optimizer, multiplier, total_epoch, after_scheduler=None):
+        if multiplier < 1.0:
+            raise ValueError("multiplier should be greater thant or equal to 1.")
+        self.multiplier, self.total_epoch, self.after_scheduler, self.finished = multiplier, total_epoch, after_scheduler, False
+        super().__init__(optimizer)
+
+    def get_lr(self):
+        if self.last_epoch > self.total_epoch:
+            if self.after_scheduler:
+                if not self.finished:
+                    self.after_scheduler.base_lrs = [b * self.multiplier for b in self.base_lrs]
+                    self.finished = True
+                return self.after_scheduler.get_last_lr()
+            return [b * self.multiplier for b in self.base_lrs]
+        if self.multiplier == 1.0:
+            return [b * (float(self.last_epoch) / self.total_epoch) for b in self.base_lrs]
+        return [b * ((self.multiplier - 1.0) * self.last_epoch / self.total_epoch + 1.0) for b in self.base_lrs]
+
+    def step(self, epoch=None):
+        if self.finished and self.after_scheduler:
+            self.after_scheduler.step(None if epoch is None else epoch - self.total_epoch)
+            self._last_lr = self.after_scheduler.get_last_lr()
+        else:
+            return super().step(epoch)
+
+    def state_dict(self):
+        state = {k: v for k, v in self.__dict__.items() if k != "optimizer"}
+        state["after_scheduler"] = {k: v for k, v in self.after_scheduler.__dict__.items() if k != "optimizer"}
+        return state
+
+    def load_state_dict(self, state_dict):
+        after = state_dict.pop("after_scheduler")
+        self.after_scheduler.__dict__.update(after)
+        self.__dict__.update(state_dict)
+
+
+def optim_interface(model, cfg_hyp):
+    """Only the branch on the hot path: ``Gradient Descent`` + ``line_search: none`` -> torch.optim.SGD (state container)."""
+    if cfg_hyp.optim.name != "Gradient Descent" or cfg_hyp.optim.get("line_search", "none") != "none":
+        raise NotImplementedError(f"optimizer {cfg_hyp.optim.name!r}/{cfg_hyp.optim.get('line_search')!r}: only plain gradient "
+                                  "descent with Nesterov momentum is fused into the engine")
+    if cfg_hyp.optim_modification.name != "none":
+        raise NotImplementedError(f"optim_modification {cfg_hyp.optim_modification.name!r} is outside the engine's scope")
+    if cfg_hyp.only_linear_layers_weight_decay:
+        raise NotImplementedError("only_linear_layers_weight_decay=True needs per-tensor weight decay (not on the hot path)")
+    params = {k: v for k, v in cfg_hyp.optim.items() if k not in ("name", "line_search")}
+    optimizer = torch.optim.SGD(model.parameters(), **params)
+    sched = cfg_hyp.scheduler
+    if sched == "cosine-decay-floored":
+        scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, cfg_hyp.steps, eta_min=cfg_hyp.optim.lr / 25)
+    elif sched == "cosine-decay":
+        scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, cfg_hyp.steps, eta_min=0.0)
+    elif sched == "cosine-4000":
+        scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, 4000, eta_min=0.0)
+    elif sched == "linear":
+        scheduler = torch.optim.lr_scheduler.MultiStepLR(
+            optimizer, milestones=[cfg_hyp.steps // 2.667, cfg_hyp.steps // 1.6, cfg_hyp.steps // 1.142], gamma=0.1)
+    elif sched == "exponential":
+        scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=0.99)
+    elif sched in ["", " ", None]:
+        scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=[], gamma=1)
+    else:
+        raise ValueError(f"Invalid scheduler {sched} provided.")
+    if cfg_hyp.warmup > 0:
+        scheduler = GradualWarmupScheduler(optimizer, multiplier=1.0, total_epoch=cfg_hyp.warmup, after_scheduler=scheduler)
+    return optimizer, scheduler
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# checkpoints (reference training/utils.py:43-70)
+# ----------------------------------------------------------------------------------------------------------------------
+def _sync_optimizer_state(engine, model, optimizer):
+    """Expose the arena's momentum as torch SGD state so ``optimizer.state_dict()`` has the reference layout."""
+    if engine.first_step:
+        return
+    for p, buf in zip(model.parameters(), engine.momentum_state()):
+        optimizer.state[p]["momentum_buffer"] = buf.to(p.device, p.dtype)
+
+
+def _save_to_checkpoint(model, optimizer, scheduler, scaler, counter, file="checkpoints/fb.pth", engine=None):
+    if engine is not None:
+        engine.store_to_model(model)
+        _sync_optimizer_state(engine, model, optimizer)
+    optim_state, model_state, scheduler_state = optimizer.state_dict(), model.state_dict(), scheduler.state_dict()
+    scaler_state = scaler.state_dict() if scaler is not None else None
+    torch.save([optim_state, model_state, scheduler_state, scaler_state, counter.step], file)
+
+
+def _load_from_checkpoint(model, optimizer, scheduler, scaler, counter, max_steps, device=None, file="checkpoints/fb.pth", engine=None):
+    try:
+        optim_state, model_state, scheduler_state, scaler_state, step = torch.load(file, map_location=device, weights_only=False)
+    except FileNotFoundError:
+        print("No existing checkpoint found. Starting to train from step 0.")
+        return
+    model.load_state_dict(model_state)
+    optimizer.load_state_dict(optim_state)
+    scheduler.load_state_dict(scheduler_state)
+    counter.step = step
+    if engine is not None:
+        engine.load_from_model(model)
+        bufs = [optimizer.state[p].get("momentum_buffer") for p in model.parameters() if p in optimizer.state]
+        if len(bufs) == len(list(model.parameters())) and all(b is not None for b in bufs):
+            engine.load_momentum(bufs)
+    if step >= max_steps:
+        raise ValueError("Maximum step size reached. Terminating computations.")
+    print(f"Existing checkpoint loaded successfully. Continuing to train from step {step}.")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def get_loss_fn(cfg_hyp, batch_size):
+    if cfg_hyp.label_smoothing not in [None, "", 0, 0.0] or cfg_hyp.loss_modification is not None:
+        raise NotImplementedError("label smoothing / loss modifications are off the hot path; the fused head kernel "
+                                  "implements torch.nn.CrossEntropyLoss() (mean)")
+    return torch.nn.CrossEntropyLoss()
+
+
+def _stage(loader, device):
+    """Materialise a (static, unaugmented) loader as device-resident tensors in loader order (drop_last honoured)."""
+    if isinstance(loader, (tuple, list)) and torch.is_tensor(loader[0]):
+        return loader[0].to(device), loader[1].to(device=device, dtype=torch.long)
+    xs, ys = [], []
+    for x, y in loader:
+        xs.append(x)
+        ys.append(y)
+    return torch.cat(xs).to(device), torch.cat(ys).to(device=device, dtype=torch.long)
+
+
+def _check_scope(cfg):
+    hyp = cfg.hyp
+    if hyp.train_stochastic or hyp.train_switch_stochastic is not None:
+        raise NotImplementedError("the engine implements the full-batch branch (hyp.train_stochastic=False) only")
+    if hyp.grad_reg.acc_strength != 0:
+        raise NotImplementedError("grad_reg.acc_strength != 0 (pre-pass over the dataset) is not implemented yet")
+    if hyp.batch_clip is not None or hyp.norm_bias.strength > 0 or hyp.grad_noise["additive"] is not None \
+            or hyp.grad_noise["multiplicative"] is not None or hyp.evaluate_ema:
+        raise NotImplementedError("batch_clip / norm_bias / grad_noise / EMA evaluation are off the hot path")
+    if hyp.grad_clip is not None and float(hyp.grad_clip_norm) != 2.0:
+        raise NotImplementedError("only the global L2 clip (grad_clip_norm=2) is fused")
+    if hyp.shuffle:
+        raise NotImplementedError("hyp.shuffle=True changes chunk composition every step; resident data is sequential")
+    if cfg.data.get("augmentations_train"):
+        log.warning("data.augmentations_train is set: the device-resident feed stages the loader ONCE (static dataset).")
+
+
+class FullBatchTrainer:
+    """Owns the engine, the resident dataset and the optimizer/scheduler state containers for one training run."""
+
+    def __init__(self, model, trainloader, validloader, setup, cfg):
+        _check_scope(cfg)
+        self.cfg, self.model = cfg, model
+        self.device = torch.device(setup["device"]) if not isinstance(setup["device"], torch.device) else setup["device"]
+        self.optimizer, self.scheduler = optim_interface(model, cfg.hyp)
+        get_loss_fn(cfg.hyp, cfg.data.batch_size)
+        self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        self.rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+        X, Y = _stage(trainloader, self.device)
+        block = min(cfg.data.batch_size, X.shape[0])
+        chunks_in_block = max(block // cfg.hyp.sub_batch, 1)
+        if block % chunks_in_block != 0:
+            raise NotImplementedError("data.batch_size must be divisible into equal sub_batch chunks")
+        self.chunk = block // chunks_in_block
+        self.num_blocks = X.shape[0] // block               # drop_last=True
+        self.n_chunks = self.num_blocks * chunks_in_block
+        self.datapoints = self.n_chunks * self.chunk
+        s = cfg.hyp.grad_reg.block_strength
+        impl = cfg.hyp.grad_reg.implementation
+        fd_sets = 0 if s == 0 else (2 if impl == "central-differences" else 1)
+        self.dtype = torch.bfloat16 if (cfg.impl.mixed_precision and s == 0) else torch.float32
+        if cfg.impl.mixed_precision and s != 0:
+            log.warning("grad_reg finite differences need matching fp32 passes (perturbation ~1e-6 per weight): running fp32.")
+        from .parallel import ShardPlan
+        self.shard = ShardPlan(self.n_chunks, self.world, self.rank)
+        G = int(cfg.impl.get("engine", {}).get("chunk_group", 13))
+        G = max(1, min(G, self.shard.count))
+        self.engine = Engine(model, X.shape[-1], self.chunk, G, compute_dtype=self.dtype, device=self.device, fd_sets=fd_sets)
+        stem = self.engine.plan.stem
+        lo, hi = self.shard.first * self.chunk, (self.shard.first + self.shard.count) * self.chunk
+        self.patches = torch.cat([stem_patches(X[i:i + 4096], stem, self.dtype) for i in range(lo, hi, 4096)]) if hi > lo else None
+        self.labels = Y[lo:hi].contiguous()
+        self.valid = _stage(validloader, self.device) if validloader is not None else None
+        self.stats = defaultdict(list)
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def step(self):
+        """One optimizer step = the reference's ``optimizer.step(gradient_evaluation)`` (training.py:226-237)."""
+        cfg, eng, hyp = self.cfg, self.engine, self.cfg.hyp
+        train_time = time.time()
+        lr = self.optimizer.param_groups[0]["lr"]
+        gr = hyp.grad_reg
+        if self.world > 1:
+            self._running0 = torch.stack([eng.running_mean, eng.running_var]).clone()
+        loss_k, correct_k, sq_k = eng.full_gradient(self.patches, self.labels, lr, gr.block_strength, gr.eps, gr.implementation)
+        if self.world > 1:
+            from .parallel import sharded_update
+            loss_k, correct_k, sq_k = sharded_update(self, loss_k, correct_k, sq_k, lr)
+        else:
+            norms = eng.grad_and_param_sqnorm()
+            o = hyp.optim
+            eng.sgd_step(lr, o.weight_decay, o.momentum, o.dampening, o.nesterov, hyp.grad_clip)
+        self._record_stats(loss_k, correct_k, sq_k, eng.norms2, lr, train_time)
+        self.scheduler.step()
+
+    def _record_stats(self, loss_k, correct_k, sq_k, norms2, lr, train_time):
+        """Same keys/formulas as reference training.py:85-119 and :205-211 (one host sync per step, after the update is queued)."""
+        hyp, stats = self.cfg.hyp, self.stats
+        host = torch.cat([loss_k, correct_k, sq_k, norms2]).cpu()
+        K = self.n_chunks
+        loss_k, correct_k, sq_k, (gn2, pn2) = host[:K], host[K:2 * K], host[2 * K:3 * K], host[3 * K:3 * K + 2]
+        for idx, entry in enumerate(sq_k.sqrt().tolist()):
+            stats[f"grad_norm_train_{idx}"] += [entry]
+        step_loss = torch.zeros(())
+        for v in loss_k:                      # sequential fp32 sum, like `step_loss += chunk_loss`
+            step_loss = step_loss + v
+        full_grad_norm = sq_k.mean()
+        param_norm = pn2
+        train_loss = step_loss / K
+        full_loss = train_loss + 0.5 * getattr(hyp.optim, "weight_decay", 0.0) * param_norm
+        if hyp.grad_reg.block_strength != 0:
+            full_loss = full_loss + lr / 4 * hyp.grad_reg.block_strength * full_grad_norm
+        stats["train_loss"] += [train_loss.item()]
+        stats["train_acc"] += [correct_k.sum().item() / self.datapoints]
+        stats["train_time"] += [time.time() - train_time]
+        stats["param_norm"] += [param_norm.item()]
+        stats["grad_norm"] += [full_grad_norm.sqrt().item()]
+        stats["full_loss"] += [full_loss.item()]
+        if hyp.grad_clip is not None:
+            grad_norm = gn2.sqrt().item()
+            stats["preclip_gradnorm"] += [grad_norm]
+            stats["clipped_step"] += [1 if grad_norm > hyp.grad_clip else 0]
+
+    def evaluate(self, stats=None):
+        """Reference training.py:343-388 (no TTA): BN in eval mode, mean CE and accuracy over the validation set."""
+        stats = self.stats if stats is None else stats
+        if self.valid is None:
+            return stats
+        if self.cfg.hyp.test_time_flips:
+            raise NotImplementedError("test_time_flips")
+        X, Y = self.valid
+        eng = self.engine
+        cap = eng.G * eng.chunk
+        loss_sum, correct, n = 0.0, 0.0, 0
+        for i in range(0, X.shape[0], cap):
+            xb, yb = X[i:i + cap], Y[i:i + cap]
+            l, c = eng.evaluate_batch(stem_patches(xb, eng.plan.stem, eng.dt), yb)
+            loss_sum += l * yb.shape[0]
+            correct += c
+            n += yb.shape[0]
+            if self.cfg.dryrun:
+                break
+        stats["valid_loss"] += [loss_sum / n]
+        stats["valid_acc"] += [correct / n]
+        return stats
+
+
+def status_message(optimizer, stats, step):
+    def last(key):
+        return stats[key][-1] if len(stats[key]) > 0 else float("NaN")
+
+    return (f'Step: {step:<4}| lr: {optimizer.param_groups[0]["lr"]:.4f} | Time: {stats["train_time"][-1]:4.2f}s |'
+            f'TRAIN loss {stats["train_loss"][-1]:7.4f} | TRAIN Acc: {stats["train_acc"][-1]:7.2%} |'
+            f'VAL loss {last("valid_loss"):7.4f} | VAL Acc: {last("valid_acc"):7.2%} |')
+
+
+def train(model, trainloader, validloader, setup, cfg):
+    """Train given model based on implementation details and hyperparameters (signature of reference training.py:50)."""
+    trainer = FullBatchTrainer(model, trainloader, validloader, setup, cfg)
+    stats, optimizer, scheduler, eng = trainer.stats, trainer.optimizer, trainer.scheduler, trainer.engine
+
+    class Counter:
+        step: int = 0
+
+    if cfg.impl.checkpoint.name is not None:
+        file = os.path.join(cfg.original_cwd, "checkpoints", cfg.impl.checkpoint.name)
+        _load_from_checkpoint(model, optimizer, scheduler, None, Counter, cfg.hyp.steps, device="cpu", file=file, engine=eng)
+
+    while Counter.step < cfg.hyp.steps:
+        trainer.step()
+        Counter.step += 1
+        if (Counter.step - 1) % cfg.impl.validate_every_nth_step == 0 or Counter.step >= cfg.hyp.steps or cfg.dryrun:
+            trainer.evaluate()
+        if trainer.rank == 0:
+            log.info(status_message(optimizer, stats, Counter.step))
+        if not torch.as_tensor(stats["train_loss"][-1]).isfinite():
+            log.info("Terminating iterations due to divergence of loss...")
+            break
+        if cfg.hyp.stop_at_full_training_accuracy > 0:
+            if min(stats["train_acc"][-cfg.hyp.stop_at_full_training_accuracy:]) == 1:
+                log.info("Terminating training after fitting all datapoints.")
+                trainer.evaluate()
+                break
+        if trainer.rank == 0 and cfg.impl.checkpoint.name is not None:
+            if (Counter.step - 1) % cfg.impl.checkpoint.save_every_nth_step == 0 or Counter.step >= cfg.hyp.steps:
+                file = os.path.join(cfg.original_cwd, "checkpoints", cfg.impl.checkpoint.name)
+                os.makedirs(os.path.dirname(file), exist_ok=True)
+                _save_to_checkpoint(model, optimizer, scheduler, None, Counter, file=file, engine=eng)
+        if cfg.dryrun:
+            break
+    eng.store_to_model(model, with_grad=True)    # closure contract: p.grad holds the last (clipped) full gradient
+    _sync_optimizer_state(eng, model, optimizer)
+    return stats

@@ -37,6 +37,13 @@ typedef enum { FB_F32 = 0, FB_BF16 = 1 } fb_dtype;
 const char* fb_last_error_string(void);
 int fb_abi_version(void);
 
+/* Optional measurement aid (the only process-global state in the library, off by default): while enabled every
+ * fb_conv2d / fb_conv2d_wgrad launch is bracketed by HIP events recorded on the launch stream.  fb_profile_read waits
+ * for the recorded launches and returns, per kernel class {0: igemm fwd, 1: igemm dgrad, 2: wgrad}, the summed
+ * elapsed milliseconds, the number of launches and the number of launches that were not recorded (pool exhausted). */
+int fb_profile_enable(int on, int capacity);
+int fb_profile_read(double* ms, int64_t* launches, int64_t* dropped);
+
 /* ---------------------------------------------------------------- convolution ------------------------------------ */
 /* Implicit-GEMM convolution on MFMA.  mode 0: forward  y = conv(x, w)        (ATen convolution, resnets.py:69,206,209,150)
  *                                      mode 1: dgrad    dx = conv_input_grad   (ATen convolution_backward, input part)
@@ -68,10 +75,10 @@ int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream);
  * at out + g*out_group_stride */
 int fb_wgrad_reduce(const float* dw_partial, float* out, int64_t out_group_stride, int32_t n_groups, int32_t split_k,
                     int32_t Cd, int32_t taps, int32_t Cs_pad, int32_t Cs_real, void* stream);
-/* master fp32 KRSC weights [n_wsets][Cout][taps][Cin_real] (stride wset_stride_in floats, 0 = one shared set) ->
- * w_fwd [n_wsets][Cout][taps][Cin_pad] and (optional) w_dgrad [n_wsets][Cin_pad][taps][Cout] in `dtype` */
-int fb_weight_prep(const float* master, int64_t wset_stride_in, int32_t n_wsets, int32_t Cout, int32_t taps, int32_t Cin_real,
-                   int32_t Cin_pad, void* w_fwd, void* w_dgrad, int32_t dtype, void* stream);
+/* master fp32 KRSC weights [Cout][taps][Cin_real] of n_wsets sets (wset_stride_in floats apart) ->
+ * w_fwd [Cout][taps][Cin_pad] and (optional) w_dgrad [Cin_pad][taps][Cout] in `dtype`, sets wset_stride_out elements apart */
+int fb_weight_prep(const float* master, int64_t wset_stride_in, int64_t wset_stride_out, int32_t n_wsets, int32_t Cout, int32_t taps,
+                   int32_t Cin_real, int32_t Cin_pad, void* w_fwd, void* w_dgrad, int32_t dtype, void* stream);
 
 /* ---------------------------------------------------------------- batch norm ------------------------------------- */
 /* Per (group, channel): mean, biased var from the partial sums; writes mean/var rows into the [n_groups][ch_total]
@@ -86,10 +93,11 @@ int fb_bn_apply(const void* x, void* y, const float* scale, const float* shift, 
                 const float* rshift, int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t relu, int32_t dtype,
                 void* stream);
 /* sequential running-stat EMA for every BN channel of the network in one launch (momentum 0.1, unbiased var,
- * torch BatchNorm2d).  Update order: for g in groups: table0[g] then (if table1) table1[g]  (SURVEY T6). */
-int fb_bn_running_update(float* running_mean, float* running_var, const float* mean0, const float* var0,
-                         const float* mean1, const float* var1, const float* unbias, int32_t n_groups, int32_t ch_total,
-                         float momentum, void* stream);
+ * torch BatchNorm2d).  mean_tab/var_tab: [n_passes][n_groups][ch_total] (passes pass_stride floats apart).
+ * Update order: for g in groups: for p in passes  -- i.e. chunk g's base pass, then its finite-difference passes,
+ * exactly the order in which the reference's sequential loop touches the buffers. */
+int fb_bn_running_update(float* running_mean, float* running_var, const float* mean_tab, const float* var_tab, int32_t n_passes,
+                         int64_t pass_stride, const float* unbias, int32_t n_groups, int32_t ch_total, float momentum, void* stream);
 /* backward: partial sums of dy and dy*xhat with dy = dout * (y > 0) when y != NULL (threshold_backward). */
 int fb_bn_bwd_reduce(const void* dout, const void* y, const void* x, const float* mean_tab, const float* invstd,
                      int32_t ch_total, int32_t ch_off, float* partial, int64_t n_pixels, int32_t C,

@@ -89,7 +89,8 @@ def run_scenario(fullbatch, compose, scen, out, dtype=torch.float):
     n, pixels, overrides, mseed = SCENARIOS[scen]
     name = scen if dtype == torch.float else f"{scen}@f64"
     tmp = tempfile.mkdtemp()
-    cfg = compose(overrides + ["impl.validate_every_nth_step=1000", f"data.pixels={pixels}"], original_cwd=tmp,
+    extra = ["impl.accumulation_dtype=double"] if dtype == torch.double else []  # else the f64 run accumulates/updates in fp32
+    cfg = compose(overrides + extra + ["impl.validate_every_nth_step=1000", f"data.pixels={pixels}"], original_cwd=tmp,
                   name=name, seed=mseed)
     x, y = make_data(n, pixels)
     trainloader, validloader = loaders(x, y, cfg.data.batch_size)

@@ -1,0 +1,110 @@
+"""End-to-end GPU parity of the engine (forward + hand-scheduled backward through the whole ResNet) vs the CPU oracle and
+the committed reference vectors.
+
+Tolerances.  The per-chunk gradient of a freshly initialised ResNet-18 is an ill-conditioned (heavily cancelling) sum:
+the reference's own fp32 CPU result differs from its float64 run by ~3e-3 relative L2 (tests/test_oracle_golden.py).
+  f32 engine  vs float64 oracle : gradient 1e-2 (same class as the reference's fp32), loss 1e-5, BN statistics 1e-5
+  bf16 engine: every activation / activation-gradient is stored with 2^-9 relative rounding, which flips ~0.4 % of the
+    ReLU masks of near-zero pre-activations; at random init with random labels (the hardest case: the chunk gradient is
+    the small residual of a cancelling sum) that alone moves the chunk gradient by ~30 % (the float64 oracle that merely
+    *rounds at the same storage points* is 0.30 from the truth).  So bf16 is held to: loss 2e-3, classifier gradient
+    5e-2, cosine > 0.9 and relative distance < 0.45 to the rounding-emulating oracle -- and to multi-step training
+    statistics (test_gpu_training.py), where the noise averages out over chunks.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import make_data, rel_err, summarise
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(depth=18, pixels=16, chunk=32, G=3, dtype=torch.float32, seed=0, fd_sets=0, stem="CIFAR", classes=10):
+    from fullbatchtraining_amd.cfg import compose
+    from fullbatchtraining_amd.engine import Engine, stem_patches
+    from fullbatchtraining_amd.models import construct_model
+
+    cfg = compose([f"model=resnet{depth}", f"model.stem={stem}"])
+    torch.manual_seed(seed)
+    model = construct_model(cfg.model, 3, classes)
+    eng = Engine(model, pixels, chunk, G, compute_dtype=dtype, fd_sets=fd_sets)
+    return cfg, model, eng, stem_patches
+
+
+def _oracle_chunk_grads(model, x, y, chunk, depth=18, stem="CIFAR", classes=10, dtype=torch.float64, emulate_bf16=False):
+    from oracle import fb_oracle as orc
+
+    q = (lambda t: t.to(torch.bfloat16).to(t.dtype)) if emulate_bf16 else orc.identity
+    spec = orc.Spec(depth, stem=stem, classes=classes)
+    state = {k: (v.clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+    params, buffers = orc.split_state(state)
+    out = []
+    for k in range(x.shape[0] // chunk):
+        g, loss, correct = orc.chunk_gradient(spec, params, buffers, x[k * chunk:(k + 1) * chunk].to(dtype), y[k * chunk:(k + 1) * chunk], q)
+        out.append((g, float(loss), float(correct)))
+    return out, params, buffers
+
+
+def _engine_grads_as_lists(eng, G):
+    flat = eng.g[:G].cpu()
+    return [[eng._unflatten(flat[g], name) for name in eng.plan.param_names] for g in range(G)]
+
+
+@pytest.mark.parametrize("dtype,gtol,ltol", [(torch.float32, 1e-2, 1e-5), (torch.bfloat16, 0.45, 2e-3)])
+def test_resnet18_chunk_gradients_vs_oracle(dtype, gtol, ltol):
+    """f32 engine vs float64 oracle; bf16 engine vs the float64 oracle that rounds to bf16 at the engine's storage points
+    (same rounding points, exact arithmetic in between), plus the distance of both to the un-rounded truth for the record."""
+    pixels, chunk, G = 16, 32, 3
+    cfg, model, eng, stem_patches = _build(18, pixels, chunk, G, dtype)
+    x, y = make_data(chunk * G, pixels)
+    truth, _, _ = _oracle_chunk_grads(model, x, y, chunk)
+    ref, params, buffers = _oracle_chunk_grads(model, x, y, chunk, emulate_bf16=dtype == torch.bfloat16)
+    patches = stem_patches(x.cuda(), eng.plan.stem, dtype)
+    eng.prep_weights(eng.theta, 1)
+    eng.group_gradient(patches, y.cuda(), G, eng.g)
+    torch.cuda.synchronize()
+    got = _engine_grads_as_lists(eng, G)
+    for g in range(G):
+        assert abs(float(eng.loss[g]) - ref[g][1]) < ltol * max(1.0, abs(ref[g][1])), (g, float(eng.loss[g]), ref[g][1])
+        if dtype == torch.float32:
+            assert float(eng.correct[g]) == ref[g][2]
+        a = torch.cat([t.reshape(-1).double() for t in got[g]])
+        b = torch.cat([t.reshape(-1).double() for t in ref[g][0]])
+        err = float((a - b).norm() / b.norm())
+        t = torch.cat([r.reshape(-1).double() for r in truth[g][0]])
+        print(f"[{dtype}] chunk {g}: engine-vs-oracle {err:.3e}; engine-vs-f64-truth {float((a - t).norm() / t.norm()):.3e}; "
+              f"oracle-vs-truth {float((b - t).norm() / t.norm()):.3e}; loss {float(eng.loss[g]):.6f} vs {ref[g][1]:.6f} (truth {truth[g][1]:.6f})")
+        assert err < gtol, (g, err)
+        cos = float((a * t).sum() / (a.norm() * t.norm()))
+        assert cos > (0.99999 if dtype == torch.float32 else 0.9), cos
+        # the classifier gradient is well conditioned: tight in fp32, bf16 activation rounding (2^-9) in bf16
+        assert rel_err(got[g][-2].numpy(), truth[g][0][-2].numpy()) < (1e-4 if dtype == torch.float32 else 5e-2)
+    # batch statistics of the first and last BN layers (chunk 0) against torch
+    L = eng.plan.stem
+    mean0 = eng.mean_tab[0, 0, L.ch_off:L.ch_off + 64].cpu()
+    xs = torch.nn.functional.conv2d(x[:chunk].double(), params["stem.0.weight"], None, 1, 1)
+    assert rel_err(mean0.numpy(), xs.mean((0, 2, 3)).numpy()) < (1e-4 if dtype == torch.float32 else 3e-2)
+
+
+def test_golden_reference_chunk_gradient_f32(golden):
+    """Engine (f32) vs vectors of the REAL reference: fb_plain chunk 0 (128 images, 32x32) raw gradient sample + scalars."""
+    data, meta = golden
+    sc = meta["scenarios"]["fb_plain"]
+    cfg, model, eng, stem_patches = _build(18, 32, 128, 2, torch.float32, seed=sc["model_seed"])
+    x, y = make_data(sc["n"], 32)
+    patches = stem_patches(x[:256].cuda(), eng.plan.stem, torch.float32)
+    eng.prep_weights(eng.theta, 1)
+    eng.group_gradient(patches, y[:256].cuda(), 2, eng.g)
+    got = _engine_grads_as_lists(eng, 2)
+    for k in range(2):
+        loss_ref, correct_ref, sq_ref = data[f"fb_plain@f64/chunk{k}_scalars"]
+        assert abs(float(eng.loss[k]) - loss_ref) < 1e-5 * abs(loss_ref)
+        assert float(eng.correct[k]) == correct_ref
+        per, samp = summarise(got[k])
+        e64 = rel_err(samp, data[f"fb_plain@f64/chunk{k}_raw_sample"])
+        e32 = rel_err(samp, data[f"fb_plain/chunk{k}_raw_sample"])
+        ref_noise = rel_err(data[f"fb_plain/chunk{k}_raw_sample"], data[f"fb_plain@f64/chunk{k}_raw_sample"])
+        print(f"chunk {k}: engine-vs-ref64 {e64:.2e}, engine-vs-ref32 {e32:.2e}, ref32-vs-ref64 {ref_noise:.2e}")
+        assert e64 < 1e-2 and e32 < 1.5e-2
+        assert abs(float(sum(t.double().pow(2).sum() for t in got[k])) - sq_ref) < 5e-3 * sq_ref

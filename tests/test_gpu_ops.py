@@ -1,0 +1,339 @@
+"""GPU parity of every libfbengine.so entry point against plain torch CPU math (same inputs, seeded).
+
+f32 kernels (exact-f32 MFMA) are held to accumulation-order roundoff; bf16 kernels are compared against the same math
+evaluated on bf16-rounded inputs with fp32 accumulation (tolerance = bf16 output rounding, 2^-8 relative).
+"""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _lib():
+    from fullbatchtraining_amd import lib
+    return lib
+
+
+def q(t, dtype):
+    return t.to(dtype).float()
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def tol(dtype, k=1.0):
+    return (2e-5 if dtype == torch.float32 else 1.2e-2) * k
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def krsc(w):  # [co, ci, kh, kw] -> [co, kh*kw, ci]
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1, w.shape[1]).contiguous()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,k,stride,hw,n", [(64, 64, 3, 1, 8, 8), (64, 128, 3, 2, 8, 8), (128, 256, 1, 1, 4, 16),
+                                                   (32, 64, 1, 1, 8, 4), (256, 256, 3, 1, 4, 32), (96, 64, 3, 1, 6, 3)])
+def test_conv_fwd_and_stats(dtype, cin, cout, k, stride, hw, n):
+    lib = _lib()
+    torch.manual_seed(0)
+    pad = k // 2
+    x = q(torch.randn(n, cin, hw, hw), dtype)
+    w = q(torch.randn(cout, cin, k, k) * 0.1, dtype)
+    ref = F.conv2d(x, w, None, stride, pad)
+    ho = ref.shape[2]
+    xd = nhwc(x).to(dtype).cuda()
+    wd = krsc(w).to(dtype).cuda()
+    out = torch.empty(n, ho, ho, cout, dtype=dtype, device="cuda")
+    nblk = (n * ho * ho + 127) // 128
+    stat = torch.zeros(2, nblk, cout, device="cuda")
+    lib.conv2d(xd, wd, out, k, k, stride, pad, 0, stat_partial=stat)
+    got = nchw(out.float().cpu())
+    assert rel(got, ref) < tol(dtype)
+    refn = nhwc(ref).reshape(-1, cout)
+    assert rel(stat[0].sum(0).cpu(), refn.sum(0)) < 1e-4
+    assert rel(stat[1].sum(0).cpu(), (refn * refn).sum(0)) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,k,stride,hw,n,amode", [(64, 64, 3, 1, 8, 8, 0), (64, 128, 3, 2, 8, 8, 2), (128, 64, 1, 1, 4, 16, 1),
+                                                          (64, 64, 3, 1, 8, 4, 1), (256, 128, 3, 2, 8, 4, 0)])
+def test_conv_dgrad(dtype, cin, cout, k, stride, hw, n, amode):
+    lib = _lib()
+    torch.manual_seed(1)
+    pad = k // 2
+    ho = (hw + 2 * pad - k) // stride + 1
+    w = q(torch.randn(cout, cin, k, k) * 0.1, dtype)
+    dy = q(torch.randn(n, cout, ho, ho), dtype)
+    ref = torch.nn.grad.conv2d_input((n, cin, hw, hw), w, dy, stride, pad)
+    addend = None
+    if amode == 1:
+        addend = q(torch.randn(n, cin, hw, hw), dtype)
+        ref = ref + addend
+        add_d = nhwc(addend).to(dtype).cuda()
+    elif amode == 2:
+        addend = q(torch.randn(n, cin, hw // 2, hw // 2), dtype)
+        ref = ref + 0.25 * addend.repeat_interleave(2, 2).repeat_interleave(2, 3)
+        add_d = nhwc(addend).to(dtype).cuda()
+    else:
+        add_d = None
+    # dgrad weights: [ci][tap][co]
+    wt = w.permute(1, 2, 3, 0).reshape(cin, k * k, cout).contiguous().to(dtype).cuda()
+    dyd = nhwc(dy).to(dtype).cuda()
+    out = torch.empty(n, hw, hw, cin, dtype=dtype, device="cuda")
+    lib.conv2d(dyd, wt, out, k, k, stride, pad, 1, addend=add_d, addend_mode=amode)
+    assert rel(nchw(out.float().cpu()), ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,k,stride,hw,ipg,groups,split", [(64, 64, 3, 1, 8, 8, 2, 1), (64, 64, 3, 1, 8, 8, 2, 3),
+                                                                  (64, 128, 3, 2, 8, 8, 1, 2), (256, 256, 3, 1, 4, 16, 2, 1),
+                                                                  (128, 256, 1, 1, 4, 16, 1, 2), (32, 64, 1, 1, 8, 4, 2, 1),
+                                                                  (128, 128, 3, 1, 8, 4, 1, 1)])
+def test_conv_wgrad(dtype, cin, cout, k, stride, hw, ipg, groups, split):
+    lib = _lib()
+    torch.manual_seed(2)
+    pad = k // 2
+    n = ipg * groups
+    ho = (hw + 2 * pad - k) // stride + 1
+    x = q(torch.randn(n, cin, hw, hw), dtype)
+    dy = q(torch.randn(n, cout, ho, ho), dtype)
+    xd, dyd = nhwc(x).to(dtype).cuda(), nhwc(dy).to(dtype).cuda()
+    slab = torch.full((groups, split, cout, k * k, cin), float("nan"), device="cuda")
+    lib.conv2d_wgrad(xd, dyd, slab, k, k, stride, pad, ipg, split)
+    out = torch.zeros(groups, cout * k * k * cin + 8, device="cuda")
+    lib.wgrad_reduce(slab, out, out.shape[1], groups, split, cout, k * k, cin, cin)
+    for g in range(groups):
+        sl = slice(g * ipg, (g + 1) * ipg)
+        ref = torch.nn.grad.conv2d_weight(x[sl], (cout, cin, k, k), dy[sl], stride, pad)
+        got = out[g, : cout * k * k * cin].view(cout, k, k, cin).permute(0, 3, 1, 2).cpu()
+        assert rel(got, ref) < (1e-5 if dtype == torch.float32 else 1e-5), (g, rel(got, ref))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_weight_prep(dtype):
+    lib = _lib()
+    torch.manual_seed(3)
+    co, taps, ci, cip, sets = 64, 9, 27, 32, 2
+    master = torch.randn(sets, 4000 + co * taps * ci).cuda()
+    wf = torch.zeros(sets, co * taps * cip + 64, dtype=dtype, device="cuda")
+    wd = torch.zeros_like(wf)
+    lib.call("fb_weight_prep", master.data_ptr() + 4 * 100, master.shape[1], wf.shape[1], sets, co, taps, ci, cip, wf.data_ptr(),
+             wd.data_ptr(), lib.dtype_code(dtype))
+    for s in range(sets):
+        m = master[s, 100:100 + co * taps * ci].view(co, taps, ci).cpu()
+        ref = torch.zeros(co, taps, cip)
+        ref[..., :ci] = m
+        assert torch.equal(wf[s, : co * taps * cip].float().cpu().view(co, taps, cip), q(ref, dtype))
+        assert torch.equal(wd[s, : co * taps * cip].float().cpu().view(cip, taps, co), q(ref.permute(2, 1, 0).contiguous(), dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,hw,ipg,groups", [(64, 8, 8, 2), (512, 4, 16, 3)])
+def test_batchnorm_fwd_bwd(dtype, C, hw, ipg, groups):
+    """conv-epilogue statistics are emulated with a 1x1 identity-free path: partial sums are produced on the host here,
+    the finalize/apply/backward kernels are what is under test."""
+    lib = _lib()
+    torch.manual_seed(4)
+    n = ipg * groups
+    x = q(torch.randn(n, C, hw, hw) * 1.5 + 0.3, dtype)
+    res = q(torch.randn(n, C, hw, hw), dtype)
+    gamma, beta = torch.rand(groups, C) + 0.5, torch.randn(groups, C) * 0.1
+    dout = q(torch.randn(n, C, hw, hw), dtype)
+    xn = nhwc(x).reshape(-1, C)
+    px = xn.shape[0]
+    nblk = px // 128
+    part = torch.stack([xn.view(nblk, 128, C).sum(1), (xn * xn).view(nblk, 128, C).sum(1)]).cuda()
+    ch_total, ch_off = C + 96, 32
+    mean_tab = torch.zeros(groups, ch_total, device="cuda")
+    var_tab = torch.zeros_like(mean_tab)
+    scale, shift, invstd = (torch.zeros(groups, C, device="cuda") for _ in range(3))
+    pg = torch.zeros(groups, 2 * C + 64)
+    pg[:, :C], pg[:, C:2 * C] = gamma, beta
+    pgd = pg.cuda()
+    ppg = ipg * hw * hw
+    lib.call("fb_bn_fwd_finalize", part.data_ptr(), nblk, groups, C, float(ppg), pgd.data_ptr(), pgd.data_ptr() + 4 * C, pg.shape[1], 1e-5,
+             mean_tab.data_ptr(), var_tab.data_ptr(), ch_total, ch_off, scale.data_ptr(), shift.data_ptr(), invstd.data_ptr())
+    xd, resd, doutd = (nhwc(t).to(dtype).cuda() for t in (x, res, dout))
+    y = torch.empty_like(xd)
+    lib.call("fb_bn_apply", xd.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), resd.data_ptr(), None, None, px, C, ppg, 1,
+             lib.dtype_code(dtype))
+    # reference, per group
+    ys, dxs, dgs, dbs = [], [], [], []
+    for g in range(groups):
+        sl = slice(g * ipg, (g + 1) * ipg)
+        xg = x[sl].double()
+        mean, var = xg.mean((0, 2, 3)), xg.var((0, 2, 3), unbiased=False)
+        assert rel(mean_tab[g, ch_off:ch_off + C].cpu(), mean) < 1e-5
+        assert rel(var_tab[g, ch_off:ch_off + C].cpu(), var) < 1e-5
+        xhat = (xg - mean[None, :, None, None]) / (var + 1e-5).sqrt()[None, :, None, None]
+        yg = torch.relu(xhat * gamma[g].double()[None, :, None, None] + beta[g].double()[None, :, None, None] + res[sl].double())
+        ys.append(yg)
+        dy = dout[sl].double() * (yg > 0)
+        m = ipg * hw * hw
+        db, dg = dy.sum((0, 2, 3)), (dy * xhat).sum((0, 2, 3))
+        dx = (gamma[g].double() / (var + 1e-5).sqrt())[None, :, None, None] * (dy - db[None, :, None, None] / m - xhat * dg[None, :, None, None] / m)
+        dxs.append(dx), dgs.append(dg), dbs.append(db)
+    yref = torch.cat(ys)
+    assert rel(nchw(y.float().cpu()), yref) < tol(dtype, 0.5)
+    # backward uses the *reference* y as mask to avoid sign flips of near-zero outputs in bf16
+    yd = nhwc(yref.float()).to(dtype).cuda()
+    part2 = torch.zeros(2, nblk, C, device="cuda")
+    lib.call("fb_bn_bwd_reduce", doutd.data_ptr(), yd.data_ptr(), xd.data_ptr(), mean_tab.data_ptr(), invstd.data_ptr(), ch_total, ch_off,
+             part2.data_ptr(), px, C, ppg, lib.dtype_code(dtype))
+    gout = torch.zeros(groups, 2 * C + 64, device="cuda")
+    coef = torch.zeros(groups, C, 3, device="cuda")
+    lib.call("fb_bn_bwd_finalize", part2.data_ptr(), nblk, groups, C, float(ppg), scale.data_ptr(), mean_tab.data_ptr(), invstd.data_ptr(),
+             ch_total, ch_off, gout.data_ptr(), gout.data_ptr() + 4 * C, gout.shape[1], coef.data_ptr())
+    dx = torch.empty_like(xd)
+    dy_out = torch.empty_like(xd)
+    lib.call("fb_bn_bwd_apply", doutd.data_ptr(), yd.data_ptr(), xd.data_ptr(), coef.data_ptr(), dx.data_ptr(), dy_out.data_ptr(), px, C, ppg,
+             lib.dtype_code(dtype))
+    assert rel(gout[:, :C].cpu(), torch.stack(dgs)) < 1e-4
+    assert rel(gout[:, C:2 * C].cpu(), torch.stack(dbs)) < 1e-4
+    assert rel(nchw(dx.float().cpu()), torch.cat(dxs)) < tol(dtype, 0.5)
+    assert rel(nchw(dy_out.float().cpu()), dout.double() * (yref > 0)) < tol(dtype, 0.5)
+
+
+def test_bn_running_update():
+    lib = _lib()
+    torch.manual_seed(5)
+    G, ch = 3, 200
+    rm, rv = torch.randn(ch), torch.rand(ch) + 0.5
+    m0, v0, m1, v1 = torch.randn(G, ch), torch.rand(G, ch), torch.randn(G, ch), torch.rand(G, ch)
+    ub = torch.full((ch,), 128.0 / 127.0)
+    d = [t.cuda() for t in (rm, rv, torch.stack([m0, m1]), torch.stack([v0, v1]), ub)]
+    lib.call("fb_bn_running_update", d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 2, G * ch, d[4].data_ptr(), G, ch, 0.1)
+    erm, erv = rm.clone(), rv.clone()
+    for g in range(G):
+        for m, v in ((m0, v0), (m1, v1)):
+            erm = 0.9 * erm + 0.1 * m[g]
+            erv = 0.9 * erv + 0.1 * (v[g] * ub)
+    assert torch.allclose(d[0].cpu(), erm, rtol=1e-6, atol=1e-7) and torch.allclose(d[1].cpu(), erv, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pools_and_head(dtype):
+    lib = _lib()
+    torch.manual_seed(6)
+    n, C, hw, classes, ipg = 8, 64, 8, 10, 4
+    groups = n // ipg
+    x = q(torch.randn(n, C, hw, hw), dtype)
+    xd = nhwc(x).to(dtype).cuda()
+    y = torch.empty(n, hw // 2, hw // 2, C, dtype=dtype, device="cuda")
+    lib.call("fb_avgpool2_fwd", xd.data_ptr(), y.data_ptr(), n, hw, hw, C, lib.dtype_code(dtype))
+    assert rel(nchw(y.float().cpu()), F.avg_pool2d(x, 2)) < tol(dtype, 0.5)
+    ym = torch.empty(n, hw // 2, hw // 2, C, dtype=dtype, device="cuda")
+    lib.call("fb_maxpool3s2_fwd", xd.data_ptr(), ym.data_ptr(), n, hw, hw, C, lib.dtype_code(dtype))
+    xr = x.clone().requires_grad_(True)
+    mp = F.max_pool2d(xr, 3, 2, 1)
+    assert torch.equal(nchw(ym.float().cpu()), mp.detach())
+    dmp = q(torch.randn_like(mp), dtype)
+    mp.backward(dmp)
+    dxm = torch.empty_like(xd)
+    lib.call("fb_maxpool3s2_bwd", xd.data_ptr(), nhwc(dmp).to(dtype).cuda().data_ptr(), dxm.data_ptr(), n, hw, hw, C, lib.dtype_code(dtype))
+    assert rel(nchw(dxm.float().cpu()), xr.grad) < tol(dtype, 0.5)
+    # head
+    feat = torch.empty(n, C, device="cuda")
+    lib.call("fb_head_pool", xd.data_ptr(), feat.data_ptr(), n, hw * hw, C, lib.dtype_code(dtype))
+    fref = x.mean((2, 3))
+    assert rel(feat.cpu(), fref) < 1e-5
+    P = classes * C + 16 + 64
+    theta = torch.randn(groups, P) * 0.2
+    labels = torch.randint(0, classes, (n,))
+    thd, lab = theta.cuda(), labels.cuda()
+    logits, dlogits = torch.empty(n, classes, device="cuda"), torch.empty(n, classes, device="cuda")
+    loss, correct = torch.empty(groups, device="cuda"), torch.empty(groups, device="cuda")
+    boff = classes * C
+    lib.call("fb_head_loss", feat.data_ptr(), thd.data_ptr(), thd.data_ptr() + 4 * boff, P, lab.data_ptr(), logits.data_ptr(),
+             dlogits.data_ptr(), loss.data_ptr(), correct.data_ptr(), groups, ipg, C, classes)
+    gout = torch.zeros(groups, P, device="cuda")
+    d_a = torch.empty(n, hw, hw, C, dtype=dtype, device="cuda")
+    lib.call("fb_head_bwd", feat.data_ptr(), dlogits.data_ptr(), thd.data_ptr(), P, gout.data_ptr(), gout.data_ptr() + 4 * boff, P,
+             d_a.data_ptr(), groups, ipg, hw * hw, C, classes, lib.dtype_code(dtype))
+    for g in range(groups):
+        sl = slice(g * ipg, (g + 1) * ipg)
+        W = theta[g, :boff].view(classes, C).clone().requires_grad_(True)
+        b = theta[g, boff:boff + classes].clone().requires_grad_(True)
+        f = feat[sl].cpu().clone().requires_grad_(True)
+        z = f @ W.t() + b
+        l = F.cross_entropy(z, labels[sl])
+        l.backward()
+        assert abs(float(loss[g]) - float(l)) < 1e-5
+        assert float(correct[g]) == float((z.argmax(-1) == labels[sl]).sum())
+        assert rel(gout[g, :boff].cpu(), W.grad.reshape(-1)) < 1e-5
+        assert rel(gout[g, boff:boff + classes].cpu(), b.grad) < 1e-5
+        dref = (f.grad / (hw * hw))[:, :, None, None].expand(-1, -1, hw, hw)
+        assert rel(nchw(d_a[sl].float().cpu()), dref) < tol(dtype, 0.5)
+
+
+def test_multi_tensor_ops():
+    lib = _lib()
+    torch.manual_seed(7)
+    P, G = 100_003 + 1, 11          # deliberately not a multiple of 4 per tensor; group stride padded
+    stride = (P + 63) // 64 * 64
+    g = torch.randn(G, stride)
+    g[:, P:] = 0
+    gd = g.cuda()
+    ws = torch.zeros(max(G, 2) * lib.MT_BLOCKS, device="cuda")
+    out = torch.zeros(G, device="cuda")
+    lib.call("fb_mt_sqnorm", gd.data_ptr(), stride, G, P, 0.5, out.data_ptr(), ws.data_ptr())
+    assert torch.allclose(out.cpu(), (0.5 * g[:, :P]).double().pow(2).sum(1).float(), rtol=1e-5)
+    # running mean + fused norms
+    avg = torch.randn(stride)
+    avgd = avg.cuda()
+    sq = torch.zeros(G, device="cuda")
+    lib.call("fb_mt_accumulate", avgd.data_ptr(), gd.data_ptr(), stride, G, P, 5, sq.data_ptr(), ws.data_ptr())
+    ref = avg[:P].clone()
+    for j in range(G):
+        ref = ref + (g[j, :P] - ref) * torch.tensor(1.0 / (5 + j + 1), dtype=torch.float32)
+    assert torch.allclose(avgd[:P].cpu(), ref, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(sq.cpu(), g[:, :P].double().pow(2).sum(1).float(), rtol=1e-5)
+    # FD perturb / combine
+    theta0 = torch.randn(stride)
+    th0 = theta0.cuda()
+    vn = (0.5 * g[:, :P]).double().pow(2).sum(1).float().cuda()
+    eps_n = torch.zeros(G, device="cuda")
+    thk = torch.zeros(G, stride, device="cuda")
+    lib.call("fb_mt_fd_perturb", th0.data_ptr(), gd.data_ptr(), stride, G, P, 0.5, 1e-2, 1.0, vn.data_ptr(), eps_n.data_ptr(), thk.data_ptr())
+    en = 1e-2 / vn.cpu().sqrt()
+    assert torch.allclose(eps_n.cpu(), en, rtol=1e-6)
+    assert torch.allclose(thk[:, :P].cpu(), theta0[None, :P] + en[:, None] * (0.5 * g[:, :P]), rtol=1e-6, atol=1e-7)
+    g2 = g + 0.01 * torch.randn(G, stride)
+    g2d = g2.cuda()
+    avg2 = torch.zeros(stride, device="cuda")
+    lib.call("fb_mt_fd_combine_accumulate", avg2.data_ptr(), gd.data_ptr(), g2d.data_ptr(), gd.data_ptr(), stride, G, P, eps_n.data_ptr(), 0.2, 0)
+    ref = torch.zeros(P)
+    for j in range(G):
+        gt = g[j, :P] + 0.2 * ((g2[j, :P] - g[j, :P]) / en[j])
+        ref = ref + (gt - ref) * torch.tensor(1.0 / (j + 1), dtype=torch.float32)
+    assert torch.allclose(avg2[:P].cpu(), ref, rtol=1e-4, atol=1e-3)   # (g2-g)/eps_n amplifies fp32 roundoff by 1/eps_n ~ 1e4
+    # norms + clip + SGD
+    theta, grad, mom = torch.randn(P), torch.randn(P) * 0.01, torch.randn(P) * 0.01
+    td, grd, md = theta.cuda(), grad.cuda(), mom.cuda()
+    n2 = torch.zeros(2, device="cuda")
+    lib.call("fb_mt_norms2", grd.data_ptr(), td.data_ptr(), P, n2.data_ptr(), ws.data_ptr())
+    assert torch.allclose(n2.cpu(), torch.stack([grad.double().pow(2).sum(), theta.double().pow(2).sum()]).float(), rtol=1e-5)
+    for first in (1, 0):
+        lib.call("fb_mt_clip_sgd", td.data_ptr(), grd.data_ptr(), md.data_ptr(), P, n2.data_ptr(), 0.25, 0.1, 5e-4, 0.9, 0.0, 1, first)
+        norm = n2[0].sqrt().cpu()
+        coef = (0.25 / (norm + 1e-6)) if norm > 0.25 else torch.tensor(1.0)
+        grad = grad * coef
+        d = grad + 5e-4 * theta
+        mom = d.clone() if first else 0.9 * mom + d
+        theta = theta - 0.1 * (d + 0.9 * mom)
+        assert torch.allclose(td.cpu(), theta, rtol=1e-5, atol=1e-6) and torch.allclose(md.cpu(), mom, rtol=1e-5, atol=1e-7)
+        assert torch.allclose(grd.cpu(), grad, rtol=1e-6, atol=1e-9)
+        lib.call("fb_mt_norms2", grd.data_ptr(), td.data_ptr(), P, n2.data_ptr(), ws.data_ptr())
