@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""Benchmark of the full-batch GD hot path: ResNet-18 / CIFAR-10-shaped synthetic data, one optimizer step = gradient of
+ALL chunks (390 x 128 = 49 920 images, the reference's drop_last behaviour) + clip + Nesterov-SGD update.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line (rank 0): whole-job images/s (value), steps/s, ms/step, plus
+  roofline     : dominant MFMA kernel class -- algorithmic FLOP per launch / mean launch duration measured with HIP events on
+                 the launch stream inside the timed region (libfbengine's fb_profile_*), against the dense bf16 MFMA peak
+  cpu_baseline : the CPU oracle (restatement of the reference path, oracle/fb_oracle.py) timed on this box's host cores on a
+                 bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3     # f32-input MFMA
+CHUNK = 128
+N_IMAGES = 50_000
+
+
+def conv_flops(plan, n_img):
+    """Algorithmic (direct-convolution, real channel counts) FLOP of the conv launches of one fwd+bwd over n_img images,
+    per kernel class.  Matches SURVEY/BASELINE: 1.1108 GFLOP/img fwd, dgrad for all convs but the stem, wgrad for all."""
+    fwd = dgrad = wgrad = 0
+    for L in plan.layers:
+        macs = n_img * L.hout * L.wout * L.cout * L.taps * L.cin_real
+        fwd += 2 * macs
+        wgrad += 2 * macs
+        if L is not plan.stem:
+            dgrad += 2 * macs
+    return {"igemm_fwd": fwd, "igemm_dgrad": dgrad, "wgrad": wgrad}
+
+
+def cpu_baseline(n_chunks=8):
+    """Times the CPU oracle on `n_chunks` chunks of 128 images (fp32, all host threads)."""
+    from fullbatchtraining_amd.cfg import compose
+    from fullbatchtraining_amd.models import construct_model
+    from oracle import fb_oracle as orc
+
+    torch.manual_seed(1)
+    model = construct_model(compose([]).model, 3, 10)
+    params, buffers = orc.split_state({k: v.clone() for k, v in model.state_dict().items()})
+    spec = orc.Spec(18)
+    gen = torch.Generator().manual_seed(1234)
+    x = torch.randn((n_chunks + 1) * CHUNK, 3, 32, 32, generator=gen)
+    y = torch.randint(0, 10, ((n_chunks + 1) * CHUNK,), generator=gen)
+    orc.chunk_gradient(spec, params, buffers, x[:CHUNK], y[:CHUNK])   # warm-up chunk
+    t0 = time.perf_counter()
+    for k in range(1, n_chunks + 1):
+        orc.chunk_gradient(spec, params, buffers, x[k * CHUNK:(k + 1) * CHUNK], y[k * CHUNK:(k + 1) * CHUNK])
+    dt = time.perf_counter() - t0
+    return {"value": round(n_chunks * CHUNK / dt, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_chunks} chunks of {CHUNK} images (fwd+bwd, fp32 oracle, grad_reg off), {dt:.1f} s; "
+                      f"one full step = 390 chunks ~ {390 * dt / n_chunks:.0f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--grad-reg", type=float, default=0.0, help="block_strength of the finite-difference regulariser (config 3)")
+    ap.add_argument("--chunk-group", type=int, default=13)
+    ap.add_argument("--images", type=int, default=N_IMAGES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=device)
+
+    from fullbatchtraining_amd import lib
+    from fullbatchtraining_amd.cfg import compose
+    from fullbatchtraining_amd.models import construct_model
+    from fullbatchtraining_amd.training import FullBatchTrainer
+
+    overrides = ["hyp=fb1", "hyp.warmup=0", f"hyp.steps={args.steps + args.warmup}", f"impl.engine.chunk_group={args.chunk_group}",
+                 f"impl.mixed_precision={'True' if args.dtype == 'bf16' else 'False'}", "data.augmentations_train="]
+    if args.grad_reg != 0:
+        overrides += ["hyp=gradreg", "hyp.warmup=0", f"hyp.steps={args.steps + args.warmup}", f"hyp.grad_reg.block_strength={args.grad_reg}"]
+    if world > 1:
+        overrides += ["impl/setup=distributed"]
+    cfg = compose(overrides, original_cwd=os.path.join(ROOT, "gpurun_out"), name="bench")
+    os.makedirs(cfg.original_cwd, exist_ok=True)
+
+    # synthetic CIFAR-shaped data, generated identically on every rank
+    gen = torch.Generator().manual_seed(1234)
+    X = torch.randn(args.images, 3, 32, 32, generator=gen)
+    Y = torch.randint(0, 10, (args.images,), generator=gen)
+    torch.manual_seed(1)
+    model = construct_model(cfg.model, 3, 10)
+    setup = dict(device=device, dtype=torch.float, memory_format=torch.contiguous_format)
+    trainer = FullBatchTrainer(model, (X, Y), None, setup, cfg)
+    del X
+    eng = trainer.engine
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step()
+    timing = not args.no_kernel_timing
+    if timing:
+        lib.profile_enable(True, 65536)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof = lib.profile_read() if timing else None
+    if timing:
+        lib.profile_enable(False)
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(t[0])
+
+    if rank == 0:
+        images_per_step = trainer.datapoints
+        steps_per_sec = args.steps / elapsed
+        passes = 1 if args.grad_reg == 0 else 2
+        out = {
+            "metric": "full-batch GD images/sec (ResNet-18 CIFAR-10 shaped, all chunks accumulated per step)",
+            "value": round(images_per_step * steps_per_sec, 1), "unit": "images/s",
+            "steps_per_sec": round(steps_per_sec, 4), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "bf16" if trainer.dtype == torch.bfloat16 else "f32", "data": "synthetic",
+            "config": {"workload": f"ResNet-18 CIFAR-10 full-batch GD step, {trainer.n_chunks} chunks x {trainer.chunk} = {images_per_step} "
+                                   f"images/step (drop_last), grad_reg block_strength={args.grad_reg}, fp32 master/accumulate",
+                       "chunk_group": eng.G, "parallelism": f"dp{world} (contiguous chunk ranges, reduce-scatter + all-gather)"},
+            "train_loss_last": trainer.stats["train_loss"][-1],
+        }
+        if prof is not None:
+            n_local = trainer.shard.count * trainer.chunk * args.steps * passes
+            flops = conv_flops(eng.plan, n_local)
+            peak = PEAK_BF16_TFLOPS if trainer.dtype == torch.bfloat16 else PEAK_F32_TFLOPS
+            kernels = {}
+            for k, (ms, launches, dropped) in prof.items():
+                if launches:
+                    scale = launches / max(launches + dropped, 1)
+                    kernels[k] = {"ms_total": round(ms, 2), "launches": launches, "dropped": dropped,
+                                  "avg_launch_us": round(1000 * ms / launches, 2),
+                                  "tflops": round(flops[k] * scale / (ms * 1e-3) / 1e12, 1)}
+            dom = max(kernels, key=lambda k: kernels[k]["ms_total"])
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": None,
+                               "flop_per_launch": flops[dom] / max(kernels[dom]["launches"] + kernels[dom]["dropped"], 1),
+                               "avg_launch_us": kernels[dom]["avg_launch_us"], "kernels": kernels,
+                               "step_mfma_frac": round(3328997376 * passes * images_per_step * steps_per_sec / world / (peak * 1e12), 4)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

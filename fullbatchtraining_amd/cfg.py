@@ -104,7 +104,7 @@ def compose(overrides=(), **extra):
     selections, assignments = {}, []
     for item in overrides:
         key, _, value = item.partition("=")
-        key = key.lstrip("+")
+        key = key.lstrip("+").replace("/", ".")
         group_dir = os.path.join(CONFIG_DIR, key.replace(".", os.sep))
         if os.path.isdir(group_dir) and os.path.isfile(os.path.join(group_dir, f"{value}.yaml")):
             selections[key] = value

@@ -1,0 +1,189 @@
+"""CPU-side tests: C-ABI library loads and exports every declared symbol (no compute), host logic (cfg, LR schedules,
+shard plan), no-GPU behaviour is a loud failure, and the multi-GPU collective wiring on world_size-2 gloo."""
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as entry
+    from fullbatchtraining_amd import lib
+
+    entry.build()
+    handle = lib.load()
+    header = open(os.path.join(REPO, "include", "fb_engine.h")).read()
+    declared = set(re.findall(r"\b(fb_[a-z0-9_]+)\s*\(", header))
+    declared -= {"fb_status", "fb_dtype"}
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert set(lib.EXPORTS) == declared
+    assert handle.fb_abi_version() == 1
+
+
+def test_engine_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from fullbatchtraining_amd.cfg import compose
+    from fullbatchtraining_amd.engine import Engine
+    from fullbatchtraining_amd.lib import EngineError
+    from fullbatchtraining_amd.models import construct_model
+
+    model = construct_model(compose([]).model, 3, 10)
+    with pytest.raises(EngineError):
+        Engine(model, 32, 128, 2)
+
+
+def test_cfg_surface_and_overrides():
+    from fullbatchtraining_amd.cfg import compose
+
+    cfg = compose(["hyp=gradreg", "data.batch_size=32", "impl.checkpoint.name=x.pth", "hyp.grad_reg.eps=1e-3"])
+    assert cfg.hyp.optim.lr == 0.8 and cfg.hyp.grad_clip == 0.25 and cfg.hyp.grad_reg.block_strength == 0.5
+    assert cfg.hyp.grad_reg.eps == 1e-3 and cfg.hyp.warmup == 400 and cfg.hyp.scheduler == "cosine-4000"
+    assert cfg.hyp.optim.weight_decay == 5e-4 and cfg.hyp.optim.nesterov is True and cfg.hyp.train_stochastic is False
+    assert cfg.data.batch_size == 32 and cfg.impl.checkpoint.name == "x.pth" and cfg.hyp.sub_batch == 128
+    assert dict(**cfg.hyp.grad_reg)["implementation"] == "forward-differences"
+    base = compose([])
+    assert base.hyp.train_stochastic is True and base.model.name == "ResNet18" and base.impl.accumulation_dtype == "float"
+    assert compose(["model=resnet152"]).model.depth == 152 and compose(["impl/setup=distributed"]).impl.setup.dist is True
+
+
+@pytest.mark.parametrize("hyp", ["fb1", "fb2", "gradreg"])
+def test_product_lr_schedule_matches_reference(golden, hyp):
+    """optim_interface state containers reproduce the reference LR sequence (warm-up from 0, cosine-4000)."""
+    import warnings
+
+    from fullbatchtraining_amd.cfg import compose
+    from fullbatchtraining_amd.training import optim_interface
+
+    _, meta = golden
+    cfg = compose([f"hyp={hyp}"])
+    optimizer, scheduler = optim_interface(torch.nn.Linear(2, 2), cfg.hyp)
+    seq = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(3000 if hyp != "fb1" else 300):
+            seq.append(optimizer.param_groups[0]["lr"])
+            scheduler.step()
+    idx = [i for i in meta["lr_index"] if i < len(seq)]
+    assert np.allclose([seq[i] for i in idx], meta["lr"][hyp], rtol=1e-12, atol=0)
+    if cfg.hyp.warmup > 0:
+        state = scheduler.state_dict()
+        assert set(state.keys()) == set(meta["checkpoint"]["scheduler_state"].keys())
+
+
+def test_out_of_scope_options_raise():
+    from fullbatchtraining_amd.cfg import compose
+    from fullbatchtraining_amd.training import _check_scope, optim_interface
+
+    with pytest.raises(NotImplementedError):
+        _check_scope(compose(["hyp=base_sgd"]))                    # stochastic branch
+    with pytest.raises(NotImplementedError):
+        _check_scope(compose(["hyp=fb1", "hyp.grad_reg.acc_strength=0.1"]))
+    cfg = compose(["hyp=fb1"])
+    cfg.hyp.optim.name = "L-BFGS"
+    with pytest.raises(NotImplementedError):
+        optim_interface(torch.nn.Linear(2, 2), cfg.hyp)
+
+
+def test_shard_plan_partitions_chunks():
+    from fullbatchtraining_amd.parallel import ShardPlan
+
+    for k, w in ((390, 8), (390, 1), (7, 2), (3, 4)):
+        plans = [ShardPlan(k, w, r) for r in range(w)]
+        assert sum(p.count for p in plans) == k
+        assert [p.first for p in plans] == [sum(pl.count for pl in plans[:r]) for r in range(w)]
+        assert max(p.count for p in plans) - min(p.count for p in plans) <= 1
+    assert [ShardPlan(390, 8, r).count for r in range(8)] == [49] * 6 + [48] * 2
+
+
+# --------------------------------------------------------------------------------------------- gloo, world_size = 2 ----
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, K, P, out_dir):
+    import sys
+    sys.path.insert(0, REPO)
+    from fullbatchtraining_amd.parallel import (ShardOps, ShardPlan, all_gather_chunk_stats, combine_running_stats,
+                                                reduce_scatter_update_all_gather)
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.manual_seed(0)                      # identical "dataset" on every rank
+    g = torch.randn(K, P)                     # per-chunk (regularised) gradients
+    theta = torch.randn(P)
+    mom = torch.randn(P) * 0.1
+    stats = torch.rand(K)
+    bn_mean = torch.randn(K, 2, 5)            # two EMA updates per chunk (finite differences), 5 channels
+    r0 = torch.stack([torch.randn(5), torch.rand(5) + 0.5])
+    plan = ShardPlan(K, world, rank)
+    # rank-local running mean over the owned chunks (what Engine.full_gradient produces)
+    avg = torch.zeros(P)
+    for j, k in enumerate(range(plan.first, plan.first + plan.count)):
+        avg += (g[k] - avg) / (j + 1)
+    lr, wd, mu, clip = 0.1, 5e-4, 0.9, 0.25
+
+    def update(lo, n, gnorm2):
+        norm = gnorm2.sqrt()
+        coef = clip / (norm + 1e-6) if norm > clip else torch.tensor(1.0)
+        gr = avg[lo:lo + n] * coef
+        avg[lo:lo + n] = gr
+        d = gr + wd * theta[lo:lo + n]
+        mom[lo:lo + n] = mu * mom[lo:lo + n] + d
+        theta[lo:lo + n] -= lr * (d + mu * mom[lo:lo + n])
+
+    ops = ShardOps(scale=lambda t, a: t.mul_(a), sqnorm=lambda t: t.pow(2).sum(), update=update)
+    gnorm2 = reduce_scatter_update_all_gather(avg, theta, plan, ops)
+    full_stats = all_gather_chunk_stats(stats[plan.first:plan.first + plan.count].clone(), plan)
+    # rank-local EMA of BN statistics
+    r_local = r0.clone()
+    for k in range(plan.first, plan.first + plan.count):
+        for u in range(2):
+            r_local = 0.9 * r_local + 0.1 * bn_mean[k, u].expand(2, 5)
+    combined = combine_running_stats(r0, r_local, plan, updates_per_chunk=2)
+    torch.save(dict(theta=theta, gnorm2=gnorm2, stats=full_stats, running=combined, mom_shard=mom.clone(), lo=rank * (P // world)),
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_sharded_step_matches_single_process(tmp_path):
+    """2 gloo ranks: reduce-scatter(sum of K_r/K-scaled local means) + sharded clip/SGD + all-gather == 1-process step on the
+    exact mean (checked with the oracle's SGD), stats gathered in chunk order, BN running stats recombined exactly."""
+    from oracle import fb_oracle as orc
+
+    K, P, world = 7, 64 * 6, 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, K, P, str(tmp_path)), nprocs=world, join=True)
+    torch.manual_seed(0)
+    g, theta, mom, stats = torch.randn(K, P), torch.randn(P), torch.randn(P) * 0.1, torch.rand(K)
+    bn_mean = torch.randn(K, 2, 5)
+    r0 = torch.stack([torch.randn(5), torch.rand(5) + 0.5])
+    mean = g.mean(0)
+    norm = mean.norm()
+    grad = mean * (0.25 / (norm + 1e-6)) if norm > 0.25 else mean
+    params = {"w": theta.clone()}
+    momentum = [mom.clone()]
+    orc.sgd_step(params, [grad.clone()], momentum, 0.1, dict(momentum=0.9, weight_decay=5e-4, dampening=0.0, nesterov=True))
+    running = r0.clone()
+    for k in range(K):
+        for u in range(2):
+            running = 0.9 * running + 0.1 * bn_mean[k, u].expand(2, 5)
+    outs = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(world)]
+    for o in outs:
+        assert torch.allclose(o["theta"], params["w"], rtol=1e-5, atol=1e-6)
+        assert torch.allclose(o["gnorm2"], norm ** 2, rtol=1e-5)
+        assert torch.equal(o["stats"], stats)
+        assert torch.allclose(o["running"], running, rtol=1e-5, atol=1e-6)
+        n = P // world
+        assert torch.allclose(o["mom_shard"][o["lo"]:o["lo"] + n], momentum[0][o["lo"]:o["lo"] + n], rtol=1e-5, atol=1e-6)
+    assert torch.equal(outs[0]["theta"], outs[1]["theta"])

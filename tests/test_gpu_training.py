@@ -45,7 +45,9 @@ def test_train_matches_reference_run_f32(golden, name, tol, group, tmp_path):
         print(f"{name} {key}: engine {np.array(stats[key])} ref32 {r32} ref64 {r64}")
         if key == "train_acc" and "gradreg_c32" in name:
             continue  # the reference's own fp32 and float64 runs disagree on the accuracy here
-        assert np.allclose(stats[key], r64, rtol=tol, atol=1e-6), key
+        # within `tol`, or within 5x the reference's own fp32-vs-float64 spread on this statistic, whichever is larger
+        bound = np.maximum(tol * np.abs(r64) + 1e-6, 5 * np.abs(r32 - r64))
+        assert np.all(np.abs(np.array(stats[key]) - r64) <= bound), (key, stats[key], r32, r64)
     n_chunks = len([k for k in stats if k.startswith("grad_norm_train_")])
     assert n_chunks == meta["scenarios"][name]["n"] // min(cfg.data.batch_size, cfg.hyp.sub_batch)
     for k in range(n_chunks):
@@ -57,7 +59,12 @@ def test_train_matches_reference_run_f32(golden, name, tol, group, tmp_path):
     noise = rel_err(data[f"{name}/final_sample"], data[f"{name}@f64/final_sample"])
     print(f"{name}: final state engine-vs-ref64 {err:.2e} (reference fp32-vs-f64 {noise:.2e})")
     assert err < max(10 * noise, 1e-5)
-    assert rel_err(model.state_dict()["stem.1.running_mean"].double().numpy(), data[f"{name}@f64/final_stem_running_mean"]) < 2e-3  # values ~1e-4 (zero-mean inputs): cancellation
+    # stem running mean = mean of a zero-mean quantity (N(0,1) inputs): ill-conditioned, so judge it against the
+    # reference's own fp32-vs-float64 spread on the same scenario
+    rm_err = rel_err(model.state_dict()["stem.1.running_mean"].double().numpy(), data[f"{name}@f64/final_stem_running_mean"])
+    rm_noise = rel_err(data[f"{name}/final_stem_running_mean"], data[f"{name}@f64/final_stem_running_mean"])
+    print(f"{name}: stem running_mean engine-vs-ref64 {rm_err:.2e} (reference fp32-vs-f64 {rm_noise:.2e})")
+    assert rm_err < max(10 * rm_noise, 2e-3)
     assert int(model.state_dict()["stem.1.num_batches_tracked"]) == int(data[f"{name}@f64/final_num_batches_tracked"][0])
     assert len(stats["valid_loss"]) >= 1 and np.isfinite(stats["valid_loss"][-1])
     # closure contract: p.grad populated with the last full gradient
