@@ -5,17 +5,36 @@
 // finite-difference regulariser relies on (both passes see identically ordered sums).
 #include "common.h"
 
+// Two-stage fixed-order sum of the per-pixel-block partials of one (group, channel): 256 threads = 16 channels x 16 segments;
+// segment s adds blocks s, s+16, ... in double, then the 16 segment sums are added in order.  Valid on threads with seg == 0.
+__device__ __forceinline__ bool partial_sum2(const float* __restrict__ part, int n_mblocks, int blocks_per_group, int C, int g,
+                                             int& c, double& s, double& q) {
+    __shared__ double red[2][16][16];
+    const int cl = threadIdx.x & 15, seg = threadIdx.x >> 4;
+    c = blockIdx.x * 16 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        const float* ps = part + ((long long)g * blocks_per_group) * C + c;
+        const float* pq = part + ((long long)n_mblocks + (long long)g * blocks_per_group) * C + c;
+        for (int k = seg; k < blocks_per_group; k += 16) { a += (double)ps[(long long)k * C]; b += (double)pq[(long long)k * C]; }
+    }
+    red[0][seg][cl] = a; red[1][seg][cl] = b;
+    __syncthreads();
+    if (seg != 0 || c >= C) return false;
+    s = 0.0; q = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { s += red[0][k][cl]; q += red[1][k][cl]; }
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void bn_fwd_finalize_kernel(const float* __restrict__ part, int n_mblocks, int blocks_per_group, int C, double inv_count,
                                        const float* __restrict__ gamma, const float* __restrict__ beta, long long pstride, float eps,
                                        float* __restrict__ mean_tab, float* __restrict__ var_tab, int ch_total, int ch_off,
                                        float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ invstd_out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    const float* ps = part + ((long long)g * blocks_per_group) * C + c;
-    const float* pq = part + ((long long)n_mblocks + (long long)g * blocks_per_group) * C + c;
-    for (int b = 0; b < blocks_per_group; ++b) { s += (double)ps[(long long)b * C]; q += (double)pq[(long long)b * C]; }
+    const int g = blockIdx.y;
+    int c; double s, q;
+    if (!partial_sum2(part, n_mblocks, blocks_per_group, C, g, c, s, q)) return;
     const double mean = s * inv_count;
     double var = q * inv_count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -35,8 +54,8 @@ extern "C" int fb_bn_fwd_finalize(const float* stat_partial, int32_t n_mblocks, 
                                   void* stream) {
     if (!stat_partial || !gamma || !beta || !mean_tab || !var_tab || !scale || !shift || !invstd) FB_FAIL(FB_ERR_ARG, "fb_bn_fwd_finalize: null pointer");
     if (n_mblocks % n_groups != 0) FB_FAIL(FB_ERR_SHAPE, "fb_bn_fwd_finalize: %d pixel blocks not divisible by %d groups", n_mblocks, n_groups);
-    dim3 grid((C + 63) / 64, n_groups);
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, grid, dim3(64), 0, (hipStream_t)stream, stat_partial, n_mblocks, n_mblocks / n_groups, C,
+    dim3 grid((C + 15) / 16, n_groups);
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, grid, dim3(256), 0, (hipStream_t)stream, stat_partial, n_mblocks, n_mblocks / n_groups, C,
                        1.0 / count, gamma, beta, (long long)param_group_stride, eps, mean_tab, var_tab, ch_total, ch_off, scale, shift, invstd);
     FB_CHECK_LAUNCH("fb_bn_fwd_finalize");
     return FB_OK;
@@ -189,12 +208,9 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int n_mbl
                                        const float* __restrict__ scale, const float* __restrict__ mean_tab, const float* __restrict__ invstd,
                                        int ch_total, int ch_off, float* __restrict__ dgamma, float* __restrict__ dbeta, long long gstride,
                                        float* __restrict__ coef) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    const float* p1 = part + ((long long)g * blocks_per_group) * C + c;
-    const float* p2 = part + ((long long)n_mblocks + (long long)g * blocks_per_group) * C + c;
-    for (int b = 0; b < blocks_per_group; ++b) { s1 += (double)p1[(long long)b * C]; s2 += (double)p2[(long long)b * C]; }
+    const int g = blockIdx.y;
+    int c; double s1, s2;
+    if (!partial_sum2(part, n_mblocks, blocks_per_group, C, g, c, s1, s2)) return;
     dbeta[(long long)g * gstride + c] = (float)s1;
     dgamma[(long long)g * gstride + c] = (float)s2;
     // dx = scale*(dy - s1/M - xhat*s2/M) = c_dy*dy + c_x*x + c_0
@@ -209,8 +225,8 @@ extern "C" int fb_bn_bwd_finalize(const float* partial, int32_t n_mblocks, int32
                                   float* dbeta, int64_t grad_group_stride, float* coef, void* stream) {
     if (!partial || !scale || !mean_tab || !invstd || !dgamma || !dbeta || !coef) FB_FAIL(FB_ERR_ARG, "fb_bn_bwd_finalize: null pointer");
     if (n_mblocks % n_groups != 0) FB_FAIL(FB_ERR_SHAPE, "fb_bn_bwd_finalize: blocks/groups");
-    dim3 grid((C + 63) / 64, n_groups);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, grid, dim3(64), 0, (hipStream_t)stream, partial, n_mblocks, n_mblocks / n_groups, C, 1.0 / count,
+    dim3 grid((C + 15) / 16, n_groups);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, grid, dim3(256), 0, (hipStream_t)stream, partial, n_mblocks, n_mblocks / n_groups, C, 1.0 / count,
                        scale, mean_tab, invstd, ch_total, ch_off, dgamma, dbeta, (long long)grad_group_stride, coef);
     FB_CHECK_LAUNCH("fb_bn_bwd_finalize");
     return FB_OK;

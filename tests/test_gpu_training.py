@@ -51,7 +51,9 @@ def test_train_matches_reference_run_f32(golden, name, tol, group, tmp_path):
     n_chunks = len([k for k in stats if k.startswith("grad_norm_train_")])
     assert n_chunks == meta["scenarios"][name]["n"] // min(cfg.data.batch_size, cfg.hyp.sub_batch)
     for k in range(n_chunks):
-        assert np.allclose(stats[f"grad_norm_train_{k}"], data[f"{name}@f64/stat/grad_norm_train_{k}"], rtol=tol)
+        r64, r32 = data[f"{name}@f64/stat/grad_norm_train_{k}"], data[f"{name}/stat/grad_norm_train_{k}"]
+        bound = np.maximum(tol * np.abs(r64), 5 * np.abs(r32 - r64))
+        assert np.all(np.abs(np.array(stats[f"grad_norm_train_{k}"]) - r64) <= bound), (k, stats[f"grad_norm_train_{k}"], r32, r64)
     # final parameters + BN buffers (state_dict order) against the reference's float64 run
     ordered = [v.double() for v in model.state_dict().values()]
     per, samp = summarise(ordered)
