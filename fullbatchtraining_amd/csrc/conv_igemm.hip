@@ -201,6 +201,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
 }
 
+int fb_try_conv3x3_halo(const fb_conv_args* a, hipStream_t st);   // conv3x3_halo.hip
+
 template <typename T> static int launch_conv(const ConvParams& p, int classes, hipStream_t st) {
     const int mblocks = (p.M + 127) / 128;
     if (p.Cd % 128 == 0 && (long long)mblocks * (p.Cd / 128) * classes >= 512) {
@@ -249,7 +251,9 @@ extern "C" int fb_conv2d(const fb_conv_args* a, void* stream) {
     p.n_mblocks = ((p.M + 127) / 128) * classes;
     hipStream_t st = (hipStream_t)stream;
     const int prof = fb_prof_begin(a->mode == 0 ? FB_PROF_IGEMM_FWD : FB_PROF_IGEMM_DGRAD, st);
-    if (a->dtype == FB_F32) launch_conv<float>(p, classes, st); else launch_conv<bf16_tag>(p, classes, st);
+    if (!fb_try_conv3x3_halo(a, st)) {
+        if (a->dtype == FB_F32) launch_conv<float>(p, classes, st); else launch_conv<bf16_tag>(p, classes, st);
+    }
     fb_prof_end(prof, st);
     FB_CHECK_LAUNCH("fb_conv2d");
     return FB_OK;

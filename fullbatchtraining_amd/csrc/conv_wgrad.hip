@@ -169,6 +169,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
 }
 
+int fb_try_wgrad3x3(const fb_wgrad_args* a, hipStream_t st);   // conv_wgrad3x3.hip
+
 extern "C" int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream) {
     if (!a || !a->x || !a->dy || !a->dw_partial) FB_FAIL(FB_ERR_ARG, "fb_conv2d_wgrad: null pointer");
     if (a->Cs % 32 != 0 || a->Cd % 64 != 0) FB_FAIL(FB_ERR_SHAPE, "fb_conv2d_wgrad: Cs=%d must be a multiple of 32, Cd=%d of 64", a->Cs, a->Cd);
@@ -187,7 +189,8 @@ extern "C" int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream) {
     p.px_per_split = (int)(ceil_div64(ceil_div64(p.px_per_group, a->split_k), kstep) * kstep);
     const int taps = a->R * a->S;
     const int prof = fb_prof_begin(FB_PROF_WGRAD, st);
-    if (big) {
+    if (fb_try_wgrad3x3(a, st)) {
+    } else if (big) {
         dim3 grid((a->Cd / 128) * (a->Cs / 128), taps, n_groups * a->split_k);
         if (a->dtype == FB_F32) hipLaunchKernelGGL((conv_wgrad_kernel<float, 2, 2, 1, 1, 4>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_tag, 2, 2, 1, 2, 4>), grid, dim3(256), 0, st, p);

@@ -1,0 +1,202 @@
+// Weight gradient of 3x3 / stride 1 / pad 1 convolutions on wide feature maps (W = 32 or 16): all nine taps from one
+// LDS-resident input halo.
+//
+//   dW[co][tap][ci] = sum_p dY[p][co] * X[p shifted by tap][ci]
+//
+// One workgroup owns a 64(co) x 64(ci) x 9(tap) output block and a slice of whole images of one chunk (split-K over images).
+// Per K-step (64 output pixels = 2 or 4 full image rows) it stages dY[64 px][64 co] and the X halo [(rows+2)x(W+2)][64 ci]
+// once and feeds all nine taps from shifted *transposed* fragment reads (ds_read_b64_tr_b16 / ds_read_b32), so dY and X are
+// read from global memory once instead of nine times.  Wave w accumulates ci block [16w,16w+16) x 9 taps x 64 co
+// (36 fragments = 144 accumulator VGPRs).  Output: the same fp32 slab layout as conv_wgrad.hip, reduced in fixed order.
+#include "common.h"
+#include "profile.h"
+
+struct Wgrad3Params {
+    const char* x; const char* dy; float* out;
+    int n_img, H, Cs, Cd;
+    int imgs_per_group, imgs_per_block, split_k;
+};
+
+template <typename T> struct W3 { };
+template <> struct W3<bf16_tag> { static constexpr int PAD = 16; };
+template <> struct W3<float> { static constexpr int PAD = 64; };
+
+// A operand: dY tile rows are the step's pixels in order
+template <typename T> __device__ __forceinline__ void frag_plain(const char* tile, int row_bytes, int pb, int c0, int lane, uint4 (&out)[2]);
+template <> __device__ __forceinline__ void frag_plain<bf16_tag>(const char* tile, int row_bytes, int pb, int c0, int lane, uint4 (&out)[2]) {
+    const int t = lane & 15, g = lane >> 4;
+    const char* a0 = tile + (pb + g * 8 + (t >> 2)) * row_bytes + (c0 + (t & 3) * 4) * 2;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0 + 4 * row_bytes));
+    out[0] = make_uint4(((unsigned)(unsigned short)lo[0]) | ((unsigned)(unsigned short)lo[1] << 16),
+                        ((unsigned)(unsigned short)lo[2]) | ((unsigned)(unsigned short)lo[3] << 16),
+                        ((unsigned)(unsigned short)hi[0]) | ((unsigned)(unsigned short)hi[1] << 16),
+                        ((unsigned)(unsigned short)hi[2]) | ((unsigned)(unsigned short)hi[3] << 16));
+}
+template <> __device__ __forceinline__ void frag_plain<float>(const char* tile, int row_bytes, int pb, int c0, int lane, uint4 (&out)[2]) {
+    const int t = lane & 15, g = lane >> 4;
+    const char* a0 = tile + (pb + g) * row_bytes + (c0 + t) * 4;
+    unsigned v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = *(const unsigned*)(a0 + 4 * e * row_bytes);
+    out[0] = make_uint4(v[0], v[1], v[2], v[3]);
+    out[1] = make_uint4(v[4], v[5], v[6], v[7]);
+}
+// B operand: X halo; pixel p of the step sits at halo row (p/W + r)*(W+2) + p%W + s
+template <typename T, int W> __device__ __forceinline__ void frag_halo(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]);
+template <> __device__ __forceinline__ void frag_halo<bf16_tag, 32>(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) {
+    const int t = lane & 15, g = lane >> 4;
+    const int p = pb + g * 8 + (t >> 2);                      // 8 consecutive pixels of one image row per lane group
+    const char* a0 = tile + ((p / 32 + r) * 34 + (p % 32) + s) * row_bytes + (c0 + (t & 3) * 4) * 2;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0 + 4 * row_bytes));
+    out[0] = make_uint4(((unsigned)(unsigned short)lo[0]) | ((unsigned)(unsigned short)lo[1] << 16),
+                        ((unsigned)(unsigned short)lo[2]) | ((unsigned)(unsigned short)lo[3] << 16),
+                        ((unsigned)(unsigned short)hi[0]) | ((unsigned)(unsigned short)hi[1] << 16),
+                        ((unsigned)(unsigned short)hi[2]) | ((unsigned)(unsigned short)hi[3] << 16));
+}
+template <> __device__ __forceinline__ void frag_halo<bf16_tag, 16>(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) {
+    const int t = lane & 15, g = lane >> 4;
+    const int p = pb + g * 8 + (t >> 2);
+    const char* a0 = tile + ((p / 16 + r) * 18 + (p % 16) + s) * row_bytes + (c0 + (t & 3) * 4) * 2;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0 + 4 * row_bytes));
+    out[0] = make_uint4(((unsigned)(unsigned short)lo[0]) | ((unsigned)(unsigned short)lo[1] << 16),
+                        ((unsigned)(unsigned short)lo[2]) | ((unsigned)(unsigned short)lo[3] << 16),
+                        ((unsigned)(unsigned short)hi[0]) | ((unsigned)(unsigned short)hi[1] << 16),
+                        ((unsigned)(unsigned short)hi[2]) | ((unsigned)(unsigned short)hi[3] << 16));
+}
+template <int W> __device__ __forceinline__ void frag_halo_f32(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) {
+    const int t = lane & 15, g = lane >> 4;
+    unsigned v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int p = pb + g + 4 * e;
+        v[e] = *(const unsigned*)(tile + ((p / W + r) * (W + 2) + (p % W) + s) * row_bytes + (c0 + t) * 4);
+    }
+    out[0] = make_uint4(v[0], v[1], v[2], v[3]);
+    out[1] = make_uint4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void frag_halo<float, 32>(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) { frag_halo_f32<32>(tile, row_bytes, pb, r, s, c0, lane, out); }
+template <> __device__ __forceinline__ void frag_halo<float, 16>(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) { frag_halo_f32<16>(tile, row_bytes, pb, r, s, c0, lane, out); }
+
+template <typename T, int W>
+__global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p) {
+    constexpr int EB = ET<T>::EB;
+    constexpr int RS = 64 / W;                       // image rows per K-step (64 pixels)
+    constexpr int HROWS = (RS + 2) * (W + 2);        // halo pixels per K-step
+    constexpr int ROW = 64 * EB + W3<T>::PAD;        // LDS row: 64 channels + pad
+    constexpr int CH = 64 * EB / 16;                 // 16-byte chunks per row
+    constexpr int LD_A = 64 * CH / 256;              // dY chunks per thread
+    constexpr int LD_B = (HROWS * CH + 255) / 256;   // halo chunks per thread
+    __shared__ __attribute__((aligned(16))) char lds[(64 + HROWS) * ROW];
+    char* tileA = lds;
+    char* tileB = lds + 64 * ROW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = p.Cs / 64;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int group = blockIdx.y / p.split_k, split = blockIdx.y % p.split_k;
+    const int img0 = group * p.imgs_per_group + split * p.imgs_per_block;
+    const int img_end = min(img0 + p.imgs_per_block, (group + 1) * p.imgs_per_group);
+    const int steps_per_img = p.H / RS;
+    const int n_steps = (img_end - img0) * steps_per_img;
+
+    f32x4_t acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[LD_A], rb[LD_B];
+    auto gload = [&](int step) {
+        const int img = img0 + step / steps_per_img, y0 = (step % steps_per_img) * RS;
+        const char* dyb = p.dy + (((long long)img * p.H + y0) * W * p.Cd + tile_m * 64) * EB;
+#pragma unroll
+        for (int i = 0; i < LD_A; ++i) {
+            const int id = tid + 256 * i, row = id / CH, ch = id % CH;
+            ra[i] = *(const uint4*)(dyb + (long long)row * p.Cd * EB + ch * 16);
+        }
+        const char* xb = p.x + ((long long)img * p.H * W * p.Cs + tile_n * 64) * EB;
+#pragma unroll
+        for (int i = 0; i < LD_B; ++i) {
+            const int id = tid + 256 * i, row = id / CH, ch = id % CH;
+            rb[i] = make_uint4(0, 0, 0, 0);
+            if (row < HROWS) {
+                const int hy = row / (W + 2), hx = row - hy * (W + 2);
+                const int sy = y0 + hy - 1, sx = hx - 1;
+                if ((unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)W)
+                    rb[i] = *(const uint4*)(xb + (long long)(sy * W + sx) * p.Cs * EB + ch * 16);
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < LD_A; ++i) { const int id = tid + 256 * i, row = id / CH, ch = id % CH; *(uint4*)(tileA + row * ROW + ch * 16) = ra[i]; }
+#pragma unroll
+        for (int i = 0; i < LD_B; ++i) { const int id = tid + 256 * i, row = id / CH, ch = id % CH; if (row < HROWS) *(uint4*)(tileB + row * ROW + ch * 16) = rb[i]; }
+    };
+
+    if (n_steps > 0) gload(0);
+    for (int step = 0; step < n_steps; ++step) {
+        __syncthreads();
+        lstore();
+        __syncthreads();
+        if (step + 1 < n_steps) gload(step + 1);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int pb = blk * 32;
+            uint4 af[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) frag_plain<T>(tileA, ROW, pb, i * 16, lane, af[i]);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                uint4 bf[2];
+                frag_halo<T, W>(tileB, ROW, pb, t / 3, t % 3, wave * 16, lane, bf);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[t][i] = mma_chunk<T>(af[i][0], bf[0], acc[t][i]);
+                    if constexpr (EB == 4) acc[t][i] = mma_chunk<T>(af[i][1], bf[1], acc[t][i]);
+                }
+            }
+        }
+    }
+
+    float* out = p.out + ((long long)(group * p.split_k + split) * p.Cd) * 9 * p.Cs;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int co = tile_m * 64 + i * 16 + (lane >> 4) * 4 + q;
+                const int ci = tile_n * 64 + wave * 16 + (lane & 15);
+                out[((long long)co * 9 + t) * p.Cs + ci] = acc[t][i][q];
+            }
+}
+
+// returns 1 if handled.  The caller's slab must hold n_groups*split_k*Cd*9*Cs floats with the split_k passed in.
+int fb_try_wgrad3x3(const fb_wgrad_args* a, hipStream_t st) {
+    static const bool disabled = getenv("FB_DISABLE_WGRAD3") != nullptr;
+    if (disabled) return 0;
+    if (a->R != 3 || a->S != 3 || a->stride != 1 || a->pad != 1) return 0;
+    if (a->Hs != a->Hd || a->Ws != a->Wd || a->Hs != a->Ws) return 0;
+    const int W = a->Ws;
+    if (W != 32 && W != 16) return 0;
+    if (a->Cs % 64 != 0 || a->Cd % 64 != 0) return 0;
+    if (a->imgs_per_group % a->split_k != 0) return 0;
+    Wgrad3Params p;
+    p.x = (const char*)a->x; p.dy = (const char*)a->dy; p.out = a->dw_partial;
+    p.n_img = a->n_img; p.H = a->Hs; p.Cs = a->Cs; p.Cd = a->Cd;
+    p.imgs_per_group = a->imgs_per_group; p.split_k = a->split_k; p.imgs_per_block = a->imgs_per_group / a->split_k;
+    const int n_groups = a->n_img / a->imgs_per_group;
+    dim3 grid((a->Cd / 64) * (a->Cs / 64), n_groups * a->split_k);
+    if (a->dtype == FB_F32) {
+        if (W == 32) hipLaunchKernelGGL((conv_wgrad3x3_kernel<float, 32>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wgrad3x3_kernel<float, 16>), grid, dim3(256), 0, st, p);
+    } else {
+        if (W == 32) hipLaunchKernelGGL((conv_wgrad3x3_kernel<bf16_tag, 32>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wgrad3x3_kernel<bf16_tag, 16>), grid, dim3(256), 0, st, p);
+    }
+    return 1;
+}

@@ -45,7 +45,8 @@ def krsc(w):  # [co, ci, kh, kw] -> [co, kh*kw, ci]
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cin,cout,k,stride,hw,n", [(64, 64, 3, 1, 8, 8), (64, 128, 3, 2, 8, 8), (128, 256, 1, 1, 4, 16),
-                                                   (32, 64, 1, 1, 8, 4), (256, 256, 3, 1, 4, 32), (96, 64, 3, 1, 6, 3)])
+                                                   (32, 64, 1, 1, 8, 4), (256, 256, 3, 1, 4, 32), (96, 64, 3, 1, 6, 3),
+                                                   (64, 64, 3, 1, 32, 2), (128, 128, 3, 1, 16, 3), (64, 128, 3, 1, 16, 2)])  # last 3: LDS-halo kernel
 def test_conv_fwd_and_stats(dtype, cin, cout, k, stride, hw, n):
     lib = _lib()
     torch.manual_seed(0)
@@ -69,7 +70,8 @@ def test_conv_fwd_and_stats(dtype, cin, cout, k, stride, hw, n):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cin,cout,k,stride,hw,n,amode", [(64, 64, 3, 1, 8, 8, 0), (64, 128, 3, 2, 8, 8, 2), (128, 64, 1, 1, 4, 16, 1),
-                                                          (64, 64, 3, 1, 8, 4, 1), (256, 128, 3, 2, 8, 4, 0)])
+                                                          (64, 64, 3, 1, 8, 4, 1), (256, 128, 3, 2, 8, 4, 0),
+                                                          (64, 64, 3, 1, 32, 2, 1), (128, 64, 3, 1, 16, 2, 0), (64, 64, 3, 1, 16, 2, 2)])  # halo kernel
 def test_conv_dgrad(dtype, cin, cout, k, stride, hw, n, amode):
     lib = _lib()
     torch.manual_seed(1)
@@ -101,7 +103,9 @@ def test_conv_dgrad(dtype, cin, cout, k, stride, hw, n, amode):
 @pytest.mark.parametrize("cin,cout,k,stride,hw,ipg,groups,split", [(64, 64, 3, 1, 8, 8, 2, 1), (64, 64, 3, 1, 8, 8, 2, 3),
                                                                   (64, 128, 3, 2, 8, 8, 1, 2), (256, 256, 3, 1, 4, 16, 2, 1),
                                                                   (128, 256, 1, 1, 4, 16, 1, 2), (32, 64, 1, 1, 8, 4, 2, 1),
-                                                                  (128, 128, 3, 1, 8, 4, 1, 1)])
+                                                                  (128, 128, 3, 1, 8, 4, 1, 1),
+                                                                  (64, 64, 3, 1, 32, 4, 2, 2), (128, 64, 3, 1, 16, 4, 2, 4),   # all-taps halo kernel
+                                                                  (64, 128, 3, 1, 16, 6, 1, 3)])
 def test_conv_wgrad(dtype, cin, cout, k, stride, hw, ipg, groups, split):
     lib = _lib()
     torch.manual_seed(2)

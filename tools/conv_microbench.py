@@ -1,0 +1,56 @@
+"""Micro-benchmark of single conv launches (HIP events) for kernel tuning.  Usage: python tools/conv_microbench.py [case ...]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from fullbatchtraining_amd import lib
+
+CASES = {  # name: (cin, cout, k, stride, hw, n_img)
+    "l1": (64, 64, 3, 1, 32, 1664), "l2": (128, 128, 3, 1, 16, 1664), "l3": (256, 256, 3, 1, 8, 1664), "l4": (512, 512, 3, 1, 4, 1664),
+    "l2s": (64, 128, 3, 2, 32, 1664), "stem": (32, 64, 1, 1, 32, 1664),
+}
+
+
+def bench(fn, iters=10):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3
+
+
+def main():
+    names = sys.argv[1:] or list(CASES)
+    dtype = torch.bfloat16 if os.environ.get("DT", "bf16") == "bf16" else torch.float32
+    for name in names:
+        cin, cout, k, stride, hw, n = CASES[name]
+        pad = k // 2
+        ho = (hw + 2 * pad - k) // stride + 1
+        x = torch.randn(n, hw, hw, cin, device="cuda").to(dtype)
+        w = (torch.randn(cout, k * k, cin, device="cuda") * 0.05).to(dtype)
+        wt = (torch.randn(cin, k * k, cout, device="cuda") * 0.05).to(dtype)
+        y = torch.empty(n, ho, ho, cout, device="cuda", dtype=dtype)
+        dy = torch.randn(n, ho, ho, cout, device="cuda").to(dtype)
+        dx = torch.empty(n, hw, hw, cin, device="cuda", dtype=dtype)
+        stat = torch.zeros(2, (n * ho * ho + 127) // 128, cout, device="cuda")
+        flops = 2 * n * ho * ho * cout * k * k * cin
+        t = bench(lambda: lib.conv2d(x, w, y, k, k, stride, pad, 0, stat_partial=stat))
+        print(f"{name:5s} fwd   {t:8.1f} us  {flops / t / 1e6:7.1f} TF/s")
+        t = bench(lambda: lib.conv2d(dy, wt, dx, k, k, stride, pad, 1))
+        print(f"{name:5s} dgrad {t:8.1f} us  {flops / t / 1e6:7.1f} TF/s")
+        ipg = 128
+        for split in ((32, 8, 1) if k == 3 and stride == 1 else (8, 1)):
+            slab = torch.empty(n // ipg * split * cout * k * k * cin, device="cuda")
+            try:
+                t = bench(lambda: lib.conv2d_wgrad(x, dy, slab, k, k, stride, pad, ipg, split))
+                print(f"{name:5s} wgrad split={split:3d} {t:8.1f} us  {flops / t / 1e6:7.1f} TF/s")
+            except Exception as e:
+                print(name, "wgrad", split, "failed", e)
+
+
+if __name__ == "__main__":
+    main()
