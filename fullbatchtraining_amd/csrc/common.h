@@ -28,10 +28,12 @@ static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b;
 // ---- bf16 <-> f32 (round to nearest even, NaN preserved) ------------------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+    return __builtin_bit_cast(unsigned short, (__bf16)f);      // v_cvt_pk_bf16_f32 (round to nearest even) on gfx950
+}
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){lo, hi}, bf16x2_t));
 }
 
 // Element-type traits.  A "chunk" is 16 bytes: 4 f32 or 8 bf16.
@@ -59,7 +61,7 @@ template <> struct ET<bf16_tag> {
     __device__ static __forceinline__ uint4 pack(const float* f) {
         unsigned w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = (unsigned)f32_to_bf16(f[2 * i]) | ((unsigned)f32_to_bf16(f[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
         return make_uint4(w[0], w[1], w[2], w[3]);
     }
 };

@@ -141,8 +141,7 @@ __global__ __launch_bounds__(256) void conv3x3s1_halo_kernel(const HaloParams p)
             }
             char* dp = p.dst + (pix * p.Cd + co) * EB;
             if constexpr (EB == 4) *(float4*)dp = make_float4(v[0], v[1], v[2], v[3]);
-            else *(uint2*)dp = make_uint2((unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16),
-                                          (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16));
+            else *(uint2*)dp = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
 #pragma unroll
             for (int r = 0; r < 4; ++r) { ssum[i][r] += v[r]; ssq[i][r] += v[r] * v[r]; }
         }

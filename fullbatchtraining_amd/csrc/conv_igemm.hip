@@ -11,14 +11,7 @@
 #include "common.h"
 #include "profile.h"
 
-struct ConvParams {
-    const char* src; const char* wgt; char* dst; const char* addend; float* stat;
-    int n_img, Hs, Ws, Cs, Hd, Wd, Cd;
-    int R, S, stride, pad, mode;
-    int qH, qW, os, ss, M;
-    int imgs_per_wset; long long wset_stride_bytes;
-    int addend_mode, n_mblocks;
-};
+#include "conv_params.h"
 
 template <typename T, int BN_CO>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
@@ -167,8 +160,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 }
                 char* dp = p.dst + (pix * p.Cd + co) * EB;
                 if constexpr (EB == 4) *(float4*)dp = make_float4(v[0], v[1], v[2], v[3]);
-                else *(uint2*)dp = make_uint2((unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16),
-                                              (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16));
+                else *(uint2*)dp = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { ssum[i][r] += v[r]; ssq[i][r] += v[r] * v[r]; }
             }
@@ -201,7 +193,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
 }
 
-int fb_try_conv3x3_halo(const fb_conv_args* a, hipStream_t st);   // conv3x3_halo.hip
+int fb_try_conv3x3_halo(const fb_conv_args* a, hipStream_t st);    // conv3x3_halo.hip
+int fb_try_conv3x3_halo2(const fb_conv_args* a, hipStream_t st);   // conv3x3_halo2.hip
 
 template <typename T> static int launch_conv(const ConvParams& p, int classes, hipStream_t st) {
     const int mblocks = (p.M + 127) / 128;
@@ -251,8 +244,12 @@ extern "C" int fb_conv2d(const fb_conv_args* a, void* stream) {
     p.n_mblocks = ((p.M + 127) / 128) * classes;
     hipStream_t st = (hipStream_t)stream;
     const int prof = fb_prof_begin(a->mode == 0 ? FB_PROF_IGEMM_FWD : FB_PROF_IGEMM_DGRAD, st);
-    if (!fb_try_conv3x3_halo(a, st)) {
-        if (a->dtype == FB_F32) launch_conv<float>(p, classes, st); else launch_conv<bf16_tag>(p, classes, st);
+    static const bool v1 = getenv("FB_IGEMM_V1") != nullptr;
+    if (!fb_try_conv3x3_halo2(a, st) && !fb_try_conv3x3_halo(a, st)) {
+        p.zeros = nullptr;
+        if (v1 || !fb_launch_igemm_glds(p, classes, a->dtype, st)) {
+            if (a->dtype == FB_F32) launch_conv<float>(p, classes, st); else launch_conv<bf16_tag>(p, classes, st);
+        }
     }
     fb_prof_end(prof, st);
     FB_CHECK_LAUNCH("fb_conv2d");

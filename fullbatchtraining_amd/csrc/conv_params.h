@@ -1,0 +1,13 @@
+// Kernel-argument block shared by the implicit-GEMM convolution kernels.
+#pragma once
+struct ConvParams {
+    const char* src; const char* wgt; char* dst; const char* addend; float* stat;
+    int n_img, Hs, Ws, Cs, Hd, Wd, Cd;
+    int R, S, stride, pad, mode;
+    int qH, qW, os, ss, M;
+    int imgs_per_wset; long long wset_stride_bytes;
+    int addend_mode, n_mblocks;
+    const char* zeros;   // >= 128 bytes of zeros in device memory (source of padding rows for LDS-direct loads)
+};
+const void* fb_zero_page();                                                   // runtime.cpp
+int fb_launch_igemm_glds(const ConvParams& p, int classes, int dtype, hipStream_t st);   // conv_igemm_glds.hip

@@ -3,6 +3,7 @@
 
 #include "common.h"
 #include "profile.h"
+#include "conv_params.h"
 
 thread_local char fb_err_buf[512] = "";
 extern "C" const char* fb_last_error_string(void) { return fb_err_buf; }
@@ -15,6 +16,17 @@ std::vector<Pair> g_pool;
 size_t g_used = 0;
 long long g_dropped[FB_PROF_CLASSES] = {0};
 }  // namespace
+
+// 4 KiB of zeros per process, allocated on first use (the one internal allocation of the library): padding source for
+// LDS-direct (global_load_lds) tile loads, which cannot synthesise zeros.
+const void* fb_zero_page() {
+    static void* page = nullptr;
+    if (!page) {
+        if (hipMalloc(&page, 4096) != hipSuccess) { page = nullptr; return nullptr; }
+        hipMemset(page, 0, 4096);
+    }
+    return page;
+}
 
 extern "C" int fb_profile_enable(int on, int capacity) {
     if (on && g_pool.size() < (size_t)capacity) {
