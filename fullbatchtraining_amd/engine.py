@@ -297,6 +297,27 @@ class Engine:
                 bufs[f"{L.bn_name}.running_var"].copy_(rv[L.ch_off:L.ch_off + L.cout])
                 bufs[f"{L.bn_name}.num_batches_tracked"].fill_(self.num_batches_tracked)
 
+    def flatten(self, tensors):
+        """List of tensors in ``model.parameters()`` order/layout (OIHW) -> flat arena vector (KRSC) on the engine's device."""
+        flat = torch.zeros(self.plan.P, device=self.device, dtype=torch.float32)
+        for name, t in zip(self.plan.param_names, tensors):
+            v = t.detach().to(self.device, torch.float32)
+            v = v.permute(0, 2, 3, 1).reshape(-1) if v.dim() == 4 else v.reshape(-1)
+            flat[self.plan.offsets[name]:self.plan.offsets[name] + v.numel()] = v
+        return flat
+
+    def unflatten_list(self, flat):
+        """Flat arena vector -> list of tensors in the reference's layouts (same device as ``flat``)."""
+        return [self._unflatten(flat, name) for name in self.plan.param_names]
+
+    def store_buffers_to_model(self, model):
+        with torch.no_grad():
+            bufs = dict(model.named_buffers())
+            for L in self.plan.layers:
+                bufs[f"{L.bn_name}.running_mean"].copy_(self.running_mean[L.ch_off:L.ch_off + L.cout])
+                bufs[f"{L.bn_name}.running_var"].copy_(self.running_var[L.ch_off:L.ch_off + L.cout])
+                bufs[f"{L.bn_name}.num_batches_tracked"].fill_(self.num_batches_tracked)
+
     def momentum_state(self):
         flat = self.mom.detach().cpu()
         return [self._unflatten(flat, name) for name in self.plan.param_names]

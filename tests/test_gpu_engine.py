@@ -108,3 +108,25 @@ def test_golden_reference_chunk_gradient_f32(golden):
         print(f"chunk {k}: engine-vs-ref64 {e64:.2e}, engine-vs-ref32 {e32:.2e}, ref32-vs-ref64 {ref_noise:.2e}")
         assert e64 < 1e-2 and e32 < 1.5e-2
         assert abs(float(sum(t.double().pow(2).sum() for t in got[k])) - sq_ref) < 5e-3 * sq_ref
+
+
+def test_bottleneck_standard_stem_chunk_gradients_vs_oracle():
+    """ResNet-50 (Bottleneck blocks, 7x7/s2 'standard' stem + MaxPool, stride-1 and stride-2 shortcuts) -- the block types of the
+    ResNet-152 configuration -- at 64x64 input: f32 engine vs float64 oracle."""
+    pixels, chunk, G = 64, 32, 2
+    cfg, model, eng, stem_patches = _build(50, pixels, chunk, G, torch.float32, stem="standard")
+    x, y = make_data(chunk * G, pixels)
+    truth, params, buffers = _oracle_chunk_grads(model, x, y, chunk, depth=50, stem="standard")
+    patches = stem_patches(x.cuda(), eng.plan.stem, torch.float32)
+    eng.prep_weights(eng.theta, 1)
+    eng.group_gradient(patches, y.cuda(), G, eng.g)
+    torch.cuda.synchronize()
+    got = _engine_grads_as_lists(eng, G)
+    for g in range(G):
+        assert abs(float(eng.loss[g]) - truth[g][1]) < 1e-5 * abs(truth[g][1])
+        a = torch.cat([t.reshape(-1).double() for t in got[g]])
+        t = torch.cat([r.reshape(-1).double() for r in truth[g][0]])
+        err = float((a - t).norm() / t.norm())
+        print(f"resnet50/standard chunk {g}: engine-vs-f64-truth {err:.3e}")
+        assert err < 5e-2, err      # 53 conv layers: fp32 conditioning of the chunk gradient is ~5x that of ResNet-18
+        assert rel_err(got[g][-2].numpy(), truth[g][0][-2].numpy()) < 1e-4
