@@ -169,7 +169,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
 }
 
-int fb_try_wgrad3x3(const fb_wgrad_args* a, hipStream_t st);   // conv_wgrad3x3.hip
+int fb_try_wgrad3x3(const fb_wgrad_args* a, hipStream_t st);      // conv_wgrad3x3.hip
+int fb_try_wgrad3x3_v2(const fb_wgrad_args* a, hipStream_t st);   // conv_wgrad3x3_v2.hip
 
 extern "C" int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream) {
     if (!a || !a->x || !a->dy || !a->dw_partial) FB_FAIL(FB_ERR_ARG, "fb_conv2d_wgrad: null pointer");
@@ -189,7 +190,7 @@ extern "C" int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream) {
     p.px_per_split = (int)(ceil_div64(ceil_div64(p.px_per_group, a->split_k), kstep) * kstep);
     const int taps = a->R * a->S;
     const int prof = fb_prof_begin(FB_PROF_WGRAD, st);
-    if (fb_try_wgrad3x3(a, st)) {
+    if (fb_try_wgrad3x3_v2(a, st) || fb_try_wgrad3x3(a, st)) {
     } else if (big) {
         dim3 grid((a->Cd / 128) * (a->Cs / 128), taps, n_groups * a->split_k);
         if (a->dtype == FB_F32) hipLaunchKernelGGL((conv_wgrad_kernel<float, 2, 2, 1, 1, 4>), grid, dim3(256), 0, st, p);

@@ -207,7 +207,7 @@ class FullBatchTrainer:
             log.warning("grad_reg finite differences need matching fp32 passes (perturbation ~1e-6 per weight): running fp32.")
         from .parallel import ShardPlan
         self.shard = ShardPlan(self.n_chunks, self.world, self.rank)
-        G = int(cfg.impl.get("engine", {}).get("chunk_group", 13))
+        G = int(cfg.impl.get("engine", {}).get("chunk_group", 30))
         G = max(1, min(G, self.shard.count))
         self.engine = Engine(model, X.shape[-1], self.chunk, G, compute_dtype=self.dtype, device=self.device, fd_sets=fd_sets)
         stem = self.engine.plan.stem
