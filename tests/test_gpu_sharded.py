@@ -1,0 +1,70 @@
+"""Sharded (multi-process) training path on ONE GPU: two ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one
+device), which exercises everything of the data-parallel path except the transport: chunk-range sharding, local running
+mean x K_r/K, reduce-scatter, sharded clip + Nesterov SGD with sharded momentum, parameter all-gather, BN running-stat
+recombination, stats gathering.  The result must equal the 1-process run (1-process semantics are the target)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+OVERRIDES = ["hyp=fbclip", "hyp.steps=3", "hyp.warmup=1", "data.batch_size=32", "hyp.sub_batch=32", "data.pixels=16",
+             "impl.validate_every_nth_step=1000", "impl.engine.chunk_group=2"]
+N, PIXELS, SEED = 7 * 32, 16, 11       # 7 chunks: ranks own 4 and 3
+
+
+def _run(rank, world, port, out_dir, grad_reg):
+    import sys
+    sys.path.insert(0, REPO)
+    from fullbatchtraining_amd.cfg import compose
+    from fullbatchtraining_amd.models import construct_model
+    from fullbatchtraining_amd.training import train
+    from tests.helpers import make_data
+
+    torch.cuda.set_device(0)
+    over = list(OVERRIDES) + (["hyp.grad_reg.block_strength=0.5"] if grad_reg else [])
+    if world > 1:
+        torch.distributed.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        over.append("impl/setup=distributed")
+    cfg = compose(over, original_cwd=out_dir, name="sharded")
+    torch.manual_seed(SEED)
+    model = construct_model(cfg.model, 3, 10)
+    x, y = make_data(N, PIXELS)
+    setup = dict(device=torch.device("cuda:0"), dtype=torch.float, memory_format=torch.contiguous_format)
+    stats = train(model, (x, y), None, setup, cfg)
+    keep = {k: v for k, v in stats.items() if k != "train_time"}
+    torch.save(dict(stats=keep, state={k: v.cpu() for k, v in model.state_dict().items()}),
+               os.path.join(out_dir, f"w{world}_r{rank}.pt"))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("grad_reg", [False, True])
+def test_two_rank_run_equals_single_process(tmp_path, grad_reg):
+    out = str(tmp_path)
+    mp.spawn(_run, args=(1, 0, out, grad_reg), nprocs=1, join=True)
+    mp.spawn(_run, args=(2, _free_port(), out, grad_reg), nprocs=2, join=True)
+    ref = torch.load(os.path.join(out, "w1_r0.pt"))
+    for r in range(2):
+        got = torch.load(os.path.join(out, f"w2_r{r}.pt"))
+        for key in ("train_loss", "train_acc", "param_norm", "grad_norm", "full_loss", "preclip_gradnorm", "clipped_step"):
+            assert np.allclose(got["stats"][key], ref["stats"][key], rtol=2e-4 if not grad_reg else 5e-3, atol=1e-6), (key, got["stats"][key], ref["stats"][key])
+        for k in range(7):
+            assert np.allclose(got["stats"][f"grad_norm_train_{k}"], ref["stats"][f"grad_norm_train_{k}"], rtol=1e-4 if not grad_reg else 5e-3)
+        for name, t in ref["state"].items():
+            if t.is_floating_point():
+                scale = float(t.abs().max()) + 1e-12
+                assert float((got["state"][name] - t).abs().max()) < (2e-4 if not grad_reg else 5e-3) * scale + 1e-6, name
+            else:
+                assert torch.equal(got["state"][name], t), name
