@@ -119,7 +119,7 @@ def call(name, *args):
     lib = load()
     status = getattr(lib, name)(*args, _stream())
     if status != 0:
-        raise EngineError(f"{name} failed ({status}): {lib.fb_last_error_string().decode()}")
+        raise EngineError(f"{name} failed ({status}): {lib.fb_last_error_string().decode()} [args: {args}]")
 
 
 def dtype_code(dtype):

@@ -212,7 +212,7 @@ class FullBatchTrainer:
         self.engine = Engine(model, X.shape[-1], self.chunk, G, compute_dtype=self.dtype, device=self.device, fd_sets=fd_sets)
         stem = self.engine.plan.stem
         lo, hi = self.shard.first * self.chunk, (self.shard.first + self.shard.count) * self.chunk
-        self.patches = torch.cat([stem_patches(X[i:i + 4096], stem, self.dtype) for i in range(lo, hi, 4096)]) if hi > lo else None
+        self.patches = torch.cat([stem_patches(X[i:min(i + 4096, hi)], stem, self.dtype) for i in range(lo, hi, 4096)]) if hi > lo else None
         self.labels = Y[lo:hi].contiguous()
         self.valid = _stage(validloader, self.device) if validloader is not None else None
         self.stats = defaultdict(list)
