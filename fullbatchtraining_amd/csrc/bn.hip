@@ -65,12 +65,14 @@ extern "C" int fb_bn_fwd_finalize(const float* stat_partial, int32_t n_mblocks, 
 template <typename T, int RES>   // RES: 0 none, 1 plain residual, 2 residual with its own BN affine
 __global__ void bn_apply_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, const float* __restrict__ scale,
                                 const float* __restrict__ shift, const uint4* __restrict__ res, const float* __restrict__ rscale,
-                                const float* __restrict__ rshift, long long n_vec, int cvec, long long vec_per_group, int C, int relu) {
+                                const float* __restrict__ rshift, long long n_vec, int cvec, long long vec_per_group, int C, int relu,
+                                unsigned char* __restrict__ mask_out) {
     constexpr int V = ET<T>::VEC;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (long long)gridDim.x * blockDim.x) {
         const int c0 = (int)(i % cvec) * V;
         const long long g = i / vec_per_group;
         float xv[V], o[V];
+        unsigned m = 0;
         ET<T>::unpack(x[i], xv);
         const float* sc = scale + g * C + c0; const float* sh = shift + g * C + c0;
         float rv[V];
@@ -81,29 +83,31 @@ __global__ void bn_apply_kernel(const uint4* __restrict__ x, uint4* __restrict__
             if (RES == 1) v += rv[k];
             if (RES == 2) v += rv[k] * rscale[g * C + c0 + k] + rshift[g * C + c0 + k];
             o[k] = relu ? fmaxf(v, 0.f) : v;
+            m |= (v > 0.f ? 1u : 0u) << k;
         }
         y[i] = ET<T>::pack(o);
+        if (mask_out) mask_out[i] = (unsigned char)m;     // ReLU mask, one byte per 16-byte vector (backward reads 1/16 of y)
     }
 }
 
 template <typename T>
 static void launch_bn_apply(const void* x, void* y, const float* scale, const float* shift, const void* res, const float* rscale,
-                            const float* rshift, int64_t n_pixels, int C, int64_t ppg, int relu, hipStream_t st) {
+                            const float* rshift, int64_t n_pixels, int C, int64_t ppg, int relu, unsigned char* mask_out, hipStream_t st) {
     const int cvec = C / ET<T>::VEC;
     const long long n_vec = n_pixels * cvec, vpg = ppg * cvec;
     const int blocks = (int)((n_vec + 255) / 256 < 8192 ? (n_vec + 255) / 256 : 8192);
-    if (!res) hipLaunchKernelGGL((bn_apply_kernel<T, 0>), dim3(blocks), dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, nullptr, nullptr, nullptr, n_vec, cvec, vpg, C, relu);
-    else if (!rscale) hipLaunchKernelGGL((bn_apply_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, nullptr, nullptr, n_vec, cvec, vpg, C, relu);
-    else hipLaunchKernelGGL((bn_apply_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, rscale, rshift, n_vec, cvec, vpg, C, relu);
+    if (!res) hipLaunchKernelGGL((bn_apply_kernel<T, 0>), dim3(blocks), dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, nullptr, nullptr, nullptr, n_vec, cvec, vpg, C, relu, mask_out);
+    else if (!rscale) hipLaunchKernelGGL((bn_apply_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, nullptr, nullptr, n_vec, cvec, vpg, C, relu, mask_out);
+    else hipLaunchKernelGGL((bn_apply_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, rscale, rshift, n_vec, cvec, vpg, C, relu, mask_out);
 }
 
 extern "C" int fb_bn_apply(const void* x, void* y, const float* scale, const float* shift, const void* res, const float* rscale,
-                           const float* rshift, int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t relu, int32_t dtype,
-                           void* stream) {
+                           const float* rshift, int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t relu, void* mask_out,
+                           int32_t dtype, void* stream) {
     if (!x || !y || !scale || !shift) FB_FAIL(FB_ERR_ARG, "fb_bn_apply: null pointer");
     if (C % 8 != 0) FB_FAIL(FB_ERR_SHAPE, "fb_bn_apply: C=%d must be a multiple of 8", C);
-    if (dtype == FB_F32) launch_bn_apply<float>(x, y, scale, shift, res, rscale, rshift, n_pixels, C, pixels_per_group, relu, (hipStream_t)stream);
-    else launch_bn_apply<bf16_tag>(x, y, scale, shift, res, rscale, rshift, n_pixels, C, pixels_per_group, relu, (hipStream_t)stream);
+    if (dtype == FB_F32) launch_bn_apply<float>(x, y, scale, shift, res, rscale, rshift, n_pixels, C, pixels_per_group, relu, (unsigned char*)mask_out, (hipStream_t)stream);
+    else launch_bn_apply<bf16_tag>(x, y, scale, shift, res, rscale, rshift, n_pixels, C, pixels_per_group, relu, (unsigned char*)mask_out, (hipStream_t)stream);
     FB_CHECK_LAUNCH("fb_bn_apply");
     return FB_OK;
 }
@@ -139,6 +143,7 @@ extern "C" int fb_bn_running_update(float* running_mean, float* running_var, con
 // backward reduce: block = 128 pixels x all channels.  thread -> (channel vector lane, pixel sub-row)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint4* __restrict__ dout, const uint4* __restrict__ y,
+                                                            const unsigned char* __restrict__ mask,
                                                             const uint4* __restrict__ x, const float* __restrict__ mean_tab,
                                                             const float* __restrict__ invstd, int ch_total, int ch_off,
                                                             float* __restrict__ partial, long long n_pixels, int C, long long ppg,
@@ -163,10 +168,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint4* __restr
                 const long long i = pidx * cvec + cv;
                 float d[V], xv[V], yv[V];
                 ET<T>::unpack(dout[i], d); ET<T>::unpack(x[i], xv);
-                if (y) ET<T>::unpack(y[i], yv);
+                unsigned mk = 0xffu;
+                if (mask) mk = mask[i];
+                else if (y) {
+                    ET<T>::unpack(y[i], yv);
+                    mk = 0;
+#pragma unroll
+                    for (int k = 0; k < V; ++k) mk |= (yv[k] > 0.f ? 1u : 0u) << k;
+                }
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
-                    const float dy = (y && !(yv[k] > 0.f)) ? 0.f : d[k];
+                    const float dy = ((mk >> k) & 1u) ? d[k] : 0.f;
                     s1[k] += dy; s2[k] += dy * ((xv[k] - mu[k]) * is[k]);
                 }
             }
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint4* __restr
     }
 }
 
-extern "C" int fb_bn_bwd_reduce(const void* dout, const void* y, const void* x, const float* mean_tab, const float* invstd,
+extern "C" int fb_bn_bwd_reduce(const void* dout, const void* y, const void* mask, const void* x, const float* mean_tab, const float* invstd,
                                 int32_t ch_total, int32_t ch_off, float* partial, int64_t n_pixels, int32_t C,
                                 int64_t pixels_per_group, int32_t dtype, void* stream) {
     if (!dout || !x || !mean_tab || !invstd || !partial) FB_FAIL(FB_ERR_ARG, "fb_bn_bwd_reduce: null pointer");
@@ -196,10 +208,10 @@ extern "C" int fb_bn_bwd_reduce(const void* dout, const void* y, const void* x, 
     if (smem > 64 * 1024) FB_FAIL(FB_ERR_UNSUPPORTED, "fb_bn_bwd_reduce: C=%d too large", C);
     if (dtype == FB_F32)
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<float>), dim3(n_mblocks), dim3(256), smem, (hipStream_t)stream, (const uint4*)dout, (const uint4*)y,
-                           (const uint4*)x, mean_tab, invstd, ch_total, ch_off, partial, (long long)n_pixels, C, (long long)pixels_per_group, n_mblocks);
+                           (const unsigned char*)mask, (const uint4*)x, mean_tab, invstd, ch_total, ch_off, partial, (long long)n_pixels, C, (long long)pixels_per_group, n_mblocks);
     else
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_tag>), dim3(n_mblocks), dim3(256), smem, (hipStream_t)stream, (const uint4*)dout, (const uint4*)y,
-                           (const uint4*)x, mean_tab, invstd, ch_total, ch_off, partial, (long long)n_pixels, C, (long long)pixels_per_group, n_mblocks);
+                           (const unsigned char*)mask, (const uint4*)x, mean_tab, invstd, ch_total, ch_off, partial, (long long)n_pixels, C, (long long)pixels_per_group, n_mblocks);
     FB_CHECK_LAUNCH("fb_bn_bwd_reduce");
     return FB_OK;
 }
@@ -233,7 +245,8 @@ extern "C" int fb_bn_bwd_finalize(const float* partial, int32_t n_mblocks, int32
 }
 
 template <typename T>
-__global__ void bn_bwd_apply_kernel(const uint4* __restrict__ dout, const uint4* __restrict__ y, const uint4* __restrict__ x,
+__global__ void bn_bwd_apply_kernel(const uint4* __restrict__ dout, const uint4* __restrict__ y, const unsigned char* __restrict__ mask,
+                                    const uint4* __restrict__ x,
                                     const float* __restrict__ coef, uint4* __restrict__ dx, uint4* __restrict__ dy_out, long long n_vec,
                                     int cvec, long long vec_per_group, int C) {
     constexpr int V = ET<T>::VEC;
@@ -242,11 +255,18 @@ __global__ void bn_bwd_apply_kernel(const uint4* __restrict__ dout, const uint4*
         const long long g = i / vec_per_group;
         float d[V], xv[V], yv[V], o[V], dyv[V];
         ET<T>::unpack(dout[i], d); ET<T>::unpack(x[i], xv);
-        if (y) ET<T>::unpack(y[i], yv);
+        unsigned mk = 0xffu;
+        if (mask) mk = mask[i];
+        else if (y) {
+            ET<T>::unpack(y[i], yv);
+            mk = 0;
+#pragma unroll
+            for (int k = 0; k < V; ++k) mk |= (yv[k] > 0.f ? 1u : 0u) << k;
+        }
         const float* cf = coef + (g * C + c0) * 3;
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            const float dy = (y && !(yv[k] > 0.f)) ? 0.f : d[k];
+            const float dy = ((mk >> k) & 1u) ? d[k] : 0.f;
             dyv[k] = dy;
             o[k] = cf[3 * k] * dy + cf[3 * k + 1] * xv[k] + cf[3 * k + 2];
         }
@@ -255,7 +275,7 @@ __global__ void bn_bwd_apply_kernel(const uint4* __restrict__ dout, const uint4*
     }
 }
 
-extern "C" int fb_bn_bwd_apply(const void* dout, const void* y, const void* x, const float* coef, void* dx, void* dy_out,
+extern "C" int fb_bn_bwd_apply(const void* dout, const void* y, const void* mask, const void* x, const float* coef, void* dx, void* dy_out,
                                int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t dtype, void* stream) {
     if (!dout || !x || !coef || !dx) FB_FAIL(FB_ERR_ARG, "fb_bn_bwd_apply: null pointer");
     const int V = dtype == FB_F32 ? 4 : 8;
@@ -264,10 +284,10 @@ extern "C" int fb_bn_bwd_apply(const void* dout, const void* y, const void* x, c
     const int blocks = (int)((n_vec + 255) / 256 < 8192 ? (n_vec + 255) / 256 : 8192);
     if (dtype == FB_F32)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)dout, (const uint4*)y,
-                           (const uint4*)x, coef, (uint4*)dx, (uint4*)dy_out, n_vec, cvec, vpg, C);
+                           (const unsigned char*)mask, (const uint4*)x, coef, (uint4*)dx, (uint4*)dy_out, n_vec, cvec, vpg, C);
     else
         hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_tag>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)dout, (const uint4*)y,
-                           (const uint4*)x, coef, (uint4*)dx, (uint4*)dy_out, n_vec, cvec, vpg, C);
+                           (const unsigned char*)mask, (const uint4*)x, coef, (uint4*)dx, (uint4*)dy_out, n_vec, cvec, vpg, C);
     FB_CHECK_LAUNCH("fb_bn_bwd_apply");
     return FB_OK;
 }

@@ -196,6 +196,7 @@ class Engine:
         self.eps_n = torch.zeros(self.G, **f32)
         self.norms2 = torch.zeros(2, **f32)
         self.pool = _Pool(self.device, self.dt)
+        self.masks = {}
         self.load_from_model(model)
 
     # ------------------------------------------------------------------------------------------------------ buffers --
@@ -365,7 +366,16 @@ class Engine:
         px = G * self.chunk * L.hout * L.wout
         call("fb_bn_apply", L.x.data_ptr(), out.data_ptr(), L.scale.data_ptr(), L.shift.data_ptr(), _ptr(res),
              resL.scale.data_ptr() if resL is not None else None, resL.shift.data_ptr() if resL is not None else None,
-             px, L.cout, self.chunk * L.hout * L.wout, 1 if relu else 0, self.dtc)
+             px, L.cout, self.chunk * L.hout * L.wout, 1 if relu else 0, _ptr(self._mask_of(out)) if relu else None, self.dtc)
+
+    def _mask_of(self, act):
+        """ReLU bitmask buffer (1 byte per 16-byte vector) paired with a post-ReLU activation tensor, created on first use."""
+        key = act.data_ptr()
+        m = self.masks.get(key)
+        if m is None:
+            m = torch.empty(act.numel() * act.element_size() // 16, device=self.device, dtype=torch.uint8)
+            self.masks[key] = m
+        return m
 
     def _sl(self, t, G):
         return t[: G * self.chunk]
@@ -416,14 +426,16 @@ class Engine:
         px = n * L.hout * L.wout
         ppg = self.chunk * L.hout * L.wout
         n_mblocks = (px + 127) // 128
-        call("fb_bn_bwd_reduce", dout.data_ptr(), _ptr(mask), L.x.data_ptr(), self.mean_tab[pidx].data_ptr(), L.invstd.data_ptr(),
+        bits = self.masks.get(mask.data_ptr()) if mask is not None else None      # bitmask written by the forward bn_apply
+        y = None if bits is not None else mask
+        call("fb_bn_bwd_reduce", dout.data_ptr(), _ptr(y), _ptr(bits), L.x.data_ptr(), self.mean_tab[pidx].data_ptr(), L.invstd.data_ptr(),
              self.plan.ch_total, L.ch_off, self.stat_ws.data_ptr(), px, L.cout, ppg, self.dtc)
         call("fb_bn_bwd_finalize", self.stat_ws.data_ptr(), n_mblocks, G, L.cout, float(ppg), L.scale.data_ptr(),
              self.mean_tab[pidx].data_ptr(), L.invstd.data_ptr(), self.plan.ch_total, L.ch_off,
              gout.data_ptr() + 4 * L.g_off, gout.data_ptr() + 4 * L.b_off, self.plan.P, L.coef.data_ptr())
         dx = self.pool.get((n, L.hout, L.wout, L.cout))
         dy = self.pool.get((n, L.hout, L.wout, L.cout)) if want_dy else None
-        call("fb_bn_bwd_apply", dout.data_ptr(), _ptr(mask), L.x.data_ptr(), L.coef.data_ptr(), dx.data_ptr(), _ptr(dy), px, L.cout, ppg,
+        call("fb_bn_bwd_apply", dout.data_ptr(), _ptr(y), _ptr(bits), L.x.data_ptr(), L.coef.data_ptr(), dx.data_ptr(), _ptr(dy), px, L.cout, ppg,
              self.dtc)
         return dx, dy
 

@@ -90,8 +90,10 @@ int fb_bn_fwd_finalize(const float* stat_partial, int32_t n_mblocks, int32_t n_g
 /* y = relu?(x*scale[g][c] + shift[g][c] + residual)  residual: none | res | res*rscale[g][c]+rshift[g][c]
  * (BatchNorm2d + ReLU(inplace) + `out += identity`, resnets.py:217-228) */
 int fb_bn_apply(const void* x, void* y, const float* scale, const float* shift, const void* res, const float* rscale,
-                const float* rshift, int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t relu, int32_t dtype,
-                void* stream);
+                const float* rshift, int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t relu, void* mask_out,
+                int32_t dtype, void* stream);
+/* mask_out (optional): ReLU mask, one byte per 16-byte vector of y (bit k = element k > 0).  The backward kernels accept it
+ * in place of y (1/16 of the bytes).  When both `mask` and `y` are NULL no mask is applied (BN without ReLU). */
 /* sequential running-stat EMA for every BN channel of the network in one launch (momentum 0.1, unbiased var,
  * torch BatchNorm2d).  mean_tab/var_tab: [n_passes][n_groups][ch_total] (passes pass_stride floats apart).
  * Update order: for g in groups: for p in passes  -- i.e. chunk g's base pass, then its finite-difference passes,
@@ -99,7 +101,7 @@ int fb_bn_apply(const void* x, void* y, const float* scale, const float* shift, 
 int fb_bn_running_update(float* running_mean, float* running_var, const float* mean_tab, const float* var_tab, int32_t n_passes,
                          int64_t pass_stride, const float* unbias, int32_t n_groups, int32_t ch_total, float momentum, void* stream);
 /* backward: partial sums of dy and dy*xhat with dy = dout * (y > 0) when y != NULL (threshold_backward). */
-int fb_bn_bwd_reduce(const void* dout, const void* y, const void* x, const float* mean_tab, const float* invstd,
+int fb_bn_bwd_reduce(const void* dout, const void* y, const void* mask, const void* x, const float* mean_tab, const float* invstd,
                      int32_t ch_total, int32_t ch_off, float* partial, int64_t n_pixels, int32_t C,
                      int64_t pixels_per_group, int32_t dtype, void* stream);
 /* dgamma/dbeta -> gradient arena (per group), coefficients for fb_bn_bwd_apply */
@@ -107,7 +109,7 @@ int fb_bn_bwd_finalize(const float* partial, int32_t n_mblocks, int32_t n_groups
                        const float* scale, const float* mean_tab, const float* invstd, int32_t ch_total, int32_t ch_off,
                        float* dgamma, float* dbeta, int64_t grad_group_stride, float* coef, void* stream);
 /* dx = c_dy*dy + c_x*x + c_0 ; optionally also stores dy (masked gradient, used by the shortcut branch) */
-int fb_bn_bwd_apply(const void* dout, const void* y, const void* x, const float* coef, void* dx, void* dy_out,
+int fb_bn_bwd_apply(const void* dout, const void* y, const void* mask, const void* x, const float* coef, void* dx, void* dy_out,
                     int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t dtype, void* stream);
 
 /* ---------------------------------------------------------------- pooling / head --------------------------------- */

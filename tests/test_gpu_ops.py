@@ -172,8 +172,9 @@ def test_batchnorm_fwd_bwd(dtype, C, hw, ipg, groups):
              mean_tab.data_ptr(), var_tab.data_ptr(), ch_total, ch_off, scale.data_ptr(), shift.data_ptr(), invstd.data_ptr())
     xd, resd, doutd = (nhwc(t).to(dtype).cuda() for t in (x, res, dout))
     y = torch.empty_like(xd)
+    bits = torch.zeros(xd.numel() * xd.element_size() // 16, dtype=torch.uint8, device="cuda")
     lib.call("fb_bn_apply", xd.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), resd.data_ptr(), None, None, px, C, ppg, 1,
-             lib.dtype_code(dtype))
+             bits.data_ptr(), lib.dtype_code(dtype))
     # reference, per group
     ys, dxs, dgs, dbs = [], [], [], []
     for g in range(groups):
@@ -195,7 +196,12 @@ def test_batchnorm_fwd_bwd(dtype, C, hw, ipg, groups):
     # backward uses the *reference* y as mask to avoid sign flips of near-zero outputs in bf16
     yd = nhwc(yref.float()).to(dtype).cuda()
     part2 = torch.zeros(2, nblk, C, device="cuda")
-    lib.call("fb_bn_bwd_reduce", doutd.data_ptr(), yd.data_ptr(), xd.data_ptr(), mean_tab.data_ptr(), invstd.data_ptr(), ch_total, ch_off,
+    # ReLU bitmask (1 byte per 16-byte vector) must encode y > 0; the backward accepts either y or the bitmask
+    vec = 16 // xd.element_size()
+    ybits = ((y.float().reshape(-1, vec) > 0).to(torch.int32) << torch.arange(vec, device="cuda")).sum(1).to(torch.uint8)
+    assert torch.equal(bits, ybits)
+    ref_bits = ((yd.float().reshape(-1, vec) > 0).to(torch.int32) << torch.arange(vec, device="cuda")).sum(1).to(torch.uint8)
+    lib.call("fb_bn_bwd_reduce", doutd.data_ptr(), None, ref_bits.data_ptr(), xd.data_ptr(), mean_tab.data_ptr(), invstd.data_ptr(), ch_total, ch_off,
              part2.data_ptr(), px, C, ppg, lib.dtype_code(dtype))
     gout = torch.zeros(groups, 2 * C + 64, device="cuda")
     coef = torch.zeros(groups, C, 3, device="cuda")
@@ -203,7 +209,7 @@ def test_batchnorm_fwd_bwd(dtype, C, hw, ipg, groups):
              ch_total, ch_off, gout.data_ptr(), gout.data_ptr() + 4 * C, gout.shape[1], coef.data_ptr())
     dx = torch.empty_like(xd)
     dy_out = torch.empty_like(xd)
-    lib.call("fb_bn_bwd_apply", doutd.data_ptr(), yd.data_ptr(), xd.data_ptr(), coef.data_ptr(), dx.data_ptr(), dy_out.data_ptr(), px, C, ppg,
+    lib.call("fb_bn_bwd_apply", doutd.data_ptr(), yd.data_ptr(), None, xd.data_ptr(), coef.data_ptr(), dx.data_ptr(), dy_out.data_ptr(), px, C, ppg,
              lib.dtype_code(dtype))
     assert rel(gout[:, :C].cpu(), torch.stack(dgs)) < 1e-4
     assert rel(gout[:, C:2 * C].cpu(), torch.stack(dbs)) < 1e-4
