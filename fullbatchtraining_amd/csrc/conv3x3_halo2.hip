@@ -56,16 +56,18 @@ __global__ __launch_bounds__(256) void conv3x3s1_halo2_kernel(const Halo2Params 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int L = h2_xcd_remap(blockIdx.x, p.n_blocks);
-    const int ct = L % p.n_ct, pt = L / p.n_ct;
+    // divisions run on the VALU: readfirstlane restores provable uniformity (else every buffer op gets a waterfall loop)
+    const int ct = __builtin_amdgcn_readfirstlane(L % p.n_ct), pt = __builtin_amdgcn_readfirstlane(L / p.n_ct);
     const int tiles_per_img = p.H / TH;
-    const int n = pt / tiles_per_img, y0 = (pt - n * tiles_per_img) * TH;
+    const int n = __builtin_amdgcn_readfirstlane(pt / tiles_per_img), y0 = (pt - n * tiles_per_img) * TH;
+    const int wset = __builtin_amdgcn_readfirstlane(n / p.imgs_per_wset);
     const int row_b = p.Cs * EB;
     const int lrow8 = lane >> 3;                           // row within a 1 KiB group
     const int chunk = (lane & 7) ^ lrow8;                  // logical chunk fetched by this lane (source-side swizzle)
 
     const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.src + (long long)n * p.H * W * row_b), 0, p.H * W * row_b, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.wgt + (long long)(n / p.imgs_per_wset) * p.wset_stride_bytes), 0, p.Cd * 9 * row_b, 0x00020000);
+        (void*)(p.wgt + (long long)wset * p.wset_stride_bytes), 0, p.Cd * 9 * row_b, 0x00020000);
     const unsigned voffW0 = (unsigned)((ct * 64 + wave * 8 + lrow8) * 9 * row_b + chunk * 16);
     const unsigned voffW1 = voffW0 + (unsigned)(32 * 9 * row_b);
 

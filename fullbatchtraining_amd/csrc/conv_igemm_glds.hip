@@ -51,8 +51,11 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(const ConvParams p, 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_co = wave >> 1, wave_px = wave & 1;
+    // block coordinates go through integer divisions (VALU): readfirstlane makes them provably wave-uniform again, otherwise
+    // hipcc wraps every buffer op that depends on them in a waterfall loop (cdna_hip_programming.md T20)
     const int L = xcd_remap1d(blockIdx.x, gridDim.x);
-    const int co_blk = L % n_co, t2 = L / n_co, mblk = t2 % mblocks, cls = t2 / mblocks;
+    const int co_blk = __builtin_amdgcn_readfirstlane(L % n_co), t2 = L / n_co;
+    const int mblk = __builtin_amdgcn_readfirstlane(t2 % mblocks), cls = __builtin_amdgcn_readfirstlane(t2 / mblocks);
     const int cpy = (p.os == 2) ? (cls >> 1) : 0, cpx = (p.os == 2) ? (cls & 1) : 0;
     const int lrow = tid >> 3;
     const int chunk = (tid & 7) ^ (lrow & 7);        // logical chunk this lane fetches (source-side swizzle)
@@ -70,12 +73,12 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(const ConvParams p, 
             a_pix[i] = 0; a_y[i] = -(1 << 28); a_x[i] = 0;
         }
     }
-    const int first_img = (mblk * 128) / qHW;
+    const int wset = __builtin_amdgcn_readfirstlane(((mblk * 128) / qHW) / p.imgs_per_wset);
     const int taps = p.R * p.S;
     const int row_b = p.Cs * EB;                                   // bytes of one pixel / one (co, tap) weight row
     const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.n_img * p.Hs * p.Ws * row_b, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.wgt + (long long)(first_img / p.imgs_per_wset) * p.wset_stride_bytes), 0, p.Cd * taps * row_b, 0x00020000);
+        (void*)(p.wgt + (long long)wset * p.wset_stride_bytes), 0, p.Cd * taps * row_b, 0x00020000);
     unsigned voffW[WROWS];
 #pragma unroll
     for (int i = 0; i < WROWS; ++i) voffW[i] = (unsigned)((co_blk * BN_CO + lrow + 32 * i) * taps * row_b + chunk * 16);

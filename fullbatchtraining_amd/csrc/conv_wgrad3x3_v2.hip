@@ -50,8 +50,8 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Par
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_n = p.Cs / 64;
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
-    const int group = blockIdx.y / p.split_k, split = blockIdx.y % p.split_k;
+    const int tile_m = __builtin_amdgcn_readfirstlane(blockIdx.x / tiles_n), tile_n = __builtin_amdgcn_readfirstlane(blockIdx.x % tiles_n);
+    const int group = __builtin_amdgcn_readfirstlane(blockIdx.y / p.split_k), split = __builtin_amdgcn_readfirstlane(blockIdx.y % p.split_k);
     const int img0 = group * p.imgs_per_group + split * p.imgs_per_block;
     const int img_end = min(img0 + p.imgs_per_block, (group + 1) * p.imgs_per_group);
     const int steps_per_img = p.H / RS;
