@@ -234,12 +234,14 @@ class Engine:
 
     def _choose_split(self, L):
         """Split the pixel reduction of wgrad so that >= ~1000 workgroups exist; slices are multiples of the K-step."""
-        if (L.R == 3 and L.stride == 1 and L.pad == 1 and L.hin == L.win and L.win in (16, 32) and L.cin_pad % 64 == 0
-                and L.cout % 64 == 0):
-            # all-taps halo wgrad kernel: split-K over whole images, split must divide the chunk
+        widths = (4, 8, 16, 32) if self.dt == torch.bfloat16 else (16, 32)
+        if (L.R == 3 and L.stride == 1 and L.pad == 1 and L.hin == L.win and L.win in widths and L.cin_pad % 64 == 0
+                and L.cout % 64 == 0 and not (L.win == 4 and self.chunk % 2)):
+            # all-taps halo wgrad kernel: split-K over whole images, split must divide the chunk (4x4 maps: image pairs)
             tiles = (L.cout // 64) * (L.cin_pad // 64)
             want = max(1, -(-512 // (tiles * self.G)))
-            return max(d for d in range(1, self.chunk + 1) if self.chunk % d == 0 and d <= max(want, 1))
+            unit = 2 if L.win == 4 else 1
+            return max(d for d in range(1, self.chunk + 1) if self.chunk % (d * unit) == 0 and d <= max(want, 1))
         big = L.cin_pad % 128 == 0 and L.cout % 128 == 0 and (L.cin_pad >= 256 or L.cout >= 256)
         tile = 128 if big else 64
         tiles = (L.cout // tile) * max(L.cin_pad // tile, 1) * L.taps

@@ -105,7 +105,9 @@ def test_conv_dgrad(dtype, cin, cout, k, stride, hw, n, amode):
                                                                   (128, 256, 1, 1, 4, 16, 1, 2), (32, 64, 1, 1, 8, 4, 2, 1),
                                                                   (128, 128, 3, 1, 8, 4, 1, 1),
                                                                   (64, 64, 3, 1, 32, 4, 2, 2), (128, 64, 3, 1, 16, 4, 2, 4),   # all-taps halo kernel
-                                                                  (64, 128, 3, 1, 16, 6, 1, 3)])
+                                                                  (64, 128, 3, 1, 16, 6, 1, 3),
+                                                                  (128, 64, 3, 1, 8, 6, 2, 2), (64, 128, 3, 1, 4, 8, 2, 2),    # 8x8 / 4x4 maps
+                                                                  (64, 64, 3, 1, 4, 6, 1, 3), (64, 64, 3, 1, 4, 6, 1, 2)])
 def test_conv_wgrad(dtype, cin, cout, k, stride, hw, ipg, groups, split):
     lib = _lib()
     torch.manual_seed(2)
