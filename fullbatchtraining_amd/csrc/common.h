@@ -81,6 +81,16 @@ template <> __device__ __forceinline__ f32x4_t mma_chunk<float>(const uint4& a, 
     return c;
 }
 
+// Sum over the 16 lanes of a DPP row (lanes 16k..16k+15), result in every lane: four v_add_f32 with row_ror modifiers --
+// no LDS traffic (``__shfl_xor`` lowers to ds_bpermute_b32, which queues behind the fragment reads of the co-resident workgroup).
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
+    return v;
+}
+
 // deterministic block reduction of `NV` values per thread (sum), result valid on thread 0; smem >= NV*nwaves floats
 template <int NV> __device__ __forceinline__ void block_reduce_sum(float (&v)[NV], float* smem) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;

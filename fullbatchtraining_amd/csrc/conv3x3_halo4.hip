@@ -1,0 +1,416 @@
+// 3x3 / stride 1 / pad 1 convolution (forward and input-gradient) from an LDS-resident input halo: persistent workgroups.
+//
+// Tile decomposition: 256 output pixels x 64 output channels per tile; the 256 pixels are contiguous in memory -- 8 full
+// rows of one 32x32 image, one 16x16 image, or four 8x8 images.  Per 128-byte input-channel slice the input halo is staged
+// once in LDS and feeds all nine taps; wave w owns pixels [64w, 64w+64) x 64 channels (16 accumulator fragments).
+//
+// A timeline of the one-tile-per-workgroup version (tools/h4_trace.hip) showed 9 of the 14 us a 64-channel tile lives being
+// spent outside the MFMA loop: ~1000 instructions of address set-up per workgroup, the halo round trip, 128 LDS shuffles for
+// the BN statistics.  Here 2 x #CU workgroups stay resident and walk the tile list:
+//   * all per-lane addresses (halo sources, fragment reads, weight rows) are computed once per workgroup; per tile only
+//     scalar work remains (two buffer descriptors, a scalar offset, the top/bottom-row validity of 32x32 tiles)
+//   * the next tile's first halo slice and its first two weight taps are requested before the epilogue of the current tile,
+//     so their round trip overlaps the output stores and the statistics
+//   * weights stream through a ring of three 8 KiB buffers, two taps ahead (9 taps = 3 ring turns: the buffer of tap U is the
+//     compile-time constant U % 3), `s_waitcnt vmcnt(2)` instead of draining the queue
+//   * zero padding = out-of-range buffer offsets (the DMA writes zeros); XOR swizzle keyed on the halo column (hx & 7), which
+//     makes it independent of the vertical tap: every fragment address is a precomputed lane register + an immediate
+//   * BN partial sums over the 16 pixel lanes with DPP row rotations (no LDS)
+#include "common.h"
+
+#include <type_traits>
+
+struct Halo4Params {
+    const char* src; const char* wgt; char* dst; const char* addend; float* stat;
+    int n_img, H, Cs, Cd, mode;
+    int imgs_per_wset; long long wset_stride_bytes;
+    int addend_mode, n_mblocks, n_ct, n_tiles;
+    unsigned magic_ct, magic_wset;                          // ceil(2^32 / d), 0 for d == 1
+#ifdef FB_H4_TRACE
+    long long* trace;                                       // tools/h4_trace.hip: 8 timestamps per tile
+#endif
+};
+#ifdef FB_H4_TRACE
+#define H4_STAMP(k) do { if (tid == 0) p.trace[(long long)L * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define H4_STAMP(k) do { } while (0)
+#endif
+
+namespace {
+template <int N> __device__ __forceinline__ void h4_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void h4_wait_lgkmcnt() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+typedef __attribute__((ext_vector_type(4))) unsigned h4_u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned h4_u32x2;
+template <int OFF> __device__ __forceinline__ uint4 h4_read16(unsigned byte_addr) {
+    h4_u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(OFF));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+template <int I, int N, typename F> __device__ __forceinline__ void h4_static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); h4_static_for<I + 1, N>(f); }
+}
+__device__ __forceinline__ int h4_xcd_remap(int b, int n) {          // consecutive results live on the same XCD
+    const int q = n >> 3, r = n & 7, xcd = b & 7, slot = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+// halo rows between fragment 0 and fragment j of a wave
+template <int W> constexpr int h4_frag_rows(int j) { return W == 32 ? (j >> 1) * 40 + (j & 1) * 16 : (W == 16 ? j * 18 : j * 2 * 10); }
+__device__ __forceinline__ int h4_div(int n, unsigned magic) { return magic ? (int)__umulhi((unsigned)n, magic) : n; }
+constexpr unsigned H4_OOB = 0x80000000u;
+
+template <int W> struct H4Geo {
+    static constexpr int TH = W >= 16 ? 256 / W : W;              // image rows per image part of the tile
+    static constexpr int IMGS = W >= 16 ? 1 : 256 / (W * W);      // whole images per tile (W = 8: 4)
+    static constexpr int TILES_PER_IMG = W == 32 ? 4 : 1;
+    // 32x32: pitch 40 = five 1 KiB load groups per halo row, so the top/bottom halo rows are whole groups (their validity
+    // depends on the tile's position in the image and is decided per load on the scalar unit)
+    static constexpr int PITCH = W == 32 ? 40 : W + 2;
+    static constexpr int IMG_ROWS = (TH + 2) * PITCH;             // halo rows per image part
+    static constexpr int ROWS = IMGS * IMG_ROWS;                  // 400, 324, 400
+    static constexpr int NGRP = (ROWS + 7) / 8;                   // 1 KiB groups of 8 rows
+};
+
+struct H4Tile { int pt, ct, n0, y0; };                             // wave-uniform description of one tile
+}  // namespace
+
+template <typename T, int W>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3s1_halo4_kernel(const Halo4Params p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using G = H4Geo<W>;
+    constexpr int EB = ET<T>::EB;
+    constexpr int PITCH = G::PITCH, NGRP = G::NGRP;
+    constexpr int HALO_BYTES = NGRP * 1024, WT_BYTES = 64 * 128, NW = 3, RED_BYTES = 4 * 64 * 2 * 4;
+#ifndef FB_H4_LDS_PAD
+#define FB_H4_LDS_PAD 0                                     // tools/h4_trace.hip: pad to force one workgroup per CU
+#endif
+    __shared__ __attribute__((aligned(16))) char lds[HALO_BYTES + NW * WT_BYTES + RED_BYTES + FB_H4_LDS_PAD];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NB = gridDim.x;
+    const int row_b = p.Cs * EB;
+    const int n_cc = row_b / 128;
+    const int lrow8 = lane >> 3;                           // row within a 1 KiB group
+
+    // ---- per-lane constants (once per workgroup) ---------------------------------------------------------------------------
+    const unsigned voffW0 = (unsigned)((wave * 8 + lrow8) * 9 * row_b + (((lane & 7) ^ lrow8) * 16));
+    const unsigned voffW1 = voffW0 + (unsigned)(32 * 9 * row_b);
+    // halo source offsets relative to the tile's origin pixel (row y0-1, column -1 of the first image); rows outside the
+    // image in x (and in y for whole-image tiles) are out of range for good
+    constexpr int KH = (NGRP + 3) / 4;
+    unsigned voffH[KH];
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+        const int row = (wave + 4 * k) * 8 + lrow8;
+        const int img_l = row / G::IMG_ROWS, rr = row - img_l * G::IMG_ROWS;
+        const int hy = rr / PITCH, hx = rr - hy * PITCH;
+        bool ok = row < G::ROWS && hx >= 1 && hx <= W;
+        if constexpr (W != 32) ok = ok && hy >= 1 && hy <= G::TH;
+        voffH[k] = ok ? (unsigned)(((img_l * p.H + hy) * W + hx) * row_b + (((lane & 7) ^ (hx & 7)) * 16)) : H4_OOB;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    // fragment j of a wave = pixels 16j..16j+15 of its 64: the same columns (W = 32: +16, same residue mod 8) a fixed number of
+    // halo rows further down, so only fragment 0 needs registers -- [horizontal variant dx+1][K half]; j and the vertical tap
+    // are instruction immediates
+    unsigned pa[3][2];
+    {
+        const int q = wave * 64 + (lane & 15);
+        const int img_l = q / (G::TH * W), qi = q - img_l * (G::TH * W);
+        const int ty = qi / W, tx = qi % W;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int hrow = img_l * G::IMG_ROWS + ty * PITCH + tx + b;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) pa[b][h] = lds0 + hrow * 128 + ((((lane >> 4) + 4 * h) ^ ((tx + b) & 7)) * 16);
+        }
+    }
+    // output offset of this lane inside a tile: pixel 64*wave + (lane & 15), channels 4*(lane >> 4) .. +3 of a 16-channel fragment
+    const int voffD = ((wave * 64 + (lane & 15)) * p.Cd + (lane >> 4) * 4) * EB;
+    // bf16 output staging in ring buffer 2 (idle between the last tap of a tile and tap 0 of the next), 2 KiB per wave:
+    //   write: fragment lane (pixel t = lane & 15, channels 16 I + 4 g..) -> row t, 16-byte chunk (2 I + g/2) ^ (t & 7), half g & 1
+    //   read : lane -> row lane >> 3 (+8), chunk (lane & 7) ^ row: channels 8 (lane & 7)..+7 of that pixel
+    const unsigned stg = lds0 + HALO_BYTES + 2 * WT_BYTES + wave * 2048;
+    const unsigned stw = stg + (lane & 15) * 128 + ((((lane >> 5) & 1) ^ (lane & 7)) * 16) + ((lane >> 4) & 1) * 8;
+    const unsigned str = stg + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) * 16);
+    const int voffT = ((wave * 64 + (lane >> 3)) * p.Cd + (lane & 7) * 8) * EB;
+    // BN partial sums: writer lanes (lane & 15 == 0) and the 128 reader threads
+    const unsigned red0 = lds0 + HALO_BYTES + NW * WT_BYTES;
+    const unsigned redw = red0 + (wave * 64 + (lane >> 4) * 4) * 8;
+    const unsigned redr = red0 + (((tid >> 6) * 2) * 64 + (tid & 63)) * 8;
+    unsigned wa[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) wa[h] = lds0 + HALO_BYTES + (lane & 15) * 128 + ((((lane >> 4) + 4 * h) ^ (lane & 7)) * 16);
+
+    // ---- tile bookkeeping (scalar; descriptors are rebuilt where they are needed to keep SGPR pressure low) ----------------
+    auto decode = [&](int L) {
+        H4Tile t;
+        t.pt = h4_div(L, p.magic_ct);
+        t.ct = L - t.pt * p.n_ct;
+        if constexpr (W == 32) { t.n0 = t.pt >> 2; t.y0 = (t.pt & 3) * G::TH; }
+        else { t.n0 = t.pt * G::IMGS; t.y0 = 0; }
+        return t;
+    };
+    auto rsrcA_of = [&](const H4Tile& t) {
+        // origin pixel (y0-1, -1): may lie before the tensor for the first tile -- only in-image offsets are ever dereferenced
+        const long long origin = ((long long)(t.n0 * p.H + t.y0 - 1) * W - 1) * row_b;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(p.src + origin), 0, (G::IMGS * p.H * W + 2 * W + 2) * row_b, 0x00020000);
+    };
+    auto rsrcW_of = [&](const H4Tile& t) {
+        const int wset = h4_div(t.n0, p.magic_wset);
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(p.wgt + (long long)wset * p.wset_stride_bytes), 0, p.Cd * 9 * row_b, 0x00020000);
+    };
+    auto halo_issue = [&](const H4Tile& t, int cc) {
+        const __amdgpu_buffer_rsrc_t rA = rsrcA_of(t);
+        const int soff = cc * 128;
+        const bool top = t.y0 == 0, bot = t.y0 + G::TH == p.H;
+        h4_static_for<0, KH>([&](auto kc) {
+            constexpr int K = decltype(kc)::value;
+            const int g = wave + 4 * K;
+            if (g < NGRP) {
+                __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(lds + g * 1024);
+                // 32x32: groups 0..4 = halo row 0 (above the image for the top tile), groups 45..49 = halo row TH+1
+                constexpr bool edge = W == 32 && (4 * K < 5 || 4 * K + 3 >= 5 * (G::TH + 1));
+                bool dead = false;
+                if constexpr (edge) dead = (g < 5 && top) || (g >= 5 * (G::TH + 1) && bot);
+                if (dead) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, dst, 16, H4_OOB, soff, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, dst, 16, voffH[K], soff, 0, 0);
+            }
+        });
+    };
+    auto wt_issue = [&](int buf, const H4Tile& t, int cc, int tap) {
+        const __amdgpu_buffer_rsrc_t rW = rsrcW_of(t);
+        const int soff = t.ct * 64 * 9 * row_b + tap * row_b + cc * 128;
+        char* dst = lds + HALO_BYTES + buf * WT_BYTES + wave * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)dst, 16, voffW0, soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)(dst + 4096), 16, voffW1, soff, 0, 0);
+    };
+    // forward walks the taps 0..8, the input gradient walks the flipped filter 8..0
+    auto tap_of = [&](int u) { return p.mode == 0 ? u : 8 - u; };
+
+    // Static round-robin tile assignment: workgroup v (XCD-grouped id) computes tiles v, v + NB, v + 2 NB, ...  Co-tiles of the
+    // same pixels and neighbouring pixel tiles are adjacent in the tile list, so at any time an XCD's L2 serves one contiguous
+    // window of the input.  (A dynamic scheduler -- per-XCD atomic counters, index drawn two tiles ahead and handed over through
+    // LDS -- was measured: it removes the ~12 % tail imbalance but costs the same in the tap loop; the kernel's throughput is
+    // set by the per-CU load/store pipeline, not by idle workgroups.)
+    int L = h4_xcd_remap(blockIdx.x, NB);
+    if (L >= p.n_tiles) return;
+    H4Tile cur = decode(L);
+    halo_issue(cur, 0);
+    wt_issue(0, cur, 0, tap_of(0));
+    wt_issue(1, cur, 0, tap_of(1));
+
+    while (true) {
+        H4_STAMP(0); H4_STAMP(1);
+#ifdef FB_H4_TRACE
+        if (tid == 0) p.trace[(long long)L * 8 + 6] = clock64();
+#endif
+        const int Ln = L + NB;
+        const bool has_next = Ln < p.n_tiles;
+        H4Tile nxt = cur;
+        if (has_next) nxt = decode(Ln);
+        h4_wait_vmcnt<0>();                                // halo slice 0 + weight taps 0, 1 (and the previous tile's stores)
+        __builtin_amdgcn_s_barrier();
+        H4_STAMP(2);
+
+        f32x4_t acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+        for (int cc = 0; cc < n_cc; ++cc) {
+            const bool more = cc + 1 < n_cc;
+            h4_static_for<0, 9>([&](auto uc) {
+                constexpr int U = decltype(uc)::value, A = U / 3, B = U % 3;
+                constexpr int BUF = U % 3, NBUF = (U + 2) % 3;
+                // weights two taps ahead go into the buffer tap U-1 used (every wave has passed the barrier that ended U-1)
+                bool issued = true;
+                if constexpr (U < 7) wt_issue(NBUF, cur, cc, tap_of(U + 2));
+                else if (more) wt_issue(NBUF, cur, cc + 1, tap_of(U - 7));
+                else if (has_next) wt_issue(NBUF, nxt, 0, tap_of(U - 7));
+                else issued = false;
+                uint4 wf0[4], pf0[4], wf1[4], pf1[4];
+                h4_static_for<0, 4>([&](auto i) { wf0[decltype(i)::value] = h4_read16<decltype(i)::value * 2048 + BUF * WT_BYTES>(wa[0]); });
+                h4_static_for<0, 4>([&](auto j) { pf0[decltype(j)::value] = h4_read16<(A * PITCH + h4_frag_rows<W>(decltype(j)::value)) * 128>(pa[B][0]); });
+                h4_static_for<0, 4>([&](auto i) { wf1[decltype(i)::value] = h4_read16<decltype(i)::value * 2048 + BUF * WT_BYTES>(wa[1]); });
+                h4_static_for<0, 4>([&](auto j) { pf1[decltype(j)::value] = h4_read16<(A * PITCH + h4_frag_rows<W>(decltype(j)::value)) * 128>(pa[B][1]); });
+                h4_wait_lgkmcnt<8>();
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = mma_chunk<T>(wf0[i], pf0[j], acc[i][j]);
+                h4_wait_lgkmcnt<0>();
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = mma_chunk<T>(wf1[i], pf1[j], acc[i][j]);
+                if constexpr (U == 8) {
+                    __builtin_amdgcn_s_barrier();         // every wave is done with this halo slice
+                    if (more) {
+                        halo_issue(cur, cc + 1);
+                        h4_wait_vmcnt<0>();
+                        __builtin_amdgcn_s_barrier();
+                    } else if (has_next) {
+                        halo_issue(nxt, 0);               // lands during the epilogue; the loop top waits for it
+                    }
+                } else {
+                    if (issued) h4_wait_vmcnt<2>();       // the weights of the next tap have landed; two loads stay in flight
+                    else h4_wait_vmcnt<0>();
+                    __builtin_amdgcn_s_barrier();
+                }
+            });
+        }
+        H4_STAMP(3);
+
+        // ---- epilogue ------------------------------------------------------------------------------------------------------
+        // outputs (and the same-shape addend) are addressed as  tile base (descriptor) + lane offset (one register, tile
+        // invariant) + scalar/immediate offsets of the fragment: no 64-bit address arithmetic on the vector unit
+        const __amdgpu_buffer_rsrc_t rsrcD = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dst + (long long)cur.pt * 256 * p.Cd * EB), 0,
+                                                                                256 * p.Cd * EB, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrcE = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.addend_mode == 1 ? p.addend + (long long)cur.pt * 256 * p.Cd * EB : p.dst), 0, p.addend_mode == 1 ? 256 * p.Cd * EB : 0, 0x00020000);
+        float ssum[4][4], ssq[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { ssum[i][r] = 0.f; ssq[i][r] = 0.f; }
+        h4_static_for<0, 4>([&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            const int soff = (J * 16 * p.Cd + cur.ct * 64) * EB;
+            h4_static_for<0, 4>([&](auto ic) {
+                constexpr int I = decltype(ic)::value;
+                float v[4] = {acc[I][J][0], acc[I][J][1], acc[I][J][2], acc[I][J][3]};
+                if (p.addend_mode == 1) {
+                    if constexpr (EB == 4) {
+                        const h4_u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrcE, voffD + I * 16 * EB, soff, 0);
+                        v[0] += __uint_as_float(a[0]); v[1] += __uint_as_float(a[1]); v[2] += __uint_as_float(a[2]); v[3] += __uint_as_float(a[3]);
+                    } else {
+                        const h4_u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(rsrcE, voffD + I * 16 * EB, soff, 0);
+                        v[0] += __uint_as_float(a[0] << 16); v[1] += __uint_as_float(a[0] & 0xffff0000u);
+                        v[2] += __uint_as_float(a[1] << 16); v[3] += __uint_as_float(a[1] & 0xffff0000u);
+                    }
+                } else if (p.addend_mode == 2) {               // 2x2-average-pooled addend, broadcast back (0.25 each)
+                    const int q = wave * 64 + J * 16 + (lane & 15);
+                    const int img_l = q / (G::TH * W), qi = q - img_l * (G::TH * W);
+                    const int oy = cur.y0 + qi / W, ox = qi % W;
+                    const long long apix = ((long long)(cur.n0 + img_l) * (p.H >> 1) + (oy >> 1)) * (W >> 1) + (ox >> 1);
+                    const char* ap = p.addend + (apix * p.Cd + cur.ct * 64 + I * 16 + (lane >> 4) * 4) * EB;
+                    if constexpr (EB == 4) { const float4 a = *(const float4*)ap; v[0] += 0.25f * a.x; v[1] += 0.25f * a.y; v[2] += 0.25f * a.z; v[3] += 0.25f * a.w; }
+                    else { const uint2 a = *(const uint2*)ap; v[0] += 0.25f * __uint_as_float(a.x << 16); v[1] += 0.25f * __uint_as_float(a.x & 0xffff0000u);
+                           v[2] += 0.25f * __uint_as_float(a.y << 16); v[3] += 0.25f * __uint_as_float(a.y & 0xffff0000u); }
+                }
+                if constexpr (EB == 4) {
+                    __builtin_amdgcn_raw_buffer_store_b128((h4_u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
+                                                           rsrcD, voffD + I * 16 * EB, soff, 0);
+                } else {
+                    // bf16: through the wave's 2 KiB staging slot ([16 pixels][64 channels], 16-byte chunks XOR-swizzled by the
+                    // pixel) so that the global stores are 16 bytes per lane and cover whole 128-byte lines (8 instead of 16
+                    // store instructions per wave; the store tail is issue-bound)
+                    const h4_u32x2 d = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    const unsigned wr = stw ^ (unsigned)(I * 32);
+                    asm volatile("ds_write_b64 %0, %1" ::"v"(wr), "v"(d) : "memory");
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ssum[I][r] += v[r]; ssq[I][r] += v[r] * v[r]; }
+            });
+            if constexpr (EB == 2) {
+                const uint4 lo = h4_read16<0>(str), hi = h4_read16<1024>(str);
+                h4_wait_lgkmcnt<0>();
+                __builtin_amdgcn_raw_buffer_store_b128((h4_u32x4){lo.x, lo.y, lo.z, lo.w}, rsrcD, voffT, soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b128((h4_u32x4){hi.x, hi.y, hi.z, hi.w}, rsrcD, voffT, soff + 8 * p.Cd * EB, 0);
+            }
+        });
+        H4_STAMP(4);
+        if (p.stat != nullptr) {
+            // [4 waves][64 co]{sum, sumsq} in its own LDS region (the halo is being refilled); inline-asm LDS ops: the compiler
+            // would drain the in-flight LDS-DMA of the next tile before any LDS access it can see
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ssum[i][r] = row16_sum(ssum[i][r]); ssq[i][r] = row16_sum(ssq[i][r]); }
+            if ((lane & 15) == 0) {
+                h4_static_for<0, 16>([&](auto c) {
+                    constexpr int I = decltype(c)::value / 4, R = decltype(c)::value % 4;
+                    const f32x2_t d = {ssum[I][R], ssq[I][R]};
+                    const unsigned wr = redw;             // (a plain use: asm operands alone do not capture in a nested lambda)
+                    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(wr), "v"(d), "n"((I * 16 + R) * 8) : "memory");
+                });
+            }
+            h4_wait_lgkmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (tid < 128) {
+                const int half = tid >> 6, col = tid & 63;
+                f32x2_t x, y;
+                asm volatile("ds_read_b64 %0, %1" : "=v"(x) : "v"(redr));
+                asm volatile("ds_read_b64 %0, %1 offset:512" : "=v"(y) : "v"(redr));
+                h4_wait_lgkmcnt<0>();
+                const long long blk = 2LL * cur.pt + half;
+                p.stat[blk * p.Cd + cur.ct * 64 + col] = x[0] + y[0];
+                p.stat[((long long)p.n_mblocks + blk) * p.Cd + cur.ct * 64 + col] = x[1] + y[1];
+            }
+        }
+        H4_STAMP(5);
+#ifdef FB_H4_TRACE
+        if (tid == 0) p.trace[(long long)L * 8 + 7] = clock64();
+#endif
+        if (!has_next) break;
+        cur = nxt;
+        L = Ln;
+    }
+#endif
+}
+
+static unsigned h4_magic(int d) { return d <= 1 ? 0u : (unsigned)(((1ULL << 32) + (unsigned)d - 1) / (unsigned)d); }
+
+// returns 1 if the kernel handled the call
+int fb_try_conv3x3_halo4(const fb_conv_args* a, hipStream_t st) {
+    static const bool disabled = getenv("FB_DISABLE_HALO4") != nullptr;
+    if (disabled) return 0;
+    if (a->R != 3 || a->S != 3 || a->stride != 1 || a->pad != 1) return 0;
+    if (a->Hs != a->Hd || a->Ws != a->Wd || a->Hs != a->Ws) return 0;
+    const int W = a->Ws;
+    if (W != 32 && W != 16 && W != 8) return 0;
+    const int EB = a->dtype == FB_F32 ? 4 : 2;
+    if (a->Cs * EB % 128 != 0 || a->Cd % 64 != 0) return 0;
+    const int imgs_per_wset = a->imgs_per_wset > 0 ? a->imgs_per_wset : a->n_img;
+    if (W == 8 && (a->n_img % 4 != 0 || imgs_per_wset % 4 != 0)) return 0;
+    if ((long long)(4 * a->Hs * W + 2 * W + 2) * a->Cs * EB >= (1LL << 31)) return 0;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+            n_cu = 256;
+    }
+    Halo4Params p;
+    p.src = (const char*)a->src; p.wgt = (const char*)a->wgt; p.dst = (char*)a->dst; p.addend = (const char*)a->addend;
+    p.stat = a->stat_partial;
+    p.n_img = a->n_img; p.H = a->Hs; p.Cs = a->Cs; p.Cd = a->Cd; p.mode = a->mode;
+    p.imgs_per_wset = imgs_per_wset;
+    p.wset_stride_bytes = a->wset_stride * EB;
+    p.addend_mode = a->addend ? a->addend_mode : 0;
+    const int n_pt = a->n_img * a->Hs * W / 256;
+    p.n_mblocks = n_pt * 2;
+    p.n_ct = a->Cd / 64;
+    p.n_tiles = n_pt * p.n_ct;
+    if ((long long)p.n_tiles * p.n_ct >= (1LL << 32) || (long long)a->n_img * imgs_per_wset >= (1LL << 32)) return 0;
+    p.magic_ct = h4_magic(p.n_ct);
+    p.magic_wset = h4_magic(imgs_per_wset);
+#ifdef FB_H4_TRACE
+    extern long long* g_h4_trace;
+    p.trace = g_h4_trace;
+#endif
+    dim3 grid(p.n_tiles < 2 * n_cu ? p.n_tiles : 2 * n_cu);
+    if (a->dtype == FB_F32) {
+        if (W == 32) hipLaunchKernelGGL((conv3x3s1_halo4_kernel<float, 32>), grid, dim3(256), 0, st, p);
+        else if (W == 16) hipLaunchKernelGGL((conv3x3s1_halo4_kernel<float, 16>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv3x3s1_halo4_kernel<float, 8>), grid, dim3(256), 0, st, p);
+    } else {
+        if (W == 32) hipLaunchKernelGGL((conv3x3s1_halo4_kernel<bf16_tag, 32>), grid, dim3(256), 0, st, p);
+        else if (W == 16) hipLaunchKernelGGL((conv3x3s1_halo4_kernel<bf16_tag, 16>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv3x3s1_halo4_kernel<bf16_tag, 8>), grid, dim3(256), 0, st, p);
+    }
+    return 1;
+}

@@ -175,8 +175,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float a = ssum[i][r], b = ssq[i][r];
-#pragma unroll
-                for (int off = 1; off < 16; off <<= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+                a = row16_sum(a); b = row16_sum(b);
                 if ((lane & 15) == 0) {
                     const int col = wave_co * (BN_CO / 2) + i * 16 + (lane >> 4) * 4 + r;
                     red[(wave_px * BN_CO + col) * 2] = a; red[(wave_px * BN_CO + col) * 2 + 1] = b;
@@ -193,8 +192,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
 }
 
-int fb_try_conv3x3_halo(const fb_conv_args* a, hipStream_t st);    // conv3x3_halo.hip
-int fb_try_conv3x3_halo2(const fb_conv_args* a, hipStream_t st);   // conv3x3_halo2.hip
+int fb_try_conv3x3_halo4(const fb_conv_args* a, hipStream_t st);   // conv3x3_halo4.hip
 
 template <typename T> static int launch_conv(const ConvParams& p, int classes, hipStream_t st) {
     const int mblocks = (p.M + 127) / 128;
@@ -245,7 +243,7 @@ extern "C" int fb_conv2d(const fb_conv_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int prof = fb_prof_begin(a->mode == 0 ? FB_PROF_IGEMM_FWD : FB_PROF_IGEMM_DGRAD, st);
     static const bool v1 = getenv("FB_IGEMM_V1") != nullptr;
-    if (!fb_try_conv3x3_halo2(a, st) && !fb_try_conv3x3_halo(a, st)) {
+    if (!fb_try_conv3x3_halo4(a, st)) {
         p.zeros = nullptr;
         if (v1 || !fb_launch_igemm_glds(p, classes, a->dtype, st)) {
             if (a->dtype == FB_F32) launch_conv<float>(p, classes, st); else launch_conv<bf16_tag>(p, classes, st);

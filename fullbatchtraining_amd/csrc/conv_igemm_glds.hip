@@ -217,8 +217,7 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(const ConvParams p, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float a = ssum[i][r], b = ssq[i][r];
-#pragma unroll
-                for (int off = 1; off < 16; off <<= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+                a = row16_sum(a); b = row16_sum(b);
                 if ((lane & 15) == 0) {
                     const int col = wave_co * (BN_CO / 2) + i * 16 + (lane >> 4) * 4 + r;
                     red[(wave_px * BN_CO + col) * 2] = a; red[(wave_px * BN_CO + col) * 2 + 1] = b;

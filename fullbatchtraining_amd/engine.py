@@ -12,6 +12,7 @@ gradients ``g[G][P]`` (+ a second/third set and per-chunk perturbed parameters f
 with conv weights in KRSC order ``[Cout][R*S][Cin]``; NHWC activations in the compute dtype (bf16 or f32).
 """
 import math
+import os
 
 import torch
 
@@ -133,7 +134,8 @@ def stem_patches(x_nchw, layer, dtype):
 
 
 class _Pool:
-    """Stream-ordered scratch reuse keyed by element count."""
+    """Stream-ordered scratch reuse keyed by element count.  A buffer may be returned together with an event of another
+    stream that still reads it (the weight-gradient stream): the next user waits for that event before writing."""
 
     def __init__(self, device, dtype):
         self.device, self.dtype, self.free = device, dtype, {}
@@ -142,13 +144,16 @@ class _Pool:
         numel = math.prod(shape)
         lst = self.free.get(numel)
         if lst:
-            return lst.pop().view(shape)
+            t, ev = lst.pop(0)                       # oldest first: its reader has most likely finished
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+            return t.view(shape)
         return torch.empty(shape, device=self.device, dtype=self.dtype)
 
-    def put(self, *tensors):
+    def put(self, *tensors, event=None):
         for t in tensors:
             if t is not None:
-                self.free.setdefault(t.numel(), []).append(t)
+                self.free.setdefault(t.numel(), []).append((t, event))
 
 
 class Engine:
@@ -197,6 +202,10 @@ class Engine:
         self.norms2 = torch.zeros(2, **f32)
         self.pool = _Pool(self.device, self.dt)
         self.masks = {}
+        # weight gradients depend on nothing downstream in the backward chain: they run on their own stream, overlapping the
+        # HBM-bound BN backward kernels and the dgrad convolutions of the main stream (FB_WGRAD_STREAM=0: same stream)
+        self.wstream = torch.cuda.Stream(device=self.device) if os.environ.get("FB_WGRAD_STREAM", "1") != "0" else None
+        self._wgrad_event = None
         self.load_from_model(model)
 
     # ------------------------------------------------------------------------------------------------------ buffers --
@@ -442,12 +451,23 @@ class Engine:
         return dx, dy
 
     def _wgrad(self, L, src, dx, G, gout):
+        """Weight gradient of layer L into gout[g] (per chunk).  Runs on the weight-gradient stream; the event of its completion
+        is kept in ``self._wgrad_event`` (callers hand it to the pool with ``dx`` and wait for it at the end of backward)."""
         n = G * self.chunk
         a = lib.WgradArgs(src.data_ptr(), dx.data_ptr(), self.slab_ws.data_ptr(), n, L.hin, L.win, L.cin_pad, L.hout, L.wout, L.cout,
                           L.R, L.S, L.stride, L.pad, self.chunk, L.split_k, self.dtc)
-        call("fb_conv2d_wgrad", lib.C.byref(a))
-        call("fb_wgrad_reduce", self.slab_ws.data_ptr(), gout.data_ptr() + 4 * L.w_off, self.plan.P, G, L.split_k, L.cout, L.taps,
-             L.cin_pad, L.cin_real)
+        if self.wstream is None:
+            call("fb_conv2d_wgrad", lib.C.byref(a))
+            call("fb_wgrad_reduce", self.slab_ws.data_ptr(), gout.data_ptr() + 4 * L.w_off, self.plan.P, G, L.split_k, L.cout, L.taps,
+                 L.cin_pad, L.cin_real)
+            return
+        ready = torch.cuda.current_stream().record_event()
+        with torch.cuda.stream(self.wstream):
+            self.wstream.wait_event(ready)
+            call("fb_conv2d_wgrad", lib.C.byref(a))
+            call("fb_wgrad_reduce", self.slab_ws.data_ptr(), gout.data_ptr() + 4 * L.w_off, self.plan.P, G, L.split_k, L.cout, L.taps,
+                 L.cin_pad, L.cin_real)
+            self._wgrad_event = self.wstream.record_event()
 
     def _dgrad(self, L, dx, G, wsets, addend=None, addend_mode=0):
         n = G * self.chunk
@@ -481,9 +501,10 @@ class Engine:
             for i in range(len(b.convs) - 1, -1, -1):
                 L = b.convs[i]
                 self._wgrad(L, srcs[i], cur_dx, G, gout)
+                ev_cur = self._wgrad_event
                 if i > 0:
                     d_mid = self._dgrad(L, cur_dx, G, wsets)
-                    pool.put(cur_dx)
+                    pool.put(cur_dx, event=ev_cur)
                     cur_dx, _ = self._bn_bwd(b.convs[i - 1], d_mid, b.mids[i - 1], G, gout, pidx, want_dy=False)
                     pool.put(d_mid)
             first = b.convs[0]
@@ -493,12 +514,13 @@ class Engine:
                 src = b.pooled if b.pooled is not None else a0
                 self._wgrad(S, src, dxs, G, gout)
                 d_p = self._dgrad(S, dxs, G, wsets)
-                pool.put(dxs)
+                pool.put(dxs, event=self._wgrad_event)
                 d = self._dgrad(first, cur_dx, G, wsets, addend=d_p, addend_mode=2 if b.pooled is not None else 1)
                 pool.put(d_p)
             else:
                 d = self._dgrad(first, cur_dx, G, wsets, addend=dy, addend_mode=1)
-            pool.put(cur_dx, dy)
+            pool.put(cur_dx, event=ev_cur)
+            pool.put(dy)
         S = plan.stem
         if plan.stem_pool:
             d_r = pool.get((n, S.hout, S.wout, 64))
@@ -508,7 +530,9 @@ class Engine:
         dx, _ = self._bn_bwd(S, d, self.stem_out, G, gout, pidx, want_dy=False)
         pool.put(d)
         self._wgrad(S, patches, dx, G, gout)
-        pool.put(dx)
+        pool.put(dx, event=self._wgrad_event)
+        if self.wstream is not None:                     # gout is complete (and the activations are free) after this point
+            torch.cuda.current_stream().wait_stream(self.wstream)
 
     # ------------------------------------------------------------------------------------------- chunk-group gradient --
     def group_gradient(self, patches, labels, G, gout, wsets=1, theta=None, pidx=0):

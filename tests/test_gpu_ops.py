@@ -46,7 +46,9 @@ def krsc(w):  # [co, ci, kh, kw] -> [co, kh*kw, ci]
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cin,cout,k,stride,hw,n", [(64, 64, 3, 1, 8, 8), (64, 128, 3, 2, 8, 8), (128, 256, 1, 1, 4, 16),
                                                    (32, 64, 1, 1, 8, 4), (256, 256, 3, 1, 4, 32), (96, 64, 3, 1, 6, 3),
-                                                   (64, 64, 3, 1, 32, 2), (128, 128, 3, 1, 16, 3), (64, 128, 3, 1, 16, 2)])  # last 3: LDS-halo kernel
+                                                   (64, 64, 3, 1, 32, 2), (128, 128, 3, 1, 16, 3), (64, 128, 3, 1, 16, 2),   # LDS-halo kernel
+                                                   (256, 128, 3, 1, 8, 4), (128, 64, 3, 1, 8, 12), (192, 64, 3, 1, 32, 1),
+                                                   (64, 64, 3, 1, 8, 2400), (64, 128, 3, 1, 16, 300), (64, 64, 3, 1, 32, 160)])   # > 2 tiles per persistent workgroup
 def test_conv_fwd_and_stats(dtype, cin, cout, k, stride, hw, n):
     lib = _lib()
     torch.manual_seed(0)
@@ -71,7 +73,9 @@ def test_conv_fwd_and_stats(dtype, cin, cout, k, stride, hw, n):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cin,cout,k,stride,hw,n,amode", [(64, 64, 3, 1, 8, 8, 0), (64, 128, 3, 2, 8, 8, 2), (128, 64, 1, 1, 4, 16, 1),
                                                           (64, 64, 3, 1, 8, 4, 1), (256, 128, 3, 2, 8, 4, 0),
-                                                          (64, 64, 3, 1, 32, 2, 1), (128, 64, 3, 1, 16, 2, 0), (64, 64, 3, 1, 16, 2, 2)])  # halo kernel
+                                                          (64, 64, 3, 1, 32, 2, 1), (128, 64, 3, 1, 16, 2, 0), (64, 64, 3, 1, 16, 2, 2),  # halo kernel
+                                                          (128, 256, 3, 1, 8, 8, 1), (128, 64, 3, 1, 8, 4, 2), (256, 256, 3, 1, 8, 4, 0),
+                                                          (64, 64, 3, 1, 32, 136, 1), (128, 64, 3, 1, 16, 600, 0)])   # persistent workgroups, several tiles each
 def test_conv_dgrad(dtype, cin, cout, k, stride, hw, n, amode):
     lib = _lib()
     torch.manual_seed(1)

@@ -61,7 +61,10 @@ def test_two_rank_run_equals_single_process(tmp_path, grad_reg):
         for key in ("train_loss", "train_acc", "param_norm", "grad_norm", "full_loss", "preclip_gradnorm", "clipped_step"):
             assert np.allclose(got["stats"][key], ref["stats"][key], rtol=2e-4 if not grad_reg else 5e-3, atol=1e-6), (key, got["stats"][key], ref["stats"][key])
         for k in range(7):
-            assert np.allclose(got["stats"][f"grad_norm_train_{k}"], ref["stats"][f"grad_norm_train_{k}"], rtol=1e-4 if not grad_reg else 5e-3)
+            # steps 1-2 agree to the bit; from step 3 on the parameters differ in the last bits (the ranks sum the full-batch
+            # gradient in a different order) and a chunk gradient amplifies that to ~1e-4 (fp32 noise floor, cf. test_gpu_training)
+            assert np.allclose(got["stats"][f"grad_norm_train_{k}"], ref["stats"][f"grad_norm_train_{k}"], rtol=1e-3 if not grad_reg else 5e-3), (
+                k, got["stats"][f"grad_norm_train_{k}"], ref["stats"][f"grad_norm_train_{k}"])
         for name, t in ref["state"].items():
             if t.is_floating_point():
                 # running means of zero-mean conv outputs are ~1e-3 with an fp32 noise floor of ~1e-4 (cf. test_gpu_training)

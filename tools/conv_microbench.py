@@ -7,6 +7,7 @@ from fullbatchtraining_amd import lib
 CASES = {  # name: (cin, cout, k, stride, hw, n_img)
     "l1": (64, 64, 3, 1, 32, 1664), "l2": (128, 128, 3, 1, 16, 1664), "l3": (256, 256, 3, 1, 8, 1664), "l4": (512, 512, 3, 1, 4, 1664),
     "l2s": (64, 128, 3, 2, 32, 1664), "stem": (32, 64, 1, 1, 32, 1664),
+    "l1big": (64, 64, 3, 1, 32, 3840), "l2big": (128, 128, 3, 1, 16, 3840), "l3big": (256, 256, 3, 1, 8, 3840), "l4big": (512, 512, 3, 1, 4, 3840),
 }
 
 
