@@ -17,6 +17,7 @@ struct WgradParams {
     int n_img, Hs, Ws, Cs, Hd, Wd, Cd;
     int R, S, stride, pad;
     int imgs_per_group, split_k, px_per_group, px_per_split;
+    long long group_stride;                                 // floats between the slabs of consecutive groups
 };
 
 template <typename T> struct WG;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 
     // ---- output: [group][split][co][tap][ci] -------------------------------------------------------------------------
     const int taps = p.R * p.S;
-    float* out = p.out + ((long long)(group * p.split_k + split) * p.Cd) * taps * p.Cs;
+    float* out = p.out + group * p.group_stride + ((long long)split * p.Cd) * taps * p.Cs;
     if constexpr (WK > 1) {
         constexpr int WN_ = 16 * NJ;
         float* red = (float*)lds;   // [WK][64][16*NJ]
@@ -182,6 +183,7 @@ extern "C" int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream) {
     p.n_img = a->n_img; p.Hs = a->Hs; p.Ws = a->Ws; p.Cs = a->Cs; p.Hd = a->Hd; p.Wd = a->Wd; p.Cd = a->Cd;
     p.R = a->R; p.S = a->S; p.stride = a->stride; p.pad = a->pad;
     p.imgs_per_group = a->imgs_per_group; p.split_k = a->split_k;
+    p.group_stride = a->group_stride ? a->group_stride : (long long)a->split_k * a->Cd * a->R * a->S * a->Cs;
     p.px_per_group = a->imgs_per_group * a->Hd * a->Wd;
     const int n_groups = a->n_img / a->imgs_per_group;
     hipStream_t st = (hipStream_t)stream;

@@ -15,6 +15,7 @@ struct Wgrad3Params {
     const char* x; const char* dy; float* out;
     int n_img, H, Cs, Cd;
     int imgs_per_group, imgs_per_block, split_k;
+    long long group_stride;
 };
 
 template <typename T> struct W3 { };
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p
         }
     }
 
-    float* out = p.out + ((long long)(group * p.split_k + split) * p.Cd) * 9 * p.Cs;
+    float* out = p.out + group * p.group_stride + ((long long)split * p.Cd) * 9 * p.Cs;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -187,6 +188,7 @@ int fb_try_wgrad3x3(const fb_wgrad_args* a, hipStream_t st) {
     if (a->imgs_per_group % a->split_k != 0) return 0;
     Wgrad3Params p;
     p.x = (const char*)a->x; p.dy = (const char*)a->dy; p.out = a->dw_partial;
+    p.group_stride = a->group_stride ? a->group_stride : (long long)a->split_k * a->Cd * 9 * a->Cs;
     p.n_img = a->n_img; p.H = a->Hs; p.Cs = a->Cs; p.Cd = a->Cd;
     p.imgs_per_group = a->imgs_per_group; p.split_k = a->split_k; p.imgs_per_block = a->imgs_per_group / a->split_k;
     const int n_groups = a->n_img / a->imgs_per_group;

@@ -1,6 +1,6 @@
-// Weight gradient of 3x3 / stride 1 / pad 1 convolutions, bf16, all nine taps from one LDS-resident input halo.
+// Weight gradient of 3x3 / pad 1 convolutions of stride 1 and 2, bf16, all nine taps from one LDS-resident input halo.
 //
-//   dW[co][tap][ci] = sum_p dY[p][co] * X[p shifted by tap][ci]          (feature maps 32x32, 16x16, 8x8, 4x4)
+//   dW[co][tap][ci] = sum_p dY[p][co] * X[stride*p + tap - 1][ci]     (output maps 32x32 .. 4x4; stride 2: 16x16 .. 4x4)
 //
 // One workgroup owns a 64(co) x 64(ci) x 9(tap) output block and a slice of whole images of one chunk (split-K over images).
 // Wave w accumulates ci block [16w,16w+16) x 9 taps x 64 co (36 fragments = 144 accumulator registers).  Per K-step
@@ -12,6 +12,10 @@
 //   * the halo row pitch (48 / 32 / 16 / 16 rows for W = 32 / 16 / 8 / 4) is a multiple of 16, which keeps bits 1 and 3 of the
 //     row index independent of the vertical tap and of the 32-pixel block: every ds_read_b64_tr_b16 address is one of a few
 //     precomputed lane registers + an immediate -- no address arithmetic in the loop
+//   * stride 2: the K-step is 32 output pixels; the halo holds the 2 RS + 1 input rows they touch, a transposed read walks
+//     every second halo row (slot swizzle (row>>1)&3, pitch a multiple of 8 rows; same-parity rows share a 128-byte bank
+//     half, so these reads are 2-way conflicted -- LDS is far from being the limit here).  Before this path the stride-2
+//     layers ran one workgroup per tap and re-read dY nine times (156 TF/s on the 64->128 layer)
 // Output: fp32 slabs [group][split][co][tap][ci] (same layout as conv_wgrad.hip), reduced in fixed order by fb_wgrad_reduce.
 #include "common.h"
 
@@ -21,6 +25,7 @@ struct Wgrad3V2Params {
     const char* x; const char* dy; float* out;
     int n_img, H, Cs, Cd;
     int imgs_per_group, imgs_per_block, split_k;
+    long long group_stride;
 };
 
 namespace {
@@ -42,12 +47,15 @@ __device__ __forceinline__ uint4 w3_join(w3_u32x2 lo, w3_u32x2 hi) { return make
 __device__ __forceinline__ int w3_f(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
 constexpr unsigned W3_OOB = 0x80000000u;
 
-// Geometry of one K-step for feature-map width W.
-//   W = 32: 2 image rows per step, W = 16: 4 image rows, W = 8: one whole image, W = 4: two whole images (32 pixels)
-template <int W> struct W3Geo {
+// Geometry of one K-step for OUTPUT feature-map width W and stride SD.
+//   stride 1: W = 32: 2 image rows per step, W = 16: 4 image rows, W = 8: one whole image, W = 4: two whole images (32 pixels)
+//   stride 2: 32 output pixels per step -- W = 16: 2 output rows (5 input rows), W = 8: 4 output rows (9 input rows, half an
+//             image), W = 4: two whole images (9 input rows each)
+template <int W, int SD> struct W3Geo;
+template <int W> struct W3Geo<W, 1> {
     static constexpr int KPX = W == 4 ? 32 : 64;                               // output pixels per step
     static constexpr int PITCH = W == 32 ? 48 : (W == 16 ? 32 : 16);           // halo row pitch (multiple of 16)
-    static constexpr int RS = W >= 16 ? 64 / W : W;                            // image rows covered by a step (per image)
+    static constexpr int RS = W >= 16 ? 64 / W : W;                            // output rows covered by a step (per image)
     static constexpr int IMGS = W == 4 ? 2 : 1;                                // whole images per step (W <= 8)
     static constexpr int IMG_ROWS = (RS + 2) * PITCH;                          // halo rows of one image part
     static constexpr int HROWS = IMGS * IMG_ROWS;                              // 192, 192, 160, 192
@@ -60,13 +68,32 @@ template <int W> struct W3Geo {
     }
     // rows added by 32-pixel block BLK and vertical tap index R: the immediate part, a multiple of 16 rows
     static constexpr int blk_rows(int BLK, int R) { return ((BLK * 32) / W + R) * PITCH; }
+    __device__ static __forceinline__ int fB(int row) { return w3_f(row); }
+};
+template <int W> struct W3Geo<W, 2> {
+    static constexpr int KPX = 32;
+    static constexpr int PITCH = W == 16 ? 40 : (W == 8 ? 24 : 16);            // >= 2W + 1 columns, multiple of 8
+    static constexpr int RS = W == 16 ? 2 : 4;
+    static constexpr int IMGS = W == 4 ? 2 : 1;
+    static constexpr int IMG_ROWS = (2 * RS + 1) * PITCH;
+    static constexpr int HROWS = IMGS * IMG_ROWS;                              // 200, 216, 288
+    static constexpr int HI_DELTA = W == 4 ? 2 * PITCH : 8;                    // output pixel +4 = next output row (W = 4) / 8 columns
+    static constexpr bool WHOLE = W == 4;
+    __device__ static __forceinline__ int lane_row(int pl, int s) {
+        if constexpr (W == 4) return (pl / 16) * IMG_ROWS + 2 * ((pl % 16) / 4) * PITCH + 2 * (pl % 4) + s;
+        else return 2 * (pl / W) * PITCH + 2 * (pl % W) + s;
+    }
+    static constexpr int blk_rows(int, int R) { return R * PITCH; }
+    __device__ static __forceinline__ int fB(int row) { return (row >> 1) & 3; }
 };
 }  // namespace
 
-template <int W>
+template <int W, int SD>
 __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    using G = W3Geo<W>;
+    using G = W3Geo<W, SD>;
+    constexpr int WI = SD * W;                          // input width; p.H is the OUTPUT height
+    const int Hi = SD * p.H;
     constexpr int KPX = G::KPX, PITCH = G::PITCH, HROWS = G::HROWS;
     constexpr int A_BYTES = KPX * 128, B_BYTES = HROWS * 128, STAGE = A_BYTES + B_BYTES;
     constexpr int NGA = KPX / 8, NGB = HROWS / 8;      // 1 KiB row groups of the dY tile / of the halo
@@ -86,7 +113,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Par
     const int lrow8 = lane >> 3;
 
     const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.n_img * p.H * W * rowA_b, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.n_img * p.H * W * rowB_b, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.n_img * Hi * WI * rowB_b, 0x00020000);
     // per-lane source offsets relative to the first pixel of the step; source-side slot swizzle
     unsigned voffA[KA];
 #pragma unroll
@@ -101,13 +128,13 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Par
         const int row = (wave + 4 * k) * 8 + lrow8;                          // halo row index
         const int img_l = row / G::IMG_ROWS, rr = row - img_l * G::IMG_ROWS;
         const int hy = rr / PITCH, hx = rr - hy * PITCH;
-        const int lslot = ((lane & 7) >> 1) ^ w3_f(row);
-        const bool xok = hx >= 1 && hx <= W && (wave + 4 * k) < NGB;
-        const unsigned base = (unsigned)((img_l * p.H * W + (hx - 1)) * rowB_b + tile_n * 128 + lslot * 32 + (lane & 1) * 16);
+        const int lslot = ((lane & 7) >> 1) ^ G::fB(row);
+        const bool xok = hx >= 1 && hx <= WI && (wave + 4 * k) < NGB;
+        const unsigned base = (unsigned)((img_l * Hi * WI + (hx - 1)) * rowB_b + tile_n * 128 + lslot * 32 + (lane & 1) * 16);
         if constexpr (G::WHOLE) {
             const int sy = hy - 1;
             hyB[k] = 0;
-            voffB[k] = (xok && sy >= 0 && sy < W) ? base + (unsigned)(sy * W * rowB_b) : W3_OOB;
+            voffB[k] = (xok && sy >= 0 && sy < WI) ? base + (unsigned)(sy * WI * rowB_b) : W3_OOB;
         } else {
             hyB[k] = xok ? hy - 1 : -(1 << 20);
             voffB[k] = base;                                                   // + sy*W*rowB_b when the row is inside the image
@@ -124,14 +151,14 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Par
             if (wave + 4 * k < NGA)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)(base + (wave + 4 * k) * 1024), 16,
                                                          voffA[k], soffA, 0, 0);
-        const int soffB = img * p.H * W * rowB_b;
+        const int soffB = img * Hi * WI * rowB_b;
 #pragma unroll
         for (int k = 0; k < KB; ++k) {
             if (wave + 4 * k < NGB) {
                 unsigned v = voffB[k];
                 if constexpr (!G::WHOLE) {
-                    const int sy = y0 + hyB[k];
-                    v = (unsigned)sy < (unsigned)p.H ? voffB[k] + (unsigned)(sy * W * rowB_b) : W3_OOB;
+                    const int sy = SD * y0 + hyB[k];
+                    v = (unsigned)sy < (unsigned)Hi ? voffB[k] + (unsigned)(sy * WI * rowB_b) : W3_OOB;
                 }
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (__attribute__((address_space(3))) void*)(base + A_BYTES + (wave + 4 * k) * 1024),
                                                          16, v, soffB, 0, 0);
@@ -152,8 +179,8 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Par
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         const int row = G::lane_row(pl, s), rowh = row + G::HI_DELTA;
-        lb[s] = lds0 + A_BYTES + row * 128 + ((wave ^ w3_f(row)) * 32) + (t & 3) * 8;
-        lbh[s] = lds0 + A_BYTES + rowh * 128 + ((wave ^ w3_f(rowh)) * 32) + (t & 3) * 8;
+        lb[s] = lds0 + A_BYTES + row * 128 + ((wave ^ G::fB(row)) * 32) + (t & 3) * 8;
+        lbh[s] = lds0 + A_BYTES + rowh * 128 + ((wave ^ G::fB(rowh)) * 32) + (t & 3) * 8;
     }
 
     f32x4_t acc[9][4];
@@ -204,7 +231,9 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Par
         __builtin_amdgcn_s_barrier();
     }
 
-    float* out = p.out + ((long long)(group * p.split_k + split) * p.Cd) * 9 * p.Cs;
+    // fp32 slab [co][tap][ci].  (Staging the tiles through LDS for 16-byte, 256-byte-contiguous stores was measured: no gain --
+    // the epilogue costs what writing the per-chunk fp32 gradients to HBM costs, e.g. 283 MB per launch for a 512x512 layer.)
+    float* out = p.out + group * p.group_stride + ((long long)split * p.Cd) * 9 * p.Cs;
 #pragma unroll
     for (int u = 0; u < 9; ++u)
 #pragma unroll
@@ -222,25 +251,34 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Par
 int fb_try_wgrad3x3_v2(const fb_wgrad_args* a, hipStream_t st) {
     static const bool disabled = getenv("FB_DISABLE_WGRAD3_V2") != nullptr;
     if (disabled || a->dtype != FB_BF16) return 0;
-    if (a->R != 3 || a->S != 3 || a->stride != 1 || a->pad != 1) return 0;
-    if (a->Hs != a->Hd || a->Ws != a->Wd || a->Hs != a->Ws) return 0;
-    const int W = a->Ws;
+    if (a->R != 3 || a->S != 3 || a->pad != 1 || (a->stride != 1 && a->stride != 2)) return 0;
+    const int SD = a->stride;
+    if (a->Hs != SD * a->Hd || a->Ws != SD * a->Wd || a->Hd != a->Wd) return 0;
+    const int W = a->Wd;
     if (W != 32 && W != 16 && W != 8 && W != 4) return 0;
+    if (SD == 2 && W == 32) return 0;
     if (a->Cs % 64 != 0 || a->Cd % 64 != 0) return 0;
     if (a->imgs_per_group % a->split_k != 0) return 0;
     const int imgs_per_block = a->imgs_per_group / a->split_k;
     if (W == 4 && (imgs_per_block & 1)) return 0;
-    const long long bytes = (long long)a->n_img * a->Hs * W * (a->Cs > a->Cd ? a->Cs : a->Cd) * 2;
-    if (bytes >= (1LL << 31)) return 0;
+    const long long bytes_x = (long long)a->n_img * a->Hs * a->Ws * a->Cs * 2, bytes_dy = (long long)a->n_img * a->Hd * a->Wd * a->Cd * 2;
+    if (bytes_x >= (1LL << 31) || bytes_dy >= (1LL << 31)) return 0;
     Wgrad3V2Params p;
     p.x = (const char*)a->x; p.dy = (const char*)a->dy; p.out = a->dw_partial;
-    p.n_img = a->n_img; p.H = a->Hs; p.Cs = a->Cs; p.Cd = a->Cd;
+    p.n_img = a->n_img; p.H = a->Hd; p.Cs = a->Cs; p.Cd = a->Cd;
     p.imgs_per_group = a->imgs_per_group; p.split_k = a->split_k; p.imgs_per_block = imgs_per_block;
+    p.group_stride = a->group_stride ? a->group_stride : (long long)a->split_k * a->Cd * 9 * a->Cs;
     const int n_groups = a->n_img / a->imgs_per_group;
     dim3 grid((a->Cd / 64) * (a->Cs / 64), n_groups * a->split_k);
-    if (W == 32) hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<32>), grid, dim3(256), 0, st, p);
-    else if (W == 16) hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<16>), grid, dim3(256), 0, st, p);
-    else if (W == 8) hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<8>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<4>), grid, dim3(256), 0, st, p);
+    if (SD == 1) {
+        if (W == 32) hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<32, 1>), grid, dim3(256), 0, st, p);
+        else if (W == 16) hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<16, 1>), grid, dim3(256), 0, st, p);
+        else if (W == 8) hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<8, 1>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<4, 1>), grid, dim3(256), 0, st, p);
+    } else {
+        if (W == 16) hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<16, 2>), grid, dim3(256), 0, st, p);
+        else if (W == 8) hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<8, 2>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<4, 2>), grid, dim3(256), 0, st, p);
+    }
     return 1;
 }

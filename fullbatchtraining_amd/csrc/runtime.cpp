@@ -7,7 +7,7 @@
 
 thread_local char fb_err_buf[512] = "";
 extern "C" const char* fb_last_error_string(void) { return fb_err_buf; }
-extern "C" int fb_abi_version(void) { return 1; }
+extern "C" int fb_abi_version(void) { return 2; }
 
 namespace {
 struct Pair { hipEvent_t a, b; int cls; };

@@ -243,13 +243,14 @@ class Engine:
 
     def _choose_split(self, L):
         """Split the pixel reduction of wgrad so that >= ~1000 workgroups exist; slices are multiples of the K-step."""
-        widths = (4, 8, 16, 32) if self.dt == torch.bfloat16 else (16, 32)
-        if (L.R == 3 and L.stride == 1 and L.pad == 1 and L.hin == L.win and L.win in widths and L.cin_pad % 64 == 0
-                and L.cout % 64 == 0 and not (L.win == 4 and self.chunk % 2)):
+        bf16 = self.dt == torch.bfloat16
+        widths = ((4, 8, 16, 32) if bf16 else (16, 32)) if L.stride == 1 else ((4, 8, 16) if bf16 else ())
+        if (L.R == 3 and L.stride in (1, 2) and L.pad == 1 and L.hout == L.wout and L.hin == L.stride * L.hout and L.wout in widths
+                and L.cin_pad % 64 == 0 and L.cout % 64 == 0 and not (L.wout == 4 and self.chunk % 2)):
             # all-taps halo wgrad kernel: split-K over whole images, split must divide the chunk (4x4 maps: image pairs)
             tiles = (L.cout // 64) * (L.cin_pad // 64)
             want = max(1, -(-512 // (tiles * self.G)))
-            unit = 2 if L.win == 4 else 1
+            unit = 2 if L.wout == 4 else 1
             return max(d for d in range(1, self.chunk + 1) if self.chunk % (d * unit) == 0 and d <= max(want, 1))
         big = L.cin_pad % 128 == 0 and L.cout % 128 == 0 and (L.cin_pad >= 256 or L.cout >= 256)
         tile = 128 if big else 64
@@ -454,19 +455,25 @@ class Engine:
         """Weight gradient of layer L into gout[g] (per chunk).  Runs on the weight-gradient stream; the event of its completion
         is kept in ``self._wgrad_event`` (callers hand it to the pool with ``dx`` and wait for it at the end of backward)."""
         n = G * self.chunk
-        a = lib.WgradArgs(src.data_ptr(), dx.data_ptr(), self.slab_ws.data_ptr(), n, L.hin, L.win, L.cin_pad, L.hout, L.wout, L.cout,
-                          L.R, L.S, L.stride, L.pad, self.chunk, L.split_k, self.dtc)
-        if self.wstream is None:
+        # one K slice and no channel padding: the kernel writes the per-chunk gradients straight into the arena rows
+        direct = L.split_k == 1 and L.cin_pad == L.cin_real
+        a = lib.WgradArgs(src.data_ptr(), dx.data_ptr(), gout.data_ptr() + 4 * L.w_off if direct else self.slab_ws.data_ptr(), n, L.hin, L.win,
+                          L.cin_pad, L.hout, L.wout, L.cout, L.R, L.S, L.stride, L.pad, self.chunk, L.split_k, self.dtc,
+                          self.plan.P if direct else 0)
+
+        def launch():
             call("fb_conv2d_wgrad", lib.C.byref(a))
-            call("fb_wgrad_reduce", self.slab_ws.data_ptr(), gout.data_ptr() + 4 * L.w_off, self.plan.P, G, L.split_k, L.cout, L.taps,
-                 L.cin_pad, L.cin_real)
+            if not direct:
+                call("fb_wgrad_reduce", self.slab_ws.data_ptr(), gout.data_ptr() + 4 * L.w_off, self.plan.P, G, L.split_k, L.cout, L.taps,
+                     L.cin_pad, L.cin_real)
+
+        if self.wstream is None:
+            launch()
             return
         ready = torch.cuda.current_stream().record_event()
         with torch.cuda.stream(self.wstream):
             self.wstream.wait_event(ready)
-            call("fb_conv2d_wgrad", lib.C.byref(a))
-            call("fb_wgrad_reduce", self.slab_ws.data_ptr(), gout.data_ptr() + 4 * L.w_off, self.plan.P, G, L.split_k, L.cout, L.taps,
-                 L.cin_pad, L.cin_real)
+            launch()
             self._wgrad_event = self.wstream.record_event()
 
     def _dgrad(self, L, dx, G, wsets, addend=None, addend_mode=0):

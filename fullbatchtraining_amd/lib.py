@@ -26,7 +26,7 @@ class WgradArgs(C.Structure):
     _fields_ = [("x", c_void_p), ("dy", c_void_p), ("dw_partial", c_void_p),
                 ("n_img", c_int), ("Hs", c_int), ("Ws", c_int), ("Cs", c_int), ("Hd", c_int), ("Wd", c_int), ("Cd", c_int),
                 ("R", c_int), ("S", c_int), ("stride", c_int), ("pad", c_int),
-                ("imgs_per_group", c_int), ("split_k", c_int), ("dtype", c_int)]
+                ("imgs_per_group", c_int), ("split_k", c_int), ("dtype", c_int), ("group_stride", c_i64)]
 
 
 _SIGS = {
@@ -141,11 +141,11 @@ def conv2d(src, wgt, dst, R, S, stride, pad, mode, addend=None, addend_mode=0, s
     call("fb_conv2d", C.byref(a))
 
 
-def conv2d_wgrad(x, dy, dw_partial, R, S, stride, pad, imgs_per_group, split_k):
+def conv2d_wgrad(x, dy, dw_partial, R, S, stride, pad, imgs_per_group, split_k, group_stride=0):
     n, hs, ws, cs = x.shape
     _, hd, wd, cd = dy.shape
     a = WgradArgs(_ptr(x), _ptr(dy), _ptr(dw_partial), n, hs, ws, cs, hd, wd, cd, R, S, stride, pad, imgs_per_group, split_k,
-                  dtype_code(x.dtype))
+                  dtype_code(x.dtype), group_stride)
     call("fb_conv2d_wgrad", C.byref(a))
 
 

@@ -63,12 +63,16 @@ typedef struct {
 int fb_conv2d(const fb_conv_args* a, void* stream);
 
 /* wgrad: dw[g][split][Cd][R*S][Cs] (fp32 partial slabs) = sum over the pixels of chunk g (split-K slice `split`) of
- * dy[p][Cd] (x) x[src(p,tap)][Cs]        (ATen convolution_backward, weight part).  Deterministic: no atomics. */
+ * dy[p][Cd] (x) x[src(p,tap)][Cs]        (ATen convolution_backward, weight part).  Deterministic: no atomics.
+ * group_stride (floats): 0 = dense slabs as above; otherwise the slab of (g, split) starts at
+ * dw_partial + g*group_stride + split*Cd*R*S*Cs -- with split_k == 1 and unpadded channels that writes the per-chunk
+ * gradient straight into the [g][P] gradient arena (group_stride = P) and no fb_wgrad_reduce pass is needed. */
 typedef struct {
     const void* x; const void* dy; float* dw_partial;
     int32_t n_img, Hs, Ws, Cs, Hd, Wd, Cd;
     int32_t R, S, stride, pad;
     int32_t imgs_per_group; int32_t split_k; int32_t dtype;
+    int64_t group_stride;
 } fb_wgrad_args;
 int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream);
 /* sums the split_k slabs in fixed order, drops channel padding (Cs_pad -> Cs_real), writes [g][Cd][R*S][Cs_real]

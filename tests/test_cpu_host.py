@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), name
     assert set(lib.EXPORTS) == declared
-    assert handle.fb_abi_version() == 1
+    assert handle.fb_abi_version() == 2
 
 
 def test_engine_fails_loudly_without_gpu():

@@ -111,7 +111,9 @@ def test_conv_dgrad(dtype, cin, cout, k, stride, hw, n, amode):
                                                                   (64, 64, 3, 1, 32, 4, 2, 2), (128, 64, 3, 1, 16, 4, 2, 4),   # all-taps halo kernel
                                                                   (64, 128, 3, 1, 16, 6, 1, 3),
                                                                   (128, 64, 3, 1, 8, 6, 2, 2), (64, 128, 3, 1, 4, 8, 2, 2),    # 8x8 / 4x4 maps
-                                                                  (64, 64, 3, 1, 4, 6, 1, 3), (64, 64, 3, 1, 4, 6, 1, 2)])
+                                                                  (64, 64, 3, 1, 4, 6, 1, 3), (64, 64, 3, 1, 4, 6, 1, 2),
+                                                                  (64, 128, 3, 2, 32, 4, 2, 2), (128, 64, 3, 2, 16, 6, 1, 3), (64, 64, 3, 2, 8, 8, 2, 2),   # stride 2, all taps
+                                                                  (128, 128, 3, 2, 16, 5, 1, 1)])
 def test_conv_wgrad(dtype, cin, cout, k, stride, hw, ipg, groups, split):
     lib = _lib()
     torch.manual_seed(2)
@@ -130,6 +132,11 @@ def test_conv_wgrad(dtype, cin, cout, k, stride, hw, ipg, groups, split):
         ref = torch.nn.grad.conv2d_weight(x[sl], (cout, cin, k, k), dy[sl], stride, pad)
         got = out[g, : cout * k * k * cin].view(cout, k, k, cin).permute(0, 3, 1, 2).cpu()
         assert rel(got, ref) < (1e-5 if dtype == torch.float32 else 1e-5), (g, rel(got, ref))
+    if split == 1:      # group_stride: per-chunk gradients written straight into arena rows, no reduce pass
+        arena = torch.full((groups, cout * k * k * cin + 40), float("nan"), device="cuda")
+        lib.conv2d_wgrad(xd, dyd, arena[:, 8:], k, k, stride, pad, ipg, 1, group_stride=arena.shape[1])
+        assert torch.equal(arena[:, 8:8 + cout * k * k * cin], out[:, : cout * k * k * cin])
+        assert bool(torch.isnan(arena[:, :8]).all()) and bool(torch.isnan(arena[:, 8 + cout * k * k * cin:]).all())
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -52,7 +52,10 @@ def test_train_matches_reference_run_f32(golden, name, tol, group, tmp_path):
     assert n_chunks == meta["scenarios"][name]["n"] // min(cfg.data.batch_size, cfg.hyp.sub_batch)
     for k in range(n_chunks):
         r64, r32 = data[f"{name}@f64/stat/grad_norm_train_{k}"], data[f"{name}/stat/grad_norm_train_{k}"]
-        bound = np.maximum(tol * np.abs(r64), 5 * np.abs(r32 - r64))
+        # a single chunk gradient sits on the fp32 noise floor (the reference's own fp32 chunk gradient is ~3e-3 rel-L2 from
+        # its float64 run, tests/test_oracle_golden.py; any other summation order lands equally far away), so its norm is
+        # only meaningful to ~1e-3 once the parameters have moved (steps >= 3); the |r32 - r64| of one sample underestimates that
+        bound = np.maximum(max(tol, 1e-3) * np.abs(r64), 5 * np.abs(r32 - r64))
         assert np.all(np.abs(np.array(stats[f"grad_norm_train_{k}"]) - r64) <= bound), (k, stats[f"grad_norm_train_{k}"], r32, r64)
     # final parameters + BN buffers (state_dict order) against the reference's float64 run
     ordered = [v.double() for v in model.state_dict().values()]
