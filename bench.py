@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--grad-reg", type=float, default=0.0, help="block_strength of the finite-difference regulariser (config 3)")
-    ap.add_argument("--chunk-group", type=int, default=30)
+    ap.add_argument("--chunk-group", type=int, default=39)
     ap.add_argument("--images", type=int, default=N_IMAGES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")

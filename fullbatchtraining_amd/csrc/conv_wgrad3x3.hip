@@ -185,12 +185,11 @@ int fb_try_wgrad3x3(const fb_wgrad_args* a, hipStream_t st) {
     const int W = a->Ws;
     if (W != 32 && W != 16) return 0;
     if (a->Cs % 64 != 0 || a->Cd % 64 != 0) return 0;
-    if (a->imgs_per_group % a->split_k != 0) return 0;
     Wgrad3Params p;
     p.x = (const char*)a->x; p.dy = (const char*)a->dy; p.out = a->dw_partial;
     p.group_stride = a->group_stride ? a->group_stride : (long long)a->split_k * a->Cd * 9 * a->Cs;
     p.n_img = a->n_img; p.H = a->Hs; p.Cs = a->Cs; p.Cd = a->Cd;
-    p.imgs_per_group = a->imgs_per_group; p.split_k = a->split_k; p.imgs_per_block = a->imgs_per_group / a->split_k;
+    p.imgs_per_group = a->imgs_per_group; p.split_k = a->split_k; p.imgs_per_block = (a->imgs_per_group + a->split_k - 1) / a->split_k;   // ragged last K slice allowed
     const int n_groups = a->n_img / a->imgs_per_group;
     dim3 grid((a->Cd / 64) * (a->Cs / 64), n_groups * a->split_k);
     if (a->dtype == FB_F32) {

@@ -258,9 +258,9 @@ int fb_try_wgrad3x3_v2(const fb_wgrad_args* a, hipStream_t st) {
     if (W != 32 && W != 16 && W != 8 && W != 4) return 0;
     if (SD == 2 && W == 32) return 0;
     if (a->Cs % 64 != 0 || a->Cd % 64 != 0) return 0;
-    if (a->imgs_per_group % a->split_k != 0) return 0;
-    const int imgs_per_block = a->imgs_per_group / a->split_k;
-    if (W == 4 && (imgs_per_block & 1)) return 0;
+    // K slices are whole images; the last slice of a chunk may be shorter (or empty: it then contributes zeros)
+    int imgs_per_block = (a->imgs_per_group + a->split_k - 1) / a->split_k;
+    if (W == 4) { if (a->imgs_per_group & 1) return 0; imgs_per_block += imgs_per_block & 1; }   // 4x4 maps: image pairs per K-step
     const long long bytes_x = (long long)a->n_img * a->Hs * a->Ws * a->Cs * 2, bytes_dy = (long long)a->n_img * a->Hd * a->Wd * a->Cd * 2;
     if (bytes_x >= (1LL << 31) || bytes_dy >= (1LL << 31)) return 0;
     Wgrad3V2Params p;

@@ -247,11 +247,12 @@ class Engine:
         widths = ((4, 8, 16, 32) if bf16 else (16, 32)) if L.stride == 1 else ((4, 8, 16) if bf16 else ())
         if (L.R == 3 and L.stride in (1, 2) and L.pad == 1 and L.hout == L.wout and L.hin == L.stride * L.hout and L.wout in widths
                 and L.cin_pad % 64 == 0 and L.cout % 64 == 0 and not (L.wout == 4 and self.chunk % 2)):
-            # all-taps halo wgrad kernel: split-K over whole images, split must divide the chunk (4x4 maps: image pairs)
+            # all-taps halo wgrad kernel: split-K over whole images (pairs for 4x4 maps); any split works (ragged last slice).
+            # One wave of workgroups: as many K slices as fit the resident slots (2 workgroups per CU; the stride-2 4x4 kernel 1)
             tiles = (L.cout // 64) * (L.cin_pad // 64)
-            want = max(1, -(-512 // (tiles * self.G)))
+            slots = 256 if (L.stride == 2 and L.wout == 4) else 512
             unit = 2 if L.wout == 4 else 1
-            return max(d for d in range(1, self.chunk + 1) if self.chunk % (d * unit) == 0 and d <= max(want, 1))
+            return max(1, min(slots // (tiles * self.G), self.chunk // (2 * unit)))
         big = L.cin_pad % 128 == 0 and L.cout % 128 == 0 and (L.cin_pad >= 256 or L.cout >= 256)
         tile = 128 if big else 64
         tiles = (L.cout // tile) * max(L.cin_pad // tile, 1) * L.taps

@@ -113,7 +113,8 @@ def test_conv_dgrad(dtype, cin, cout, k, stride, hw, n, amode):
                                                                   (128, 64, 3, 1, 8, 6, 2, 2), (64, 128, 3, 1, 4, 8, 2, 2),    # 8x8 / 4x4 maps
                                                                   (64, 64, 3, 1, 4, 6, 1, 3), (64, 64, 3, 1, 4, 6, 1, 2),
                                                                   (64, 128, 3, 2, 32, 4, 2, 2), (128, 64, 3, 2, 16, 6, 1, 3), (64, 64, 3, 2, 8, 8, 2, 2),   # stride 2, all taps
-                                                                  (128, 128, 3, 2, 16, 5, 1, 1)])
+                                                                  (128, 128, 3, 2, 16, 5, 1, 1),
+                                                                  (64, 64, 3, 1, 16, 10, 2, 3), (64, 64, 3, 1, 32, 7, 1, 4), (64, 64, 3, 1, 4, 10, 2, 3), (64, 128, 3, 2, 16, 7, 2, 5)])   # ragged K slices
 def test_conv_wgrad(dtype, cin, cout, k, stride, hw, ipg, groups, split):
     lib = _lib()
     torch.manual_seed(2)
