@@ -19,6 +19,18 @@ import torch
 import torch.distributed as dist
 
 
+def group_size(n_chunks, chunk_group):
+    """Chunks per batched launch for a rank that owns ``n_chunks``: equal-sized groups (no ragged last launch), as many as
+    brings the size closest to ``chunk_group`` -- 390 chunks run as 10 x 39, a rank's 49 chunks (8 GPUs) as one group of 49
+    rather than 39 + 10.  The size stays below 1.5 x chunk_group (f32 activations of 58 chunks are still < 2^31 bytes, the
+    range of the kernels' buffer descriptors)."""
+    if n_chunks <= 0:
+        return max(1, chunk_group)
+    g = max(1, min(chunk_group, n_chunks))
+    n_groups = max(1, int(n_chunks / g + 0.5))
+    return -(-n_chunks // n_groups)
+
+
 class ShardPlan:
     """Contiguous chunk ranges: the first ``K % world`` ranks own one chunk more."""
 

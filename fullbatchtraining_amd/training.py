@@ -205,13 +205,9 @@ class FullBatchTrainer:
         self.dtype = torch.bfloat16 if (cfg.impl.mixed_precision and s == 0) else torch.float32
         if cfg.impl.mixed_precision and s != 0:
             log.warning("grad_reg finite differences need matching fp32 passes (perturbation ~1e-6 per weight): running fp32.")
-        from .parallel import ShardPlan
+        from .parallel import ShardPlan, group_size
         self.shard = ShardPlan(self.n_chunks, self.world, self.rank)
-        G = int(cfg.impl.get("engine", {}).get("chunk_group", 39))
-        G = max(1, min(G, self.shard.count))
-        # equal-sized groups (no ragged last launch): 49 chunks with chunk_group 39 run as 25 + 24, not 39 + 10
-        n_groups = -(-self.shard.count // G) if self.shard.count else 1
-        G = -(-self.shard.count // n_groups) if self.shard.count else G
+        G = group_size(self.shard.count, int(cfg.impl.get("engine", {}).get("chunk_group", 39)))
         self.engine = Engine(model, X.shape[-1], self.chunk, G, compute_dtype=self.dtype, device=self.device, fd_sets=fd_sets)
         stem = self.engine.plan.stem
         lo, hi = self.shard.first * self.chunk, (self.shard.first + self.shard.count) * self.chunk

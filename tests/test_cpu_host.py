@@ -103,6 +103,11 @@ def test_shard_plan_partitions_chunks():
         assert [p.first for p in plans] == [sum(pl.count for pl in plans[:r]) for r in range(w)]
         assert max(p.count for p in plans) - min(p.count for p in plans) <= 1
     assert [ShardPlan(390, 8, r).count for r in range(8)] == [49] * 6 + [48] * 2
+    from fullbatchtraining_amd.parallel import group_size
+    assert [group_size(c, 39) for c in (390, 195, 98, 97, 49, 48, 7, 1, 58, 59)] == [39, 39, 33, 49, 49, 48, 7, 1, 58, 30]
+    for c in range(1, 400):                      # equal groups, never more than 1.5 x the configured size
+        g = group_size(c, 39)
+        assert 1 <= g < 59 and -(-c // g) * g - c < -(-c // g)
 
 
 # --------------------------------------------------------------------------------------------- gloo, world_size = 2 ----
