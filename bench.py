@@ -85,11 +85,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    # FB_BENCH_SHARE_DEVICE=1 (development only): all ranks on cuda:0 over gloo -- exercises the multi-rank orchestration on
+    # a 1-GPU box (RCCL refuses two ranks on one device); the number it prints is not a scaling result
+    share = os.environ.get("FB_BENCH_SHARE_DEVICE") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=device)
+        if share:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=device)
 
     from fullbatchtraining_amd import lib
     from fullbatchtraining_amd.cfg import compose
