@@ -167,6 +167,12 @@ class Engine:
         self.dtc = lib.dtype_code(compute_dtype)
         self.plan = Plan(model, pixels)
         self.chunk, self.G = chunk, max_groups
+        for L in self.plan.layers:
+            if (chunk * L.hout * L.wout) % 128 != 0:
+                raise lib.EngineError(f"chunk size {chunk} x {L.hout}x{L.wout} feature map of {L.conv_name}: pixels per chunk must be a "
+                                      "multiple of 128 (BN statistics are reduced in 128-pixel blocks that must not straddle chunks); "
+                                      "use a chunk size (data.batch_size / hyp.sub_batch) that is a multiple of "
+                                      f"{128 // math.gcd(128, L.hout * L.wout)}")
         P = self.plan.P
         f32 = dict(device=self.device, dtype=torch.float32)
         self.theta = torch.zeros(P, **f32)

@@ -130,3 +130,34 @@ def test_bottleneck_standard_stem_chunk_gradients_vs_oracle():
         print(f"resnet50/standard chunk {g}: engine-vs-f64-truth {err:.3e}")
         assert err < 5e-2, err      # 53 conv layers: fp32 conditioning of the chunk gradient is ~5x that of ResNet-18
         assert rel_err(got[g][-2].numpy(), truth[g][0][-2].numpy()) < 1e-4
+
+
+def test_imagenet_shaped_maps_chunk_gradient_vs_oracle():
+    """ResNet-18 with the 'standard' (ImageNet) stem on 96x96 inputs: feature maps 48 -> (MaxPool) 24, 12, 6, 3 -- non-power-of-two
+    sizes like the 56/28/14/7 of the 224x224 configurations (every stride-2 transition halves an even size, as there; the
+    reference's AvgPool shortcut cannot take odd ones), which go through the generic implicit-GEMM / per-tap weight-gradient
+    kernels (the LDS-halo kernels cover 32/16/8/4 only).  One chunk of 128 images (3x3 maps: chunk * 9 must be a multiple of 128)."""
+    pixels, chunk, G = 96, 128, 1
+    cfg, model, eng, stem_patches = _build(18, pixels, chunk, G, torch.float32, stem="standard")
+    assert {24, 12, 6, 3} <= {L.hout for L in eng.plan.layers}
+    x, y = make_data(chunk * G, pixels)
+    truth, params, buffers = _oracle_chunk_grads(model, x, y, chunk, depth=18, stem="standard")
+    patches = stem_patches(x.cuda(), eng.plan.stem, torch.float32)
+    eng.prep_weights(eng.theta, 1)
+    eng.group_gradient(patches, y.cuda(), G, eng.g)
+    torch.cuda.synchronize()
+    got = _engine_grads_as_lists(eng, G)
+    assert abs(float(eng.loss[0]) - truth[0][1]) < 1e-5 * abs(truth[0][1])
+    a = torch.cat([t.reshape(-1).double() for t in got[0]])
+    t = torch.cat([r.reshape(-1).double() for r in truth[0][0]])
+    err = float((a - t).norm() / t.norm())
+    print(f"resnet18/standard 96x96: engine-vs-f64-truth {err:.3e}")
+    assert err < 2e-2, err
+    assert rel_err(got[0][-2].numpy(), truth[0][0][-2].numpy()) < 1e-4
+
+
+def test_chunk_must_fill_whole_statistics_blocks():
+    """BN statistics are reduced per 128-pixel block and a block must not straddle two chunks: refused with a clear message."""
+    from fullbatchtraining_amd.lib import EngineError
+    with pytest.raises(EngineError, match="multiple of 128"):
+        _build(18, 96, 32, 1, torch.float32, stem="standard")       # 3x3 maps: 32 * 9 pixels per chunk
