@@ -9,6 +9,17 @@ thread_local char fb_err_buf[512] = "";
 extern "C" const char* fb_last_error_string(void) { return fb_err_buf; }
 extern "C" int fb_abi_version(void) { return 2; }
 
+// ---- workspace sizes (floats) ------------------------------------------------------------------------------------------
+extern "C" int64_t fb_ws_conv_stat_floats(const fb_conv_args* a) {
+    return a ? 2 * (((int64_t)a->n_img * a->Hd * a->Wd + 127) / 128) * a->Cd : 0;
+}
+extern "C" int64_t fb_ws_wgrad_slab_floats(const fb_wgrad_args* a) {
+    if (!a || a->imgs_per_group <= 0) return 0;
+    return (int64_t)(a->n_img / a->imgs_per_group) * a->split_k * a->Cd * a->R * a->S * a->Cs;
+}
+extern "C" int64_t fb_ws_bn_partial_floats(int64_t n_pixels, int32_t C) { return 2 * ((n_pixels + 127) / 128) * C; }
+extern "C" int64_t fb_ws_mt_floats(int32_t n_groups) { return (int64_t)(n_groups > 2 ? n_groups : 2) * FB_MT_BLOCKS; }
+
 namespace {
 struct Pair { hipEvent_t a, b; int cls; };
 bool g_on = false;

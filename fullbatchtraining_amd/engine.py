@@ -201,7 +201,7 @@ class Engine:
             unbias[L.ch_off:L.ch_off + L.cout] = m / (m - 1)
         self.unbias = unbias.to(self.device)
         self._alloc_activations()
-        self.mt_ws = torch.zeros(max(self.G, 2) * lib.MT_BLOCKS, **f32)
+        self.mt_ws = torch.zeros(lib.load().fb_ws_mt_floats(self.G), **f32)
         self.sq = torch.zeros(self.G, **f32)
         self.vnorm2 = torch.zeros(self.G, **f32)
         self.eps_n = torch.zeros(self.G, **f32)
@@ -226,9 +226,13 @@ class Engine:
             L.invstd = torch.empty(self.G, L.cout, **f32)
             L.coef = torch.empty(self.G, L.cout, 3, **f32)
             px = n * L.hout * L.wout
-            max_part = max(max_part, 2 * _round_up(px, 128) // 128 * L.cout * 4)  # x4: stride-2 dgrad classes never stat
             L.split_k = self._choose_split(L)
-            max_slab = max(max_slab, self.G * L.split_k * L.cout * L.taps * L.cin_pad)
+            # scratch sizes from the library's own queries (conv statistics / BN-backward partial sums share one buffer)
+            handle = lib.load()
+            max_part = max(max_part, handle.fb_ws_bn_partial_floats(px, L.cout),
+                           handle.fb_ws_conv_stat_floats(lib.C.byref(lib.ConvArgs(n_img=n, Hd=L.hout, Wd=L.wout, Cd=L.cout))))
+            max_slab = max(max_slab, handle.fb_ws_wgrad_slab_floats(lib.C.byref(lib.WgradArgs(
+                n_img=n, imgs_per_group=self.chunk, split_k=L.split_k, Cd=L.cout, R=L.R, S=L.S, Cs=L.cin_pad))))
         self.stat_ws = torch.empty(max_part, **f32)
         self.slab_ws = torch.empty(max_slab, **f32)
         self.stem_out = torch.empty(n, self.plan.stem.hout, self.plan.stem.wout, 64, device=dev, dtype=dt)

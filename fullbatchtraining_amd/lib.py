@@ -58,7 +58,8 @@ _SIGS = {
     "fb_mt_clip_sgd": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_float, c_float, c_float, c_float, c_float, c_int, c_int, c_void_p],
     "fb_mt_scale": [c_void_p, c_i64, c_float, c_void_p],
 }
-EXPORTS = tuple(_SIGS) + ("fb_last_error_string", "fb_abi_version", "fb_profile_enable", "fb_profile_read")
+EXPORTS = tuple(_SIGS) + ("fb_last_error_string", "fb_abi_version", "fb_profile_enable", "fb_profile_read", "fb_ws_conv_stat_floats",
+                          "fb_ws_wgrad_slab_floats", "fb_ws_bn_partial_floats", "fb_ws_mt_floats")
 PROF_CLASSES = ("igemm_fwd", "igemm_dgrad", "wgrad")
 
 
@@ -98,6 +99,10 @@ def load():
             fn.argtypes, fn.restype = sig, c_int
         lib.fb_last_error_string.restype = C.c_char_p
         lib.fb_abi_version.restype = c_int
+        lib.fb_ws_conv_stat_floats.argtypes, lib.fb_ws_conv_stat_floats.restype = [C.POINTER(ConvArgs)], c_i64
+        lib.fb_ws_wgrad_slab_floats.argtypes, lib.fb_ws_wgrad_slab_floats.restype = [C.POINTER(WgradArgs)], c_i64
+        lib.fb_ws_bn_partial_floats.argtypes, lib.fb_ws_bn_partial_floats.restype = [c_i64, c_int], c_i64
+        lib.fb_ws_mt_floats.argtypes, lib.fb_ws_mt_floats.restype = [c_int], c_i64
         _lib = lib
     return _lib
 

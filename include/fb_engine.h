@@ -75,6 +75,17 @@ typedef struct {
     int64_t group_stride;
 } fb_wgrad_args;
 int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream);
+
+/* Workspace sizes (in floats) of the caller-owned scratch buffers the entry points below take; host-side arithmetic only,
+ * no launch.  The library never allocates device memory.
+ *   fb_ws_conv_stat_floats   : stat_partial of fb_conv2d(mode 0)  = 2 * ceil(n_img*Hd*Wd / 128) * Cd
+ *   fb_ws_wgrad_slab_floats  : dw_partial of fb_conv2d_wgrad      = (n_img/imgs_per_group) * split_k * Cd * R*S * Cs
+ *   fb_ws_bn_partial_floats  : partial of fb_bn_bwd_reduce        = 2 * ceil(n_pixels / 128) * C
+ *   fb_ws_mt_floats          : ws of the fb_mt_* reductions       = max(n_groups, 2) * FB_MT_BLOCKS */
+int64_t fb_ws_conv_stat_floats(const fb_conv_args* a);
+int64_t fb_ws_wgrad_slab_floats(const fb_wgrad_args* a);
+int64_t fb_ws_bn_partial_floats(int64_t n_pixels, int32_t C);
+int64_t fb_ws_mt_floats(int32_t n_groups);
 /* sums the split_k slabs in fixed order, drops channel padding (Cs_pad -> Cs_real), writes [g][Cd][R*S][Cs_real]
  * at out + g*out_group_stride */
 int fb_wgrad_reduce(const float* dw_partial, float* out, int64_t out_group_stride, int32_t n_groups, int32_t split_k,

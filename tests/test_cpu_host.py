@@ -29,6 +29,18 @@ def test_library_exports_every_declared_symbol():
     assert handle.fb_abi_version() == 2
 
 
+def test_workspace_size_queries():
+    """Host-side arithmetic of the C ABI (no launch): scratch sizes the caller has to provide."""
+    from fullbatchtraining_amd import lib
+    h = lib.load()
+    conv = lib.ConvArgs(n_img=256, Hd=16, Wd=16, Cd=128)
+    assert h.fb_ws_conv_stat_floats(lib.C.byref(conv)) == 2 * (256 * 256 // 128) * 128
+    wg = lib.WgradArgs(n_img=256, imgs_per_group=128, split_k=5, Cd=128, R=3, S=3, Cs=64)
+    assert h.fb_ws_wgrad_slab_floats(lib.C.byref(wg)) == 2 * 5 * 128 * 9 * 64
+    assert h.fb_ws_bn_partial_floats(1000, 64) == 2 * 8 * 64
+    assert h.fb_ws_mt_floats(1) == 2 * lib.MT_BLOCKS and h.fb_ws_mt_floats(39) == 39 * lib.MT_BLOCKS
+
+
 def test_engine_fails_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
