@@ -23,6 +23,7 @@ from collections import defaultdict
 import torch
 from torch.optim.lr_scheduler import _LRScheduler
 
+from . import lib
 from .engine import Engine, stem_patches
 
 log = logging.getLogger("fullbatchtraining_amd")
@@ -295,6 +296,55 @@ def status_message(optimizer, stats, step):
     return (f'Step: {step:<4}| lr: {optimizer.param_groups[0]["lr"]:.4f} | Time: {stats["train_time"][-1]:4.2f}s |'
             f'TRAIN loss {stats["train_loss"][-1]:7.4f} | TRAIN Acc: {stats["train_acc"][-1]:7.2%} |'
             f'VAL loss {last("valid_loss"):7.4f} | VAL Acc: {last("valid_acc"):7.2%} |')
+
+
+def _measure_implementation_noise(model, trainloader, validloader, setup, cfg):
+    """Floating-point difference between two successive evaluations of the (regularised, clipped) full-batch gradient from the
+    same checkpoint -- the protocol of reference training.py:429-600 / measure_floating_point_accuracy.py, same printed lines.
+    Every reduction of the engine has a fixed order (no atomics), so the two gradients are bit-identical and the errors are 0.0;
+    that is the acceptance test for the deterministic split-K / statistics reductions.  Returns the numbers as a dict."""
+    trainer = FullBatchTrainer(model, trainloader, validloader, setup, cfg)
+    if trainer.world > 1:
+        raise NotImplementedError("_measure_implementation_noise: single-process protocol")
+    eng, hyp, optimizer, scheduler = trainer.engine, cfg.hyp, trainer.optimizer, trainer.scheduler
+
+    class Counter:
+        step: int = 0
+
+    if cfg.impl.checkpoint.name is None:
+        print("Could not load checkpoint. Using newly initalized model.")
+        cfg.impl.checkpoint.name = cfg.name
+        file = os.path.join(cfg.original_cwd, "checkpoints", cfg.impl.checkpoint.name)
+        os.makedirs(os.path.dirname(file), exist_ok=True)
+        _save_to_checkpoint(model, optimizer, scheduler, None, Counter, file=file, engine=eng)
+    file = os.path.join(cfg.original_cwd, "checkpoints", cfg.impl.checkpoint.name)
+
+    def gradient_evaluation():
+        _, model_state, _, _, step = torch.load(file, map_location="cpu", weights_only=False)
+        model.load_state_dict(model_state)
+        eng.load_from_model(model)                       # parameters and BN buffers as in the checkpoint
+        log.info(f"Loaded model checkpoint from step {step} successfully.")
+        lr, gr = optimizer.param_groups[0]["lr"], hyp.grad_reg
+        loss_k, _, _ = eng.full_gradient(trainer.patches, trainer.labels, lr, gr.block_strength, gr.eps, gr.implementation)
+        if hyp.grad_clip is not None:                    # _modify_gradient_params, clip part (reference :198-211)
+            grad_norm = float(eng.grad_and_param_sqnorm()[0].sqrt())
+            if grad_norm > hyp.grad_clip:
+                lib.call("fb_mt_scale", eng.avg.data_ptr(), eng.plan.P, hyp.grad_clip / (grad_norm + 1e-6))
+        return loss_k.mean(), eng.avg.clone()
+
+    loss1, g1 = gradient_evaluation()
+    print(f"Completed first pass with loss {loss1.item()}.")
+    loss2, g2 = gradient_evaluation()
+    print(f"Completed first pass with loss {loss2.item()}.")
+    out = dict(loss=[loss1.item(), loss2.item()],
+               norm_linf=g1.max().item(), norm_l2=g1.double().pow(2).sum().sqrt().item(), norm_l1=g1.double().abs().sum().item(),
+               error_linf=(g1 - g2).max().item(), error_l2=(g1 - g2).double().pow(2).sum().sqrt().item(),
+               error_l1=(g1 - g2).double().abs().sum().item())
+    print(f"Gradient Norms | L^Inf: {out['norm_linf']} | L2: {out['norm_l2']} | L1: {out['norm_l1']}.")
+    print(f"Error in L^inf Norm: Total: {out['error_linf']} | Relative: {out['error_linf'] / out['norm_linf']}.")
+    print(f"Error in L^2 Norm: Total: {out['error_l2']} | Relative: {out['error_l2'] / out['norm_l2']}.")
+    print(f"Error in L^1 Norm: Total: {out['error_l1']} | Relative: {out['error_l1'] / out['norm_l1']}.")
+    return out
 
 
 def train(model, trainloader, validloader, setup, cfg):

@@ -108,3 +108,27 @@ def test_checkpoint_roundtrip_and_reference_layout(golden, tmp_path):
     assert np.allclose(stats2["train_loss"][-1], full[2], rtol=2e-4)
     with pytest.raises(ValueError):
         _run(meta, "fb_clip_warm", ["impl.checkpoint.name=ck.pth", "hyp.steps=3"], tmp_path)
+
+
+@pytest.mark.parametrize("over,clip", [(["hyp=fb1"], False), (["hyp=fbclip", "hyp.grad_clip=0.05"], True),
+                                       (["hyp=gradreg", "hyp.grad_reg.block_strength=0.5", "hyp.warmup=0"], True),
+                                       (["hyp=fb1", "impl.mixed_precision=True"], False)])
+def test_implementation_noise_protocol_is_exactly_zero(over, clip, tmp_path):
+    """SURVEY 8f N2, reference training.py:429-600: two evaluations of the full-batch gradient from the same checkpoint.  The
+    reference measures a run-to-run FP error there (atomics in cuDNN wgrad); here every reduction has a fixed order, so the two
+    gradients (regularised and clipped, f32 and bf16) must be bit-identical."""
+    from fullbatchtraining_amd.cfg import compose
+    from fullbatchtraining_amd.models import construct_model
+    from fullbatchtraining_amd.training import _measure_implementation_noise
+
+    cfg = compose(over + ["data.batch_size=32", "hyp.sub_batch=32", "data.pixels=16", "impl.engine.chunk_group=3", "hyp.steps=4"],
+                  original_cwd=str(tmp_path), name="noise")
+    torch.manual_seed(3)
+    model = construct_model(cfg.model, 3, 10)
+    x, y = make_data(5 * 32, 16)
+    setup = dict(device=torch.device("cuda:0"), dtype=torch.float, memory_format=torch.contiguous_format)
+    out = _measure_implementation_noise(model, (x, y), None, setup, cfg)
+    assert out["error_linf"] == 0.0 and out["error_l2"] == 0.0 and out["error_l1"] == 0.0
+    assert out["loss"][0] == out["loss"][1] and np.isfinite(out["loss"][0]) and out["norm_l2"] > 0
+    if clip:
+        assert out["norm_l2"] <= float(cfg.hyp.grad_clip) * (1 + 1e-5)
