@@ -289,6 +289,30 @@ class FullBatchTrainer:
         return stats
 
 
+def evaluate(model, dataloader, stats, setup, impl, hyp, dryrun=False):
+    """Validation loss / accuracy of a model (signature of reference training.py:343): BN in eval mode (running statistics),
+    mean CE, fraction correct.  Used by verify_model_checkpoint.py; `train` evaluates through its own engine instead."""
+    if stats is None:
+        stats = defaultdict(list)
+    if getattr(hyp, "test_time_flips", False):
+        raise NotImplementedError("test_time_flips")
+    device = setup["device"] if torch.device(setup["device"]).type == "cuda" else torch.device("cuda")
+    X, Y = _stage(dataloader, device)
+    dtype = torch.bfloat16 if impl.mixed_precision else torch.float32
+    batch = min(1024, X.shape[0])
+    eng = Engine(model, X.shape[-1], batch, 1, compute_dtype=dtype, device=device)
+    loss_sum, correct, n = 0.0, 0.0, 0
+    for i in range(0, X.shape[0], batch):
+        xb, yb = X[i:i + batch], Y[i:i + batch]
+        l, c = eng.evaluate_batch(stem_patches(xb, eng.plan.stem, eng.dt), yb)
+        loss_sum, correct, n = loss_sum + l * yb.shape[0], correct + c, n + yb.shape[0]
+        if dryrun:
+            break
+    stats["valid_loss"] += [loss_sum / n]
+    stats["valid_acc"] += [correct / n]
+    return stats
+
+
 def status_message(optimizer, stats, step):
     def last(key):
         return stats[key][-1] if len(stats[key]) > 0 else float("NaN")

@@ -108,6 +108,17 @@ def test_checkpoint_roundtrip_and_reference_layout(golden, tmp_path):
     assert np.allclose(stats2["train_loss"][-1], full[2], rtol=2e-4)
     with pytest.raises(ValueError):
         _run(meta, "fb_clip_warm", ["impl.checkpoint.name=ck.pth", "hyp.steps=3"], tmp_path)
+    # verify_model_checkpoint.py path: load the model state of the file into a fresh container and evaluate it with
+    # the reference-signature `evaluate`: same numbers as the validation pass at the end of the run that wrote the checkpoint
+    from fullbatchtraining_amd.models import construct_model
+    from fullbatchtraining_amd.training import evaluate
+    fresh = construct_model(cfg2.model, 3, 10)
+    fresh.load_state_dict(torch.load(tmp_path / "checkpoints" / "ck.pth", weights_only=False)[1])
+    sc = meta["scenarios"]["fb_clip_warm"]
+    x, y = make_data(sc["n"], sc["pixels"])
+    setup = dict(device=torch.device("cuda:0"), dtype=torch.float, memory_format=torch.contiguous_format)
+    ev = evaluate(fresh, (x[:64], y[:64]), None, setup, cfg2.impl, cfg2.hyp)
+    assert np.allclose(ev["valid_loss"][-1], stats2["valid_loss"][-1], rtol=1e-5) and ev["valid_acc"][-1] == stats2["valid_acc"][-1]
 
 
 @pytest.mark.parametrize("over,clip", [(["hyp=fb1"], False), (["hyp=fbclip", "hyp.grad_clip=0.05"], True),
