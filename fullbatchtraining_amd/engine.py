@@ -122,14 +122,23 @@ class Plan:
         self.fcw_off, self.fcb_off = self.offsets["fc.weight"], self.offsets["fc.bias"]
 
 
-def stem_patches(x_nchw, layer, dtype):
-    """[N,C,H,W] fp32 -> [N,Ho,Wo,cin_pad] patches in tap-major (kh,kw,c) order matching KRSC weights (data staging)."""
-    n, c, _, _ = x_nchw.shape
-    k, s, p = layer.k_orig, layer.stride_orig, layer.pad_orig
-    cols = torch.nn.functional.unfold(x_nchw.float(), kernel_size=k, padding=p, stride=s)  # [N, c*k*k, L], (c,kh,kw) major
-    cols = cols.view(n, c, k * k, layer.hout * layer.wout).permute(0, 3, 2, 1).reshape(n, layer.hout, layer.wout, k * k * c)
-    out = torch.zeros(n, layer.hout, layer.wout, layer.cin_pad, device=x_nchw.device, dtype=dtype)
-    out[..., : k * k * c] = cols.to(dtype)
+def stem_patches(x_nchw, layer, dtype, aug=None, out=None):
+    """[N,C,H,W] fp32 (device) -> [N,Ho,Wo,cin_pad] patches in tap-major (kh,kw,c) order matching the KRSC weights
+    (`fb_stem_patches`).  ``aug = (crop_oy, crop_ox, flip, crop_pad, pad_value)``: per-image int8 device tensors for the on-device
+    RandomCrop(H, crop_pad) / RandomHorizontalFlip (either may be None) and the per-channel value of a black pixel."""
+    if x_nchw.device.type != "cuda":
+        raise lib.EngineError("stem_patches: the patch gather runs on the GPU (no CPU path)")
+    x = x_nchw.float().contiguous()
+    n, c, h, w = x.shape
+    if out is None:
+        out = torch.empty(n, layer.hout, layer.wout, layer.cin_pad, device=x.device, dtype=dtype)
+    oy = ox = fl = pv = None
+    crop_pad = 0
+    if aug is not None:
+        oy, ox, fl, crop_pad, pad_value = aug
+        pv = (lib.c_float * c)(*[float(v) for v in pad_value]) if pad_value is not None else None
+    call("fb_stem_patches", x.data_ptr(), out.data_ptr(), n, c, h, w, layer.k_orig, layer.stride_orig, layer.pad_orig, layer.cin_pad,
+         _ptr(oy), _ptr(ox), _ptr(fl), crop_pad, pv, lib.dtype_code(dtype))
     return out
 
 

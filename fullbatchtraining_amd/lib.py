@@ -42,6 +42,8 @@ _SIGS = {
     "fb_bn_bwd_finalize": [c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                            c_i64, c_void_p, c_void_p],
     "fb_bn_bwd_apply": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_void_p],
+    "fb_stem_patches": [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                        C.POINTER(c_float), c_int, c_void_p],
     "fb_avgpool2_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "fb_maxpool3s2_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "fb_maxpool3s2_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],

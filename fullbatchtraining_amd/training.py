@@ -176,8 +176,35 @@ def _check_scope(cfg):
         raise NotImplementedError("only the global L2 clip (grad_clip_norm=2) is fused")
     if hyp.shuffle:
         raise NotImplementedError("hyp.shuffle=True changes chunk composition every step; resident data is sequential")
-    if cfg.data.get("augmentations_train"):
-        log.warning("data.augmentations_train is set: the device-resident feed stages the loader ONCE (static dataset).")
+
+
+def _device_augmentation(cfg, trainloader):
+    """On-device RandomCrop / RandomHorizontalFlip (reference config/data/CIFAR10.yaml:11-13).  Opt-in with
+    `impl.engine.device_augment=True`: the caller vouches that the feed (tensor pair or loader) yields UN-augmented, normalised
+    images; they stay resident and every step sees a freshly cropped / flipped copy.  Without it a feed is staged once as it comes
+    (static dataset), which is also what the reference runs with `data.augmentations_train=` do.
+    Returns None or dict(crop_pad, flip_p, pad_value)."""
+    aug = cfg.data.get("augmentations_train")
+    if not aug:
+        return None
+    if not bool(cfg.impl.get("engine", {}).get("device_augment", False)):
+        log.warning("data.augmentations_train is set: the device-resident feed stages the loader ONCE (static dataset); "
+                    "impl.engine.device_augment=True augments un-augmented inputs on the device every step.")
+        return None
+    out = dict(crop_pad=0, flip_p=0.0, pad_value=None)
+    for key in aug.keys():
+        if key == "RandomCrop":
+            size, pad = (list(aug[key]) + [0])[:2] if not isinstance(aug[key], int) else (aug[key], 0)
+            if int(size) != int(cfg.data.pixels):
+                raise NotImplementedError(f"RandomCrop to {size} != data.pixels {cfg.data.pixels}")
+            out["crop_pad"] = int(pad)
+        elif key == "RandomHorizontalFlip":
+            out["flip_p"] = float(aug[key])
+        else:
+            raise NotImplementedError(f"data.augmentations_train.{key}: only RandomCrop and RandomHorizontalFlip run on the device")
+    if cfg.data.get("normalize", False):       # RandomCrop pads the raw image with black; the tensors here are normalised
+        out["pad_value"] = [-float(m) / float(sd) for m, sd in zip(cfg.data.mean, cfg.data.std)]
+    return out
 
 
 class FullBatchTrainer:
@@ -212,7 +239,12 @@ class FullBatchTrainer:
         self.engine = Engine(model, X.shape[-1], self.chunk, G, compute_dtype=self.dtype, device=self.device, fd_sets=fd_sets)
         stem = self.engine.plan.stem
         lo, hi = self.shard.first * self.chunk, (self.shard.first + self.shard.count) * self.chunk
-        self.patches = torch.cat([stem_patches(X[i:min(i + 4096, hi)], stem, self.dtype) for i in range(lo, hi, 4096)]) if hi > lo else None
+        self.patches = torch.empty(hi - lo, stem.hout, stem.wout, stem.cin_pad, device=self.device, dtype=self.dtype) if hi > lo else None
+        self.augment = _device_augmentation(cfg, trainloader)
+        self.images = X[lo:hi].float().contiguous() if (self.augment is not None and hi > lo) else None   # base images stay resident
+        self._aug_step, self._n_total, self._lo = 0, X.shape[0], lo
+        if hi > lo and self.augment is None:
+            stem_patches(X[lo:hi], stem, self.dtype, out=self.patches)
         self.labels = Y[lo:hi].contiguous()
         self.valid = _stage(validloader, self.device) if validloader is not None else None
         self.stats = defaultdict(list)
@@ -222,6 +254,8 @@ class FullBatchTrainer:
         """One optimizer step = the reference's ``optimizer.step(gradient_evaluation)`` (training.py:226-237)."""
         cfg, eng, hyp = self.cfg, self.engine, self.cfg.hyp
         train_time = time.time()
+        if self.augment is not None and self.images is not None:
+            self._regather_augmented()
         lr = self.optimizer.param_groups[0]["lr"]
         gr = hyp.grad_reg
         if self.world > 1:
@@ -236,6 +270,23 @@ class FullBatchTrainer:
             eng.sgd_step(lr, o.weight_decay, o.momentum, o.dampening, o.nesterov, hyp.grad_clip)
         self._record_stats(loss_k, correct_k, sq_k, eng.norms2, lr, train_time)
         self.scheduler.step()
+
+    def _regather_augmented(self):
+        """A fresh RandomCrop offset / flip per image and step (the reference draws them in its DataLoader workers once per epoch =
+        step); drawn for the WHOLE dataset from one seeded CPU generator so that a rank's images get the same augmentation however
+        the chunks are sharded, then the stem patches of this rank's images are gathered again on the device."""
+        a = self.augment
+        seed = self.cfg.seed if getattr(self.cfg, "seed", None) is not None else 0
+        gen = torch.Generator().manual_seed(1_000_003 * int(seed) + self._aug_step)
+        self._aug_step += 1
+        n, lo = self.images.shape[0], self._lo
+        oy = ox = fl = None
+        if a["crop_pad"] > 0:
+            off = torch.randint(0, 2 * a["crop_pad"] + 1, (2, self._n_total), generator=gen, dtype=torch.int8)
+            oy, ox = (off[i, lo:lo + n].to(self.device) for i in range(2))
+        if a["flip_p"] > 0:
+            fl = (torch.rand(self._n_total, generator=gen) < a["flip_p"]).to(torch.int8)[lo:lo + n].to(self.device)
+        stem_patches(self.images, self.engine.plan.stem, self.dtype, aug=(oy, ox, fl, a["crop_pad"], a["pad_value"]), out=self.patches)
 
     def _record_stats(self, loss_k, correct_k, sq_k, norms2, lr, train_time):
         """Same keys/formulas as reference training.py:85-119 and :205-211 (one host sync per step, after the update is queued)."""

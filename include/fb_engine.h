@@ -127,6 +127,17 @@ int fb_bn_bwd_finalize(const float* partial, int32_t n_mblocks, int32_t n_groups
 int fb_bn_bwd_apply(const void* dout, const void* y, const void* mask, const void* x, const float* coef, void* dx, void* dy_out,
                     int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t dtype, void* stream);
 
+/* ---------------------------------------------------------------- data path --------------------------------------- */
+/* Stem patch gather: images [n_img][C][H][W] fp32 (device) -> patches [n_img][Ho][Wo][cin_pad] in `dtype`, element tap*C + c
+ * (tap-major like the KRSC weights), zero beyond k*k*C and outside the image (the convolution's own zero padding); the stem
+ * convolution (resnets.py:150 / :179) then runs as a 1x1 convolution over these rows.
+ * Optional on-device augmentation (config/data/CIFAR10.yaml:11-13: RandomCrop(H, crop_pad) then RandomHorizontalFlip):
+ * crop_oy/crop_ox [n_img] int8 in [0, 2*crop_pad] (device; both or neither), flip [n_img] int8 0/1 (device, optional);
+ * pad_value: HOST array of C floats = value of a black pixel after normalisation (-mean/std), NULL = 0. */
+int fb_stem_patches(const float* images, void* patches, int64_t n_img, int32_t C, int32_t H, int32_t W, int32_t k, int32_t stride,
+                    int32_t pad, int32_t cin_pad, const int8_t* crop_oy, const int8_t* crop_ox, const int8_t* flip, int32_t crop_pad,
+                    const float* pad_value, int32_t dtype, void* stream);
+
 /* ---------------------------------------------------------------- pooling / head --------------------------------- */
 int fb_avgpool2_fwd(const void* x, void* y, int32_t n_img, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
 /* MaxPool2d(3,2,1) of the 'standard' stem (resnets.py:78); bwd scatters through recomputed argmax */

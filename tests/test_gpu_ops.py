@@ -361,3 +361,51 @@ def test_multi_tensor_ops():
         assert torch.allclose(td.cpu(), theta, rtol=1e-5, atol=1e-6) and torch.allclose(md.cpu(), mom, rtol=1e-5, atol=1e-7)
         assert torch.allclose(grd.cpu(), grad, rtol=1e-6, atol=1e-9)
         lib.call("fb_mt_norms2", grd.data_ptr(), td.data_ptr(), P, n2.data_ptr(), ws.data_ptr())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k,stride,pad,hw,cin_pad,aug", [(3, 1, 1, 32, 32, False), (3, 1, 1, 32, 32, True), (7, 2, 3, 64, 160, False),
+                                                         (3, 1, 1, 16, 64, True)])
+def test_stem_patches_and_device_augmentation(dtype, k, stride, pad, hw, cin_pad, aug):
+    """fb_stem_patches vs torch: unfold of the (augmented) image; augmentation = torchvision's RandomCrop(hw, 4) on the image
+    padded with black (-mean/std after normalisation), then RandomHorizontalFlip, with given per-image draws."""
+    lib = _lib()
+    torch.manual_seed(12)
+    n, c, cp = 9, 3, 4
+    x = torch.randn(n, c, hw, hw)
+    pv = [-0.49 / 0.25, -0.48 / 0.24, -0.45 / 0.26]
+    ref_img = x
+    oy = ox = fl = None
+    if aug:
+        oy, ox = torch.randint(0, 2 * cp + 1, (2, n), dtype=torch.int8)
+        fl = (torch.rand(n) < 0.5).to(torch.int8)
+        padded = torch.empty(n, c, hw + 2 * cp, hw + 2 * cp)
+        for ch in range(c):
+            padded[:, ch] = pv[ch]
+        padded[:, :, cp:cp + hw, cp:cp + hw] = x
+        ref_img = torch.stack([padded[i, :, int(oy[i]):int(oy[i]) + hw, int(ox[i]):int(ox[i]) + hw] for i in range(n)])
+        ref_img = torch.stack([im.flip(-1) if int(fl[i]) else im for i, im in enumerate(ref_img)])
+    ho = (hw + 2 * pad - k) // stride + 1
+    cols = F.unfold(ref_img, kernel_size=k, padding=pad, stride=stride).view(n, c, k * k, ho * ho).permute(0, 3, 2, 1).reshape(n, ho, ho, k * k * c)
+    ref = torch.zeros(n, ho, ho, cin_pad)
+    ref[..., : k * k * c] = cols
+    out = torch.full((n, ho, ho, cin_pad), float("nan"), device="cuda").to(dtype)
+    pvc = (lib.c_float * c)(*pv) if aug else None
+    xd = x.cuda()                                   # (kept alive: the call only sees its address)
+    lib.call("fb_stem_patches", xd.data_ptr(), out.data_ptr(), n, c, hw, hw, k, stride, pad, cin_pad,
+             _dp(oy), _dp(ox), _dp(fl), cp if aug else 0, pvc, lib.dtype_code(dtype))
+    got, want = out.float().cpu(), q(ref, dtype)
+    bad = (got != want).nonzero()
+    assert bad.shape[0] == 0, (bad.shape[0], bad[:6].tolist(), [float(got[tuple(b)]) for b in bad[:6]], [float(want[tuple(b)]) for b in bad[:6]],
+                               None if oy is None else (oy.tolist(), ox.tolist(), fl.tolist()))
+
+
+_KEEP = []
+
+
+def _dp(t):
+    if t is None:
+        return None
+    d = t.cuda()
+    _KEEP.append(d)
+    return d.data_ptr()

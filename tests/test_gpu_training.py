@@ -143,3 +143,33 @@ def test_implementation_noise_protocol_is_exactly_zero(over, clip, tmp_path):
     assert out["loss"][0] == out["loss"][1] and np.isfinite(out["loss"][0]) and out["norm_l2"] > 0
     if clip:
         assert out["norm_l2"] <= float(cfg.hyp.grad_clip) * (1 + 1e-5)
+
+
+def test_device_augmentation_changes_the_feed_every_step(tmp_path):
+    """impl.engine.device_augment=True (SURVEY 8f N3): every step trains on a freshly cropped / flipped copy of the resident images;
+    the run is reproducible for a given seed, differs from the static-feed run, and the patches are valid crops (ops test)."""
+    from fullbatchtraining_amd.cfg import compose
+    from fullbatchtraining_amd.models import construct_model
+    from fullbatchtraining_amd.training import FullBatchTrainer
+
+    def run(extra):
+        cfg = compose(["hyp=fb1", "hyp.steps=3", "hyp.warmup=0", "data.batch_size=32", "hyp.sub_batch=32", "impl.engine.chunk_group=2"] + extra,
+                      original_cwd=str(tmp_path), name="aug", seed=5)
+        torch.manual_seed(3)
+        model = construct_model(cfg.model, 3, 10)
+        x, y = make_data(4 * 32, 32)
+        setup = dict(device=torch.device("cuda:0"), dtype=torch.float, memory_format=torch.contiguous_format)
+        tr = FullBatchTrainer(model, (x, y), None, setup, cfg)
+        feeds = []
+        for _ in range(3):
+            tr.step()
+            feeds.append(tr.patches.float().cpu().clone())
+        return tr.stats["train_loss"], feeds
+
+    loss_a, feeds_a = run(["impl.engine.device_augment=True"])
+    loss_b, feeds_b = run(["impl.engine.device_augment=True"])
+    loss_s, feeds_s = run([])
+    assert loss_a == loss_b and all(torch.equal(a, b) for a, b in zip(feeds_a, feeds_b))          # reproducible
+    assert not torch.equal(feeds_a[0], feeds_a[1]) and not torch.equal(feeds_a[1], feeds_a[2])      # new draw every step
+    assert torch.equal(feeds_s[0], feeds_s[2]) and not torch.equal(feeds_s[0], feeds_a[0])          # static feed without the switch
+    assert loss_a[0] != loss_s[0] and all(np.isfinite(loss_a))
