@@ -18,8 +18,9 @@ __global__ void mt_finalize_kernel(const float* __restrict__ ws, float* __restri
     out[i] = (float)s;
 }
 
-// ---- |scale*x[g]|^2 -----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mt_sqnorm_kernel(const float* __restrict__ x, long long gstride, long long n, float scale, float* __restrict__ ws) {
+// ---- |scale*x[g] + add_scale*add|^2 ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mt_sqnorm_kernel(const float* __restrict__ x, long long gstride, long long n, float scale,
+                                                        const float* __restrict__ add, float add_scale, float* __restrict__ ws) {
     __shared__ float sm[8];
     const int g = blockIdx.y;
     const float* xg = x + (long long)g * gstride;
@@ -27,19 +28,23 @@ __global__ __launch_bounds__(256) void mt_sqnorm_kernel(const float* __restrict_
     const long long n4 = n / 4;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         const float4 v = ((const float4*)xg)[i];
-        const float a = v.x * scale, b = v.y * scale, c = v.z * scale, d = v.w * scale;
+        float a = v.x * scale, b = v.y * scale, c = v.z * scale, d = v.w * scale;
+        if (add) { const float4 p = ((const float4*)add)[i]; a += add_scale * p.x; b += add_scale * p.y; c += add_scale * p.z; d += add_scale * p.w; }
         acc[0] += a * a + b * b + c * c + d * d;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) for (long long i = n4 * 4; i < n; ++i) { const float a = xg[i] * scale; acc[0] += a * a; }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (long long i = n4 * 4; i < n; ++i) { const float a = xg[i] * scale + (add ? add_scale * add[i] : 0.f); acc[0] += a * a; }
     block_reduce_sum<1>(acc, sm);
     if (threadIdx.x == 0) ws[(long long)g * FB_MT_BLOCKS + blockIdx.x] = acc[0];
 }
 
-extern "C" int fb_mt_sqnorm(const float* x, int64_t group_stride, int32_t n_groups, int64_t n, float scale, float* out, float* ws, void* stream) {
+extern "C" int fb_mt_sqnorm(const float* x, int64_t group_stride, int32_t n_groups, int64_t n, float scale, const float* add, float add_scale,
+                            float* out, float* ws, void* stream) {
     if (!x || !out || !ws) FB_FAIL(FB_ERR_ARG, "fb_mt_sqnorm: null pointer");
-    if (((uintptr_t)x & 15) || (group_stride & 3)) FB_FAIL(FB_ERR_ARG, "fb_mt_sqnorm: 16-byte alignment required");
+    if (((uintptr_t)x & 15) || ((uintptr_t)add & 15) || (group_stride & 3)) FB_FAIL(FB_ERR_ARG, "fb_mt_sqnorm: 16-byte alignment required");
     const int nb = mt_blocks(n);
-    hipLaunchKernelGGL(mt_sqnorm_kernel, dim3(nb, n_groups), dim3(256), 0, (hipStream_t)stream, x, (long long)group_stride, (long long)n, scale, ws);
+    hipLaunchKernelGGL(mt_sqnorm_kernel, dim3(nb, n_groups), dim3(256), 0, (hipStream_t)stream, x, (long long)group_stride, (long long)n, scale, add,
+                       add_scale, ws);
     hipLaunchKernelGGL(mt_finalize_kernel, dim3((n_groups + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, out, nb, n_groups);
     FB_CHECK_LAUNCH("fb_mt_sqnorm");
     return FB_OK;
@@ -110,31 +115,34 @@ extern "C" int fb_mt_accumulate(float* avg, const float* g, int64_t group_stride
     return FB_OK;
 }
 
-// ---- finite-difference perturbation: theta[g] = theta0 + sign*eps_n[g]*(s*g[g]) -------------------------------------------
+// ---- finite-difference perturbation: theta[g] = theta0 + sign*eps_n[g]*(s*g[g] + acc*pre) ---------------------------------
 __global__ void mt_epsn_kernel(const float* __restrict__ vnorm2, float eps, float* __restrict__ eps_n, int n_groups) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < n_groups) eps_n[g] = eps / sqrtf(vnorm2[g]);
 }
 __global__ __launch_bounds__(256) void mt_fd_perturb_kernel(const float* __restrict__ theta0, const float* __restrict__ g, long long gstride,
                                                             long long n, float s, float sign, const float* __restrict__ eps_n,
-                                                            float* __restrict__ out) {
+                                                            const float* __restrict__ pre, float acc, float* __restrict__ out) {
     const int grp = blockIdx.y;
     const float alpha = sign * eps_n[grp];
     const float* gg = g + (long long)grp * gstride; float* og = out + (long long)grp * gstride;
     const long long n4 = n / 4;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         const float4 t = ((const float4*)theta0)[i], v = ((const float4*)gg)[i];
-        ((float4*)og)[i] = make_float4(t.x + alpha * (s * v.x), t.y + alpha * (s * v.y), t.z + alpha * (s * v.z), t.w + alpha * (s * v.w));
+        float4 w = make_float4(s * v.x, s * v.y, s * v.z, s * v.w);
+        if (pre) { const float4 q = ((const float4*)pre)[i]; w.x += acc * q.x; w.y += acc * q.y; w.z += acc * q.z; w.w += acc * q.w; }
+        ((float4*)og)[i] = make_float4(t.x + alpha * w.x, t.y + alpha * w.y, t.z + alpha * w.z, t.w + alpha * w.w);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) for (long long i = n4 * 4; i < n; ++i) og[i] = theta0[i] + alpha * (s * gg[i]);
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (long long i = n4 * 4; i < n; ++i) og[i] = theta0[i] + alpha * (s * gg[i] + (pre ? acc * pre[i] : 0.f));
 }
 
 extern "C" int fb_mt_fd_perturb(const float* theta0, const float* g, int64_t group_stride, int32_t n_groups, int64_t n, float s, float eps,
-                                float sign, const float* vnorm2, float* eps_n, float* theta_out, void* stream) {
+                                float sign, const float* vnorm2, float* eps_n, const float* pre, float acc, float* theta_out, void* stream) {
     if (!theta0 || !g || !vnorm2 || !eps_n || !theta_out) FB_FAIL(FB_ERR_ARG, "fb_mt_fd_perturb: null pointer");
     hipLaunchKernelGGL(mt_epsn_kernel, dim3((n_groups + 63) / 64), dim3(64), 0, (hipStream_t)stream, vnorm2, eps, eps_n, n_groups);
     hipLaunchKernelGGL(mt_fd_perturb_kernel, dim3(mt_blocks(n), n_groups), dim3(256), 0, (hipStream_t)stream, theta0, g, (long long)group_stride,
-                       (long long)n, s, sign, eps_n, theta_out);
+                       (long long)n, s, sign, eps_n, pre, acc, theta_out);
     FB_CHECK_LAUNCH("fb_mt_fd_perturb");
     return FB_OK;
 }

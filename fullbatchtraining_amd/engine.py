@@ -570,7 +570,7 @@ class Engine:
 
     # --------------------------------------------------------------------------------------- full-batch gradient + step --
     def full_gradient(self, patches, labels, lr, block_strength=0.0, eps=1e-2, implementation="forward-differences",
-                      chunk_ids=None, counter0=0):
+                      chunk_ids=None, counter0=0, acc_strength=0.0):
         """Accumulate the regularised gradient over chunks (reference training.py:144-174) into ``self.avg``.
 
         ``patches``/``labels`` hold the whole resident dataset; chunk k = rows [k*chunk, (k+1)*chunk).  ``chunk_ids``
@@ -581,7 +581,7 @@ class Engine:
         k_first = 0 if chunk_ids is None else chunk_ids[0]
         f32 = dict(device=self.device, dtype=torch.float32)
         loss_all, correct_all, sq_all = torch.empty(n_chunks, **f32), torch.empty(n_chunks, **f32), torch.empty(n_chunks, **f32)
-        fd = block_strength != 0
+        fd = block_strength != 0 or acc_strength != 0          # GradRegularizer.__init__, modules.py:150-152
         if fd:
             if implementation not in ("forward-differences", "forward-differences-legacy", "central-differences"):
                 raise NotImplementedError(f"grad_reg.implementation={implementation!r} needs double backward; the engine implements the "
@@ -592,6 +592,24 @@ class Engine:
         if counter0 == 0:
             self.avg.zero_()
         self.prep_weights(self.theta, 1)
+        pre = None
+        if acc_strength != 0:
+            # pre-pass (reference training.py:128-142): the plain full-batch gradient at theta, needed as a whole before the first
+            # chunk is regularised.  It is a train-mode pass of its own: the BN running statistics take one more update per chunk
+            if getattr(self, "pre", None) is None:
+                self.pre = torch.zeros(P, **f32)
+            pre = self.pre
+            pre.zero_()
+            done = 0
+            while done < n_chunks:
+                g_n = min(G, n_chunks - done)
+                lo = (k_first + done) * chunk
+                self.group_gradient(patches[lo:lo + g_n * chunk], labels[lo:lo + g_n * chunk], g_n, self.g, 1, self.theta, 0)
+                call("fb_mt_accumulate", pre.data_ptr(), self.g.data_ptr(), P, g_n, P, done, None, self.mt_ws.data_ptr())
+                call("fb_bn_running_update", self.running_mean.data_ptr(), self.running_var.data_ptr(), self.mean_tab.data_ptr(),
+                     self.var_tab.data_ptr(), 1, self.G * self.plan.ch_total, self.unbias.data_ptr(), g_n, self.plan.ch_total, BN_MOMENTUM)
+                self.num_batches_tracked += g_n
+                done += g_n
         done = 0
         while done < n_chunks:
             g_n = min(G, n_chunks - done)
@@ -609,16 +627,18 @@ class Engine:
                 central = implementation == "central-differences"
                 s = 1.0 if legacy else float(block_strength)
                 cf = lr / 4 * (block_strength if legacy else 1.0)
-                call("fb_mt_sqnorm", self.g.data_ptr(), P, g_n, P, 1.0, self.sq.data_ptr(), self.mt_ws.data_ptr())
-                call("fb_mt_sqnorm", self.g.data_ptr(), P, g_n, P, s, self.vnorm2.data_ptr(), self.mt_ws.data_ptr())
+                # finite-difference direction v = s*g_k + acc*pre (modules.py:217-221; the legacy variant ignores pre, :243-245)
+                vpre, vacc = (None, 0.0) if (legacy or pre is None) else (pre.data_ptr(), float(acc_strength))
+                call("fb_mt_sqnorm", self.g.data_ptr(), P, g_n, P, 1.0, None, 0.0, self.sq.data_ptr(), self.mt_ws.data_ptr())
+                call("fb_mt_sqnorm", self.g.data_ptr(), P, g_n, P, s, vpre, vacc, self.vnorm2.data_ptr(), self.mt_ws.data_ptr())
                 call("fb_mt_fd_perturb", self.theta.data_ptr(), self.g.data_ptr(), P, g_n, P, s, float(eps), 0.5 if central else 1.0,
-                     self.vnorm2.data_ptr(), self.eps_n.data_ptr(), self.theta_k.data_ptr())
+                     self.vnorm2.data_ptr(), self.eps_n.data_ptr(), vpre, vacc, self.theta_k.data_ptr())
                 self.prep_weights(self.theta_k, g_n, per_chunk=True)
                 self.group_gradient(xb, yb, g_n, self.g_fd[0], 2, self.theta_k, 1)
                 n_passes = 2
                 if central:
                     call("fb_mt_fd_perturb", self.theta.data_ptr(), self.g.data_ptr(), P, g_n, P, s, float(eps), -0.5,
-                         self.vnorm2.data_ptr(), self.eps_n.data_ptr(), self.theta_k.data_ptr())
+                         self.vnorm2.data_ptr(), self.eps_n.data_ptr(), vpre, vacc, self.theta_k.data_ptr())
                     self.prep_weights(self.theta_k, g_n, per_chunk=True)
                     self.group_gradient(xb, yb, g_n, self.g_fd[1], 2, self.theta_k, 2)
                     n_passes = 3

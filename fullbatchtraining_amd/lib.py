@@ -52,9 +52,10 @@ _SIGS = {
                      c_void_p],
     "fb_head_bwd": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                     c_void_p],
-    "fb_mt_sqnorm": [c_void_p, c_i64, c_int, c_i64, c_float, c_void_p, c_void_p, c_void_p],
+    "fb_mt_sqnorm": [c_void_p, c_i64, c_int, c_i64, c_float, c_void_p, c_float, c_void_p, c_void_p, c_void_p],
     "fb_mt_accumulate": [c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_void_p, c_void_p, c_void_p],
-    "fb_mt_fd_perturb": [c_void_p, c_void_p, c_i64, c_int, c_i64, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
+    "fb_mt_fd_perturb": [c_void_p, c_void_p, c_i64, c_int, c_i64, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+                         c_void_p],
     "fb_mt_fd_combine_accumulate": [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_void_p, c_float, c_int, c_void_p],
     "fb_mt_norms2": [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p],
     "fb_mt_clip_sgd": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_float, c_float, c_float, c_float, c_float, c_int, c_int, c_void_p],

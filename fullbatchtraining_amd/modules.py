@@ -60,8 +60,6 @@ class GradRegularizer:
 
     @torch.no_grad()
     def _finite_differences(self, grads, inputs, labels, pre_grads):
-        if pre_grads is not None or self.acc_strength != 0:
-            raise NotImplementedError("acc_strength / pre_grads (full-gradient pre-pass) is not implemented")
         eng = self._engine(inputs)
         P = eng.plan.P
         eng.load_from_model(self.model)
@@ -73,11 +71,16 @@ class GradRegularizer:
         cf = lr / 4 * (self.block_strength if legacy else 1.0)
         patches = stem_patches(inputs.float(), eng.plan.stem, torch.float32)
         labels = labels.to(dtype=torch.long)
-        call("fb_mt_sqnorm", eng.g.data_ptr(), P, 1, P, s, eng.vnorm2.data_ptr(), eng.mt_ws.data_ptr())
+        # direction v = s*g + acc_strength*pre_grads (modules.py:217-221); the legacy variant disregards pre_grads (:243-245)
+        vpre, vacc = None, 0.0
+        if pre_grads is not None and not legacy:
+            pre = eng.flatten([g.detach() for g in pre_grads]).to(eng.device)
+            vpre, vacc = pre.data_ptr(), float(self.acc_strength)
+        call("fb_mt_sqnorm", eng.g.data_ptr(), P, 1, P, s, vpre, vacc, eng.vnorm2.data_ptr(), eng.mt_ws.data_ptr())
         passes = [(0.5, 0), (-0.5, 1)] if central else [(1.0, 0)]
         for sign, slot in passes:
             call("fb_mt_fd_perturb", eng.theta.data_ptr(), eng.g.data_ptr(), P, 1, P, s, float(self.eps), sign, eng.vnorm2.data_ptr(),
-                 eng.eps_n.data_ptr(), eng.theta_k.data_ptr())
+                 eng.eps_n.data_ptr(), vpre, vacc, eng.theta_k.data_ptr())
             eng.prep_weights(eng.theta_k, 1, per_chunk=True)
             eng.group_gradient(patches, labels, 1, eng.g_fd[slot], 2, eng.theta_k, 1 + slot)
         eng.avg.zero_()

@@ -168,7 +168,11 @@ def _check_scope(cfg):
     if hyp.train_stochastic or hyp.train_switch_stochastic is not None:
         raise NotImplementedError("the engine implements the full-batch branch (hyp.train_stochastic=False) only")
     if hyp.grad_reg.acc_strength != 0:
-        raise NotImplementedError("grad_reg.acc_strength != 0 (pre-pass over the dataset) is not implemented yet")
+        if max(cfg.data.batch_size // hyp.sub_batch, 1) != 1:
+            raise NotImplementedError("grad_reg.acc_strength with sub_batch < batch_size: the reference's pre-pass runs whole blocks "
+                                      "(other BN batches than the main loop)")
+        if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            raise NotImplementedError("grad_reg.acc_strength in the sharded path")
     if hyp.batch_clip is not None or hyp.norm_bias.strength > 0 or hyp.grad_noise["additive"] is not None \
             or hyp.grad_noise["multiplicative"] is not None or hyp.evaluate_ema:
         raise NotImplementedError("batch_clip / norm_bias / grad_noise / EMA evaluation are off the hot path")
@@ -229,9 +233,10 @@ class FullBatchTrainer:
         self.datapoints = self.n_chunks * self.chunk
         s = cfg.hyp.grad_reg.block_strength
         impl = cfg.hyp.grad_reg.implementation
-        fd_sets = 0 if s == 0 else (2 if impl == "central-differences" else 1)
-        self.dtype = torch.bfloat16 if (cfg.impl.mixed_precision and s == 0) else torch.float32
-        if cfg.impl.mixed_precision and s != 0:
+        fd = s != 0 or cfg.hyp.grad_reg.acc_strength != 0
+        fd_sets = 0 if not fd else (2 if impl == "central-differences" else 1)
+        self.dtype = torch.bfloat16 if (cfg.impl.mixed_precision and not fd) else torch.float32
+        if cfg.impl.mixed_precision and fd:
             log.warning("grad_reg finite differences need matching fp32 passes (perturbation ~1e-6 per weight): running fp32.")
         from .parallel import ShardPlan, group_size
         self.shard = ShardPlan(self.n_chunks, self.world, self.rank)
@@ -260,7 +265,12 @@ class FullBatchTrainer:
         gr = hyp.grad_reg
         if self.world > 1:
             self._running0 = torch.stack([eng.running_mean, eng.running_var]).clone()
-        loss_k, correct_k, sq_k = eng.full_gradient(self.patches, self.labels, lr, gr.block_strength, gr.eps, gr.implementation)
+        loss_k, correct_k, sq_k = eng.full_gradient(self.patches, self.labels, lr, gr.block_strength, gr.eps, gr.implementation,
+                                                    acc_strength=gr.acc_strength)
+        self._pre_sqnorm = None
+        if gr.acc_strength != 0:             # |pre_grads|^2 for full_loss (reference training.py:98-101)
+            lib.call("fb_mt_norms2", eng.pre.data_ptr(), None, eng.plan.P, eng.norms2.data_ptr(), eng.mt_ws.data_ptr())
+            self._pre_sqnorm = eng.norms2[0:1].clone()
         if self.world > 1:
             from .parallel import sharded_update
             loss_k, correct_k, sq_k = sharded_update(self, loss_k, correct_k, sq_k, lr)
@@ -291,9 +301,10 @@ class FullBatchTrainer:
     def _record_stats(self, loss_k, correct_k, sq_k, norms2, lr, train_time):
         """Same keys/formulas as reference training.py:85-119 and :205-211 (one host sync per step, after the update is queued)."""
         hyp, stats = self.cfg.hyp, self.stats
-        host = torch.cat([loss_k, correct_k, sq_k, norms2]).cpu()
+        pre2 = self._pre_sqnorm if getattr(self, "_pre_sqnorm", None) is not None else torch.zeros(1, device=norms2.device)
+        host = torch.cat([loss_k, correct_k, sq_k, norms2, pre2]).cpu()
         K = self.n_chunks
-        loss_k, correct_k, sq_k, (gn2, pn2) = host[:K], host[K:2 * K], host[2 * K:3 * K], host[3 * K:3 * K + 2]
+        loss_k, correct_k, sq_k, (gn2, pn2), pre2 = host[:K], host[K:2 * K], host[2 * K:3 * K], host[3 * K:3 * K + 2], host[3 * K + 2]
         for idx, entry in enumerate(sq_k.sqrt().tolist()):
             stats[f"grad_norm_train_{idx}"] += [entry]
         step_loss = torch.zeros(())
@@ -305,6 +316,8 @@ class FullBatchTrainer:
         full_loss = train_loss + 0.5 * getattr(hyp.optim, "weight_decay", 0.0) * param_norm
         if hyp.grad_reg.block_strength != 0:
             full_loss = full_loss + lr / 4 * hyp.grad_reg.block_strength * full_grad_norm
+        if hyp.grad_reg.acc_strength != 0:
+            full_loss = full_loss + lr / 4 * hyp.grad_reg.acc_strength * pre2
         stats["train_loss"] += [train_loss.item()]
         stats["train_acc"] += [correct_k.sum().item() / self.datapoints]
         stats["train_time"] += [time.time() - train_time]
@@ -400,7 +413,8 @@ def _measure_implementation_noise(model, trainloader, validloader, setup, cfg):
         eng.load_from_model(model)                       # parameters and BN buffers as in the checkpoint
         log.info(f"Loaded model checkpoint from step {step} successfully.")
         lr, gr = optimizer.param_groups[0]["lr"], hyp.grad_reg
-        loss_k, _, _ = eng.full_gradient(trainer.patches, trainer.labels, lr, gr.block_strength, gr.eps, gr.implementation)
+        loss_k, _, _ = eng.full_gradient(trainer.patches, trainer.labels, lr, gr.block_strength, gr.eps, gr.implementation,
+                                         acc_strength=gr.acc_strength)
         if hyp.grad_clip is not None:                    # _modify_gradient_params, clip part (reference :198-211)
             grad_norm = float(eng.grad_and_param_sqnorm()[0].sqrt())
             if grad_norm > hyp.grad_clip:

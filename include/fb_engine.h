@@ -157,18 +157,21 @@ int fb_head_bwd(const float* feat, const float* dlogits, const float* fc_w, int6
                 int32_t C, int32_t classes, int32_t dtype, void* stream);
 
 /* ---------------------------------------------------------------- multi-tensor (flat fp32 arena) ------------------ */
-/* out[g] = sum_i (scale*x[g][i])^2, deterministic two-stage.  ws: n_groups*FB_MT_BLOCKS floats.
- * (g.pow(2).sum() stack-sum, training.py:162 / modules.py:223) */
+/* out[g] = sum_i (scale*x[g][i] + add_scale*add[i])^2 (add optional, shared by the groups), deterministic two-stage.
+ * ws: n_groups*FB_MT_BLOCKS floats.  (g.pow(2).sum() stack-sum, training.py:162; norm of the finite-difference direction
+ * block_strength*g + acc_strength*pre_grads, modules.py:217-223) */
 #define FB_MT_BLOCKS 1024
-int fb_mt_sqnorm(const float* x, int64_t group_stride, int32_t n_groups, int64_t n, float scale, float* out, float* ws,
-                 void* stream);
+int fb_mt_sqnorm(const float* x, int64_t group_stride, int32_t n_groups, int64_t n, float scale, const float* add, float add_scale,
+                 float* out, float* ws, void* stream);
 /* running mean over chunks (_stable_mean_accumulation, training.py:45-47): for j: avg += (g[j]-avg)/(counter0+j+1).
  * If sq_out != NULL also writes sq_out[j] = |g[j]|^2 (fused, one pass). */
 int fb_mt_accumulate(float* avg, const float* g, int64_t group_stride, int32_t n_groups, int64_t n, int32_t counter0,
                      float* sq_out, float* ws, void* stream);
-/* eps_n[g] = eps / sqrt(vnorm2[g]);  theta_out[g] = theta0 + (sign*eps_n[g]) * (s*g[g])   (modules.py:217-226) */
+/* eps_n[g] = eps / sqrt(vnorm2[g]);  theta_out[g] = theta0 + (sign*eps_n[g]) * (s*g[g] + acc*pre)   (modules.py:217-226;
+ * pre = the pre-computed full gradient of the acc_strength pre-pass, training.py:128-142, NULL without it) */
 int fb_mt_fd_perturb(const float* theta0, const float* g, int64_t group_stride, int32_t n_groups, int64_t n, float s,
-                     float eps, float sign, const float* vnorm2, float* eps_n, float* theta_out, void* stream);
+                     float eps, float sign, const float* vnorm2, float* eps_n, const float* pre, float acc, float* theta_out,
+                     void* stream);
 /* vhp = (ga - gb)/eps_n[g]; gt = g + cf*vhp; avg += (gt-avg)/(counter0+j+1)   (modules.py:232-240 + training.py:45-47) */
 int fb_mt_fd_combine_accumulate(float* avg, const float* g, const float* ga, const float* gb, int64_t group_stride,
                                 int32_t n_groups, int64_t n, const float* eps_n, float cf, int32_t counter0, void* stream);

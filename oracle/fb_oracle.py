@@ -335,14 +335,16 @@ IMPLEMENTATIONS = (
 )
 
 
-def gradreg(spec, params, buffers, grads, x, y, lr, block_strength, eps, implementation, q=identity):
+def gradreg(spec, params, buffers, grads, x, y, lr, block_strength, eps, implementation, q=identity, acc_strength=0.0, pre_grads=None):
     """In-place modification of ``grads`` for one chunk; mirrors modules.py:211-241 / 243-264 / 266-300.
 
     Parameters are perturbed in place and restored exactly like the reference (clone/copy, or subtract for legacy).
-    BN running statistics are updated again by every extra forward.
+    BN running statistics are updated again by every extra forward.  ``pre_grads`` (the full gradient of the
+    acc_strength pre-pass, training.py:128-142) joins the finite-difference direction: v = block_strength*g + acc_strength*pre
+    (modules.py:217-221, 273-275); the legacy variant disregards it (modules.py:243-245).
     """
-    if block_strength == 0:
-        return grads  # _pass, modules.py:177-178
+    if block_strength == 0 and acc_strength == 0:
+        return grads  # _pass, modules.py:150-152,177-178
     if implementation not in IMPLEMENTATIONS:
         raise ValueError(f"Invalid spec. given for regularizer implementation: {implementation}")
     plist = list(params.values())
@@ -350,6 +352,9 @@ def gradreg(spec, params, buffers, grads, x, y, lr, block_strength, eps, impleme
     if implementation == "forward-differences":
         original = [p.clone() for p in plist]
         vec = [g * block_strength for g in grads]
+        if pre_grads is not None:
+            for v, pg in zip(vec, pre_grads):
+                v.add_(pg, alpha=acc_strength)
         eps_n = eps / sqnorm(vec).sqrt()
         for p, v in zip(plist, vec):
             p.add_(v, alpha=float(eps_n))
@@ -375,6 +380,9 @@ def gradreg(spec, params, buffers, grads, x, y, lr, block_strength, eps, impleme
     elif implementation == "central-differences":
         original = [p.clone() for p in plist]
         vec = [g * block_strength for g in grads]
+        if pre_grads is not None:
+            for v, pg in zip(vec, pre_grads):
+                v.add_(pg, alpha=acc_strength)
         eps_n = eps / sqnorm(vec).sqrt()
         for p, v in zip(plist, vec):
             p.add_(v, alpha=float(0.5 * eps_n))
@@ -458,6 +466,15 @@ def full_batch_step(spec, params, buffers, momentum, X, Y, hyp, lr, stats, chunk
     """
     names = list(params)
     n_chunks = X.shape[0] // chunk  # drop_last=True, reference data_preparation.py:68
+    acc = hyp.get("acc_strength", 0.0)
+    pre = None
+    if acc != 0:  # pre-pass, training.py:128-142: plain full gradient (running mean over blocks); a train-mode pass of its own
+        pre = [torch.zeros_like(p) for p in params.values()]
+        for counter, k in enumerate(range(n_chunks) if chunk_range is None else chunk_range):
+            g0, _, _ = chunk_gradient(spec, params, buffers, X[k * chunk:(k + 1) * chunk], Y[k * chunk:(k + 1) * chunk], q)
+            for a, g in zip(pre, g0):
+                g.sub_(a)
+                a.add_(g, alpha=1 / (counter + 1))
     avg = [torch.zeros_like(p) for p in params.values()]
     grad_norms = torch.zeros(n_chunks, dtype=avg[0].dtype)
     step_loss, step_preds, datapoints = 0.0, 0.0, 0
@@ -468,7 +485,7 @@ def full_batch_step(spec, params, buffers, momentum, X, Y, hyp, lr, stats, chunk
         grads, loss, correct = chunk_gradient(spec, params, buffers, xk, yk, q)
         grad_norms[k] = sqnorm(grads)  # training.py:162
         grads = gradreg(spec, params, buffers, grads, xk, yk, lr, hyp["block_strength"], hyp["eps"],
-                        hyp["implementation"], q)  # training.py:163
+                        hyp["implementation"], q, acc, pre)  # training.py:163
         for a, g in zip(avg, grads):  # _stable_mean_accumulation, training.py:45-47
             g.sub_(a)
             a.add_(g, alpha=1 / (counter + 1))
@@ -482,6 +499,8 @@ def full_batch_step(spec, params, buffers, momentum, X, Y, hyp, lr, stats, chunk
     full_loss = step_loss / n_chunks + 0.5 * hyp["weight_decay"] * param_norm
     if hyp["block_strength"] != 0:
         full_loss = full_loss + lr / 4 * hyp["block_strength"] * full_grad_norm
+    if acc != 0:  # training.py:98-101
+        full_loss = full_loss + lr / 4 * acc * sqnorm(pre)
     stats["train_loss"].append(float(step_loss) / n_chunks)
     stats["train_acc"].append(float(step_preds) / datapoints)
     stats["param_norm"].append(float(param_norm))

@@ -21,4 +21,10 @@ def golden():
     here = os.path.join(REPO, "tests", "golden")
     with open(os.path.join(here, "meta.json")) as handle:
         meta = json.load(handle)
-    return np.load(os.path.join(here, "scenarios.npz")), meta
+    data = dict(np.load(os.path.join(here, "scenarios.npz")))
+    extra = os.path.join(here, "scenarios_extra.npz")            # scenarios added later (make_golden.py --extra)
+    if os.path.isfile(extra):
+        data.update(np.load(extra))
+        with open(os.path.join(here, "meta_extra.json")) as handle:
+            meta["scenarios"].update(json.load(handle)["scenarios"])
+    return data, meta

@@ -85,8 +85,20 @@ SCENARIOS = {
 }
 
 
+# Scenarios added after the first fixture set was committed; they live in their own files (scenarios_extra.npz, meta_extra.json,
+# written by `python tests/golden/make_golden.py --extra`) so that the original vectors stay byte-identical.
+SCENARIOS_EXTRA = {
+    # acc_strength: pre-pass over the dataset + full-gradient term in the finite-difference direction (training.py:128-142,
+    # modules.py:217-221 / 273-275)
+    "fb_acc": (128, 16, ["hyp=fb1", "hyp.steps=2", "hyp.warmup=0", "hyp.grad_reg.block_strength=0.5", "hyp.grad_reg.acc_strength=0.25",
+                         "data.batch_size=32", "hyp.sub_batch=32"], 3),
+    "fb_acc_central": (128, 16, ["hyp=fb1", "hyp.steps=2", "hyp.warmup=0", "hyp.grad_reg.block_strength=0.0", "hyp.grad_reg.acc_strength=0.5",
+                                 "hyp.grad_reg.implementation=central-differences", "data.batch_size=64", "hyp.sub_batch=64"], 9),
+}
+
+
 def run_scenario(fullbatch, compose, scen, out, dtype=torch.float):
-    n, pixels, overrides, mseed = SCENARIOS[scen]
+    n, pixels, overrides, mseed = (SCENARIOS[scen] if scen in SCENARIOS else SCENARIOS_EXTRA[scen])
     name = scen if dtype == torch.float else f"{scen}@f64"
     tmp = tempfile.mkdtemp()
     extra = ["impl.accumulation_dtype=double"] if dtype == torch.double else []  # else the f64 run accumulates/updates in fp32
@@ -199,6 +211,22 @@ def checkpoint_structure(fullbatch, compose):
     )
 
 
+def main_extra():
+    torch.set_num_threads(8)
+    fullbatch = import_reference()
+    from fullbatchtraining_amd.cfg import compose
+
+    out = {}
+    for name in SCENARIOS_EXTRA:
+        run_scenario(fullbatch, compose, name, out)
+        run_scenario(fullbatch, compose, name, out, dtype=torch.double)
+    np.savez_compressed(os.path.join(HERE, "scenarios_extra.npz"), **out)
+    meta = dict(scenarios={k: dict(n=v[0], pixels=v[1], overrides=v[2], model_seed=v[3]) for k, v in SCENARIOS_EXTRA.items()})
+    with open(os.path.join(HERE, "meta_extra.json"), "w") as handle:
+        json.dump(meta, handle, indent=1)
+    print("wrote", os.path.join(HERE, "scenarios_extra.npz"), os.path.join(HERE, "meta_extra.json"))
+
+
 def main():
     torch.set_num_threads(8)
     fullbatch = import_reference()
@@ -227,4 +255,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main_extra() if "--extra" in sys.argv else main()

@@ -23,7 +23,8 @@ def hyp_from_cfg(cfg):
     o = cfg.hyp.optim
     return dict(lr=o.lr, weight_decay=o.weight_decay, momentum=o.momentum, nesterov=o.nesterov, dampening=o.dampening,
                 block_strength=cfg.hyp.grad_reg.block_strength, eps=cfg.hyp.grad_reg.eps,
-                implementation=cfg.hyp.grad_reg.implementation, grad_clip=cfg.hyp.grad_clip)
+                implementation=cfg.hyp.grad_reg.implementation, grad_clip=cfg.hyp.grad_clip,
+                acc_strength=cfg.hyp.grad_reg.acc_strength)
 
 
 def rel_err(a, b):

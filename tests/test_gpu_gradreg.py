@@ -52,3 +52,43 @@ def test_gradreg_object_matches_reference(golden, name):
         GradRegularizer(model, optimizer, None, block_strength=0.5, implementation="finite_diff")
     with pytest.raises(NotImplementedError):
         GradRegularizer(model, optimizer, None, block_strength=0.5, implementation="autograd")([], None, None, None)
+
+
+@pytest.mark.parametrize("implementation,block_strength", [("forward-differences", 0.5), ("central-differences", 0.0)])
+def test_gradreg_object_with_pre_grads(implementation, block_strength):
+    """acc_strength / pre_grads (reference modules.py:217-221, 273-275): the finite-difference direction becomes
+    block_strength*g + acc_strength*pre_grads.  Object under test vs the float64 oracle (itself pinned to the reference's
+    acc_strength runs, tests/test_oracle_golden.py::test_training_float64_pin[fb_acc*])."""
+    from fullbatchtraining_amd.cfg import compose
+    from fullbatchtraining_amd.models import construct_model
+    from fullbatchtraining_amd.modules import GradRegularizer
+    from oracle import fb_oracle as orc
+
+    cfg = compose(["data.pixels=16"])
+    torch.manual_seed(21)
+    model = construct_model(cfg.model, 3, 10)
+    x, y = make_data(64, 16)
+    state = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+    params, buffers = orc.split_state(state)
+    spec = orc.Spec(18)
+    raw, _, _ = orc.chunk_gradient(spec, params, buffers, x[:32].double(), y[:32])
+    pre, _, _ = orc.chunk_gradient(spec, params, buffers, x[32:].double(), y[32:])       # any other gradient-shaped list
+    want = orc.gradreg(spec, params, buffers, [g.clone() for g in raw], x[:32].double(), y[:32], 0.1, block_strength, 1e-2, implementation,
+                       acc_strength=0.25, pre_grads=pre)
+    # the model on the GPU: parameters as at init, BN buffers as the oracle had them BEFORE its FD pass (after the two first passes)
+    model = model.cuda()
+    optimizer = torch.optim.SGD(model.parameters(), lr=0.1)
+    greg = GradRegularizer(model, optimizer, torch.nn.CrossEntropyLoss(), block_strength=block_strength, acc_strength=0.25, eps=1e-2,
+                           implementation=implementation)
+    grads = [g.float().cuda() for g in raw]
+    out = greg(grads, x[:32].cuda(), y[:32].cuda(), [g.float().cuda() for g in pre])
+    assert out is grads
+    a = torch.cat([g.reshape(-1).double().cpu() for g in grads])
+    t = torch.cat([g.reshape(-1) for g in want])
+    err = float((a - t).norm() / t.norm())
+    print(f"{implementation} with pre_grads: GradRegularizer-vs-oracle64 {err:.2e}")
+    assert err < 2e-2          # same class as the pre_grads-free variants above (fp32 finite differences of a cancelling sum)
+    if block_strength != 0:      # (with block_strength 0 and no pre_grads the direction is 0 and eps_n infinite -- in the reference too)
+        grads0 = [g.float().cuda() for g in raw]
+        greg(grads0, x[:32].cuda(), y[:32].cuda(), None)
+        assert float((torch.cat([g.reshape(-1) for g in grads0]) - torch.cat([g.reshape(-1) for g in grads])).norm()) > 0

@@ -313,7 +313,7 @@ def test_multi_tensor_ops():
     gd = g.cuda()
     ws = torch.zeros(max(G, 2) * lib.MT_BLOCKS, device="cuda")
     out = torch.zeros(G, device="cuda")
-    lib.call("fb_mt_sqnorm", gd.data_ptr(), stride, G, P, 0.5, out.data_ptr(), ws.data_ptr())
+    lib.call("fb_mt_sqnorm", gd.data_ptr(), stride, G, P, 0.5, None, 0.0, out.data_ptr(), ws.data_ptr())
     assert torch.allclose(out.cpu(), (0.5 * g[:, :P]).double().pow(2).sum(1).float(), rtol=1e-5)
     # running mean + fused norms
     avg = torch.randn(stride)
@@ -331,10 +331,22 @@ def test_multi_tensor_ops():
     vn = (0.5 * g[:, :P]).double().pow(2).sum(1).float().cuda()
     eps_n = torch.zeros(G, device="cuda")
     thk = torch.zeros(G, stride, device="cuda")
-    lib.call("fb_mt_fd_perturb", th0.data_ptr(), gd.data_ptr(), stride, G, P, 0.5, 1e-2, 1.0, vn.data_ptr(), eps_n.data_ptr(), thk.data_ptr())
+    lib.call("fb_mt_fd_perturb", th0.data_ptr(), gd.data_ptr(), stride, G, P, 0.5, 1e-2, 1.0, vn.data_ptr(), eps_n.data_ptr(), None, 0.0, thk.data_ptr())
     en = 1e-2 / vn.cpu().sqrt()
     assert torch.allclose(eps_n.cpu(), en, rtol=1e-6)
     assert torch.allclose(thk[:, :P].cpu(), theta0[None, :P] + en[:, None] * (0.5 * g[:, :P]), rtol=1e-6, atol=1e-7)
+    # acc_strength variants: direction v = 0.5*g + 0.3*pre (pre shared by the groups)
+    pre = torch.randn(stride)
+    pre[P:] = 0
+    pred = pre.cuda()
+    lib.call("fb_mt_sqnorm", gd.data_ptr(), stride, G, P, 0.5, pred.data_ptr(), 0.3, out.data_ptr(), ws.data_ptr())
+    v = 0.5 * g[:, :P] + 0.3 * pre[None, :P]
+    assert torch.allclose(out.cpu(), v.double().pow(2).sum(1).float(), rtol=1e-5)
+    eps_v = torch.zeros(G, device="cuda")
+    lib.call("fb_mt_fd_perturb", th0.data_ptr(), gd.data_ptr(), stride, G, P, 0.5, 1e-2, -0.5, out.data_ptr(), eps_v.data_ptr(), pred.data_ptr(), 0.3,
+             thk.data_ptr())
+    env = 1e-2 / out.cpu().sqrt()
+    assert torch.allclose(thk[:, :P].cpu(), theta0[None, :P] - 0.5 * env[:, None] * v, rtol=1e-6, atol=1e-7)
     g2 = g + 0.01 * torch.randn(G, stride)
     g2d = g2.cuda()
     avg2 = torch.zeros(stride, device="cuda")

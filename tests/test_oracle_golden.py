@@ -108,7 +108,8 @@ def test_reference_fp32_noise_floor_on_record(golden):
     print(f"reference fp32-vs-f64: raw chunk gradient {raw:.2e}, FD-regularised gradient {reg:.2e}")
 
 
-TRAIN_CASES = ["fb_plain", "fb_gradreg", "fb_clip_warm", "fb_gradreg_c32", "fb_central", "fb_legacy"]
+TRAIN_CASES = ["fb_plain", "fb_gradreg", "fb_clip_warm", "fb_gradreg_c32", "fb_central", "fb_legacy",
+               "fb_acc", "fb_acc_central"]      # acc_strength pre-pass (scenarios_extra.npz)
 
 
 @pytest.mark.parametrize("name", TRAIN_CASES)
