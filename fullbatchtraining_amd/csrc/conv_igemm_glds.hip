@@ -55,7 +55,10 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(const ConvParams p, 
     // hipcc wraps every buffer op that depends on them in a waterfall loop (cdna_hip_programming.md T20)
     const int L = xcd_remap1d(blockIdx.x, gridDim.x);
     const int co_blk = __builtin_amdgcn_readfirstlane(L % n_co), t2 = L / n_co;
-    const int mblk = __builtin_amdgcn_readfirstlane(t2 % mblocks), cls = __builtin_amdgcn_readfirstlane(t2 / mblocks);
+    // the four parity classes of a stride-2 input gradient read the same dY pixels (with 0/1-pixel offsets): class is the
+    // fast index so that they run side by side on one XCD and share them in L2 (PMC: dY was fetched four times from HBM)
+    const int classes = (int)gridDim.x / (mblocks * n_co);
+    const int cls = __builtin_amdgcn_readfirstlane(t2 % classes), mblk = __builtin_amdgcn_readfirstlane(t2 / classes);
     const int cpy = (p.os == 2) ? (cls >> 1) : 0, cpx = (p.os == 2) ? (cls & 1) : 0;
     const int lrow = tid >> 3;
     const int chunk = (tid & 7) ^ (lrow & 7);        // logical chunk this lane fetches (source-side swizzle)
