@@ -193,6 +193,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 }
 
 int fb_try_conv3x3_halo4(const fb_conv_args* a, hipStream_t st);   // conv3x3_halo4.hip
+int fb_try_conv3x3_halo5(const fb_conv_args* a, hipStream_t st);   // conv3x3_halo5.hip
 
 template <typename T> static int launch_conv(const ConvParams& p, int classes, hipStream_t st) {
     const int mblocks = (p.M + 127) / 128;
@@ -243,7 +244,7 @@ extern "C" int fb_conv2d(const fb_conv_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int prof = fb_prof_begin(a->mode == 0 ? FB_PROF_IGEMM_FWD : FB_PROF_IGEMM_DGRAD, st);
     static const bool v1 = getenv("FB_IGEMM_V1") != nullptr;
-    if (!fb_try_conv3x3_halo4(a, st)) {
+    if (!fb_try_conv3x3_halo5(a, st) && !fb_try_conv3x3_halo4(a, st)) {
         p.zeros = nullptr;
         if (v1 || !fb_launch_igemm_glds(p, classes, a->dtype, st)) {
             if (a->dtype == FB_F32) launch_conv<float>(p, classes, st); else launch_conv<bf16_tag>(p, classes, st);
