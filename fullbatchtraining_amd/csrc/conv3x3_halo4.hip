@@ -128,14 +128,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
     // output offset of this lane inside a tile: pixel 64*wave + (lane & 15), channels 4*(lane >> 4) .. +3 of a 16-channel fragment
+    const int g4 = lane >> 4;
     const int voffD = ((wave * 64 + (lane & 15)) * p.Cd + (lane >> 4) * 4) * EB;
-    // bf16 output staging in ring buffer 2 (idle between the last tap of a tile and tap 0 of the next), 2 KiB per wave:
-    //   write: fragment lane (pixel t = lane & 15, channels 16 I + 4 g..) -> row t, 16-byte chunk (2 I + g/2) ^ (t & 7), half g & 1
-    //   read : lane -> row lane >> 3 (+8), chunk (lane & 7) ^ row: channels 8 (lane & 7)..+7 of that pixel
-    const unsigned stg = lds0 + HALO_BYTES + 2 * WT_BYTES + wave * 2048;
-    const unsigned stw = stg + (lane & 15) * 128 + ((((lane >> 5) & 1) ^ (lane & 7)) * 16) + ((lane >> 4) & 1) * 8;
-    const unsigned str = stg + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) * 16);
-    const int voffT = ((wave * 64 + (lane >> 3)) * p.Cd + (lane & 7) * 8) * EB;
+    // bf16 outputs after the row swap of a fragment pair: lane group g owns channels {0, 16, 8, 24}[g] .. +7 of the pair's 32
+    const int voffT = ((wave * 64 + (lane & 15)) * p.Cd + (g4 & 1) * 16 + (g4 >> 1) * 8) * EB;
     // BN partial sums: writer lanes (lane & 15 == 0) and the 128 reader threads
     const unsigned red0 = lds0 + HALO_BYTES + NW * WT_BYTES;
     const unsigned redw = red0 + (wave * 64 + (lane >> 4) * 4) * 8;
@@ -280,6 +276,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         h4_static_for<0, 4>([&](auto jc) {
             constexpr int J = decltype(jc)::value;
             const int soff = (J * 16 * p.Cd + cur.ct * 64) * EB;
+            unsigned pk[4][2];
             h4_static_for<0, 4>([&](auto ic) {
                 constexpr int I = decltype(ic)::value;
                 float v[4] = {acc[I][J][0], acc[I][J][1], acc[I][J][2], acc[I][J][3]};
@@ -306,22 +303,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     __builtin_amdgcn_raw_buffer_store_b128((h4_u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
                                                            rsrcD, voffD + I * 16 * EB, soff, 0);
                 } else {
-                    // bf16: through the wave's 2 KiB staging slot ([16 pixels][64 channels], 16-byte chunks XOR-swizzled by the
-                    // pixel) so that the global stores are 16 bytes per lane and cover whole 128-byte lines (8 instead of 16
-                    // store instructions per wave; the store tail is issue-bound)
-                    const h4_u32x2 d = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    const unsigned wr = stw ^ (unsigned)(I * 32);
-                    asm volatile("ds_write_b64 %0, %1" ::"v"(wr), "v"(d) : "memory");
+                    // bf16: a lane holds channels 4g..4g+3 of this 16-channel fragment (8 bytes).  v_permlane16_swap exchanges the
+                    // odd 16-lane rows of fragment I with the even rows of fragment I+1, after which every lane owns 8 CONSECUTIVE
+                    // channels: one 16-byte store per fragment pair -- half the store instructions (the epilogue is store-issue
+                    // bound), without a trip through LDS
+                    pk[I][0] = pack_bf16x2(v[0], v[1]); pk[I][1] = pack_bf16x2(v[2], v[3]);
+                    if constexpr ((I & 1) == 1) {
+                        const h4_u32x2 lo = __builtin_amdgcn_permlane16_swap(pk[I - 1][0], pk[I][0], false, false);   // rows (X0,Y0,X2,Y2) / (X1,Y1,X3,Y3)
+                        const h4_u32x2 hi = __builtin_amdgcn_permlane16_swap(pk[I - 1][1], pk[I][1], false, false);
+                        __builtin_amdgcn_raw_buffer_store_b128((h4_u32x4){lo[0], hi[0], lo[1], hi[1]}, rsrcD, voffT + (I >> 1) * 32 * EB, soff, 0);
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { ssum[I][r] += v[r]; ssq[I][r] += v[r] * v[r]; }
             });
-            if constexpr (EB == 2) {
-                const uint4 lo = h4_read16<0>(str), hi = h4_read16<1024>(str);
-                h4_wait_lgkmcnt<0>();
-                __builtin_amdgcn_raw_buffer_store_b128((h4_u32x4){lo.x, lo.y, lo.z, lo.w}, rsrcD, voffT, soff, 0);
-                __builtin_amdgcn_raw_buffer_store_b128((h4_u32x4){hi.x, hi.y, hi.z, hi.w}, rsrcD, voffT, soff + 8 * p.Cd * EB, 0);
-            }
         });
         H4_STAMP(4);
         if (p.stat != nullptr) {

@@ -188,27 +188,45 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(const ConvParams p, 
 #pragma unroll
     for (int j = 0; j < FJ; ++j) {
         const int m = mblk * 128 + wave_px * 64 + j * 16 + (lane & 15);
-        if (m < p.M) {
-            const int n = m / qHW, rem = m - n * qHW, qy = rem / p.qW, qx = rem - qy * p.qW;
-            const int oy = qy * p.os + cpy, ox = qx * p.os + cpx;
-            const long long pix = ((long long)n * p.Hd + oy) * p.Wd + ox;
+        const bool valid = m < p.M;                     // (rows past M were zero-filled: their accumulators are 0)
+        const int mc = valid ? m : p.M - 1;
+        const int n = mc / qHW, rem = mc - n * qHW, qy = rem / p.qW, qx = rem - qy * p.qW;
+        const int oy = qy * p.os + cpy, ox = qx * p.os + cpx;
+        const long long pix = ((long long)n * p.Hd + oy) * p.Wd + ox;
+        unsigned pk[FI][2];
 #pragma unroll
-            for (int i = 0; i < FI; ++i) {
-                const int co = co_blk * BN_CO + wave_co * (BN_CO / 2) + i * 16 + (lane >> 4) * 4;
-                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if (p.addend_mode != 0) {
-                    const long long apix = p.addend_mode == 1 ? pix : ((long long)n * (p.Hd >> 1) + (oy >> 1)) * (p.Wd >> 1) + (ox >> 1);
-                    const float sc = p.addend_mode == 1 ? 1.f : 0.25f;
-                    const char* ap = p.addend + (apix * p.Cd + co) * EB;
-                    if constexpr (EB == 4) { const float4 a = *(const float4*)ap; v[0] += sc * a.x; v[1] += sc * a.y; v[2] += sc * a.z; v[3] += sc * a.w; }
-                    else { const uint2 a = *(const uint2*)ap; v[0] += sc * __uint_as_float(a.x << 16); v[1] += sc * __uint_as_float(a.x & 0xffff0000u);
-                           v[2] += sc * __uint_as_float(a.y << 16); v[3] += sc * __uint_as_float(a.y & 0xffff0000u); }
-                }
-                char* dp = p.dst + (pix * p.Cd + co) * EB;
-                if constexpr (EB == 4) *(float4*)dp = make_float4(v[0], v[1], v[2], v[3]);
-                else *(uint2*)dp = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        for (int i = 0; i < FI; ++i) {
+            const int co = co_blk * BN_CO + wave_co * (BN_CO / 2) + i * 16 + (lane >> 4) * 4;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (p.addend_mode != 0 && valid) {
+                const long long apix = p.addend_mode == 1 ? pix : ((long long)n * (p.Hd >> 1) + (oy >> 1)) * (p.Wd >> 1) + (ox >> 1);
+                const float sc = p.addend_mode == 1 ? 1.f : 0.25f;
+                const char* ap = p.addend + (apix * p.Cd + co) * EB;
+                if constexpr (EB == 4) { const float4 a = *(const float4*)ap; v[0] += sc * a.x; v[1] += sc * a.y; v[2] += sc * a.z; v[3] += sc * a.w; }
+                else { const uint2 a = *(const uint2*)ap; v[0] += sc * __uint_as_float(a.x << 16); v[1] += sc * __uint_as_float(a.x & 0xffff0000u);
+                       v[2] += sc * __uint_as_float(a.y << 16); v[3] += sc * __uint_as_float(a.y & 0xffff0000u); }
+            }
+            if constexpr (EB == 4) {
+                if (valid) *(float4*)(p.dst + (pix * p.Cd + co) * EB) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                pk[i][0] = pack_bf16x2(v[0], v[1]); pk[i][1] = pack_bf16x2(v[2], v[3]);
+            }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { ssum[i][r] += v[r]; ssq[i][r] += v[r] * v[r]; }
+            for (int r = 0; r < 4; ++r) { ssum[i][r] += v[r]; ssq[i][r] += v[r] * v[r]; }
+        }
+        if constexpr (EB == 2) {
+            // a lane holds channels 4g..4g+3 of each 16-channel fragment (8 bytes); v_permlane16_swap exchanges the odd 16-lane rows of
+            // fragment i with the even rows of fragment i+1: every lane then owns 8 consecutive channels ({0,16,8,24}[g] of the pair's
+            // 32) and one 16-byte store per pair replaces two 8-byte ones (the epilogue is bound by store issue).  All lanes take part
+            // in the swap; only the store is predicated.
+#pragma unroll
+            for (int i = 0; i < FI; i += 2) {
+                typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+                const u32x2_t lo = __builtin_amdgcn_permlane16_swap(pk[i][0], pk[i + 1][0], false, false);
+                const u32x2_t hi = __builtin_amdgcn_permlane16_swap(pk[i][1], pk[i + 1][1], false, false);
+                const int g = lane >> 4;
+                const int co = co_blk * BN_CO + wave_co * (BN_CO / 2) + i * 16 + (g & 1) * 16 + (g >> 1) * 8;
+                if (valid) *(uint4*)(p.dst + (pix * p.Cd + co) * EB) = make_uint4(lo[0], hi[0], lo[1], hi[1]);
             }
         }
     }
