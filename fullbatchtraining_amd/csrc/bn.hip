@@ -90,11 +90,86 @@ __global__ void bn_apply_kernel(const uint4* __restrict__ x, uint4* __restrict__
     }
 }
 
+// "Span" variants of the elementwise kernels (used whenever the channel vectors of a pixel divide 256): a workgroup owns a run of
+// consecutive 16-byte vectors of ONE statistics group, so a thread keeps its channel vector for the whole run and its
+// coefficients stay in registers -- the grid-stride form above re-reads 16-48 coefficient dwords per 16-byte vector through
+// the same texture path as the data (1.5-3x its bytes).  Four vectors per thread are in flight per loop trip.
+template <int V> __device__ __forceinline__ void load_coef(const float* __restrict__ p, float* o) {
+#pragma unroll
+    for (int k = 0; k < V; k += 4) { const float4 v = *(const float4*)(p + k); o[k] = v.x; o[k + 1] = v.y; o[k + 2] = v.z; o[k + 3] = v.w; }
+}
+constexpr int BN_SPAN_U = 4;
+// streaming accesses of the span kernels: every tensor is far larger than L2 + Infinity Cache and is touched once per kernel
+typedef __attribute__((ext_vector_type(4))) unsigned bn_u32x4_t;
+__device__ __forceinline__ uint4 ld_stream(const uint4* p) {
+    const bn_u32x4_t v = __builtin_nontemporal_load((const bn_u32x4_t*)p);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void st_stream(uint4* p, const uint4& v) {
+    __builtin_nontemporal_store((bn_u32x4_t){v.x, v.y, v.z, v.w}, (bn_u32x4_t*)p);
+}
+
+template <typename T, int RES>
+__global__ __launch_bounds__(256) void bn_apply_span_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const uint4* __restrict__ res,
+                                                            const float* __restrict__ rscale, const float* __restrict__ rshift, long long n_vec,
+                                                            int cvec, long long vec_per_group, int C, int relu, unsigned char* __restrict__ mask_out,
+                                                            int span) {
+    constexpr int V = ET<T>::VEC;
+    const long long g = blockIdx.y, base = g * vec_per_group;
+    const long long lim = n_vec - base < vec_per_group ? n_vec - base : vec_per_group;
+    const long long lo = (long long)blockIdx.x * span;
+    const long long hi = lo + span < lim ? lo + span : lim;
+    const int c0 = (int)(threadIdx.x % cvec) * V;
+    float sc[V], sh[V], rsc[RES == 2 ? V : 1], rsh[RES == 2 ? V : 1];
+    load_coef<V>(scale + g * C + c0, sc); load_coef<V>(shift + g * C + c0, sh);
+    if constexpr (RES == 2) { load_coef<V>(rscale + g * C + c0, rsc); load_coef<V>(rshift + g * C + c0, rsh); }
+    x += base; y += base;
+    if (RES) res += base;
+    if (mask_out) mask_out += base;
+    auto one = [&](const uint4& xr, const uint4& rr, long long i) {
+        float xv[V], rv[V], o[V];
+        unsigned m = 0;
+        ET<T>::unpack(xr, xv);
+        if (RES) ET<T>::unpack(rr, rv);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float v = xv[k] * sc[k] + sh[k];
+            if (RES == 1) v += rv[k];
+            if (RES == 2) v += rv[k] * rsc[k] + rsh[k];
+            o[k] = relu ? fmaxf(v, 0.f) : v;
+            m |= (v > 0.f ? 1u : 0u) << k;
+        }
+        st_stream(y + i, ET<T>::pack(o));
+        if (mask_out) mask_out[i] = (unsigned char)m;
+    };
+    long long i = lo + threadIdx.x;
+    for (; i + (BN_SPAN_U - 1) * 256 < hi; i += BN_SPAN_U * 256) {
+        uint4 xr[BN_SPAN_U], rr[BN_SPAN_U];
+#pragma unroll
+        for (int u = 0; u < BN_SPAN_U; ++u) { xr[u] = ld_stream(x + i + u * 256); if (RES) rr[u] = ld_stream(res + i + u * 256); }
+#pragma unroll
+        for (int u = 0; u < BN_SPAN_U; ++u) one(xr[u], rr[u], i + u * 256);
+    }
+    for (; i < hi; i += 256) { uint4 rr = make_uint4(0, 0, 0, 0); if (RES) rr = res[i]; one(x[i], rr, i); }
+}
+
+// run length of a span kernel: 4096 vectors (64 KiB per tensor) when that still gives >= 2048 workgroups, else 1024
+static inline int bn_span(long long n_vec) { return n_vec / 4096 >= 2048 ? 4096 : 1024; }
+
 template <typename T>
 static void launch_bn_apply(const void* x, void* y, const float* scale, const float* shift, const void* res, const float* rscale,
                             const float* rshift, int64_t n_pixels, int C, int64_t ppg, int relu, unsigned char* mask_out, hipStream_t st) {
     const int cvec = C / ET<T>::VEC;
     const long long n_vec = n_pixels * cvec, vpg = ppg * cvec;
+    if (256 % cvec == 0 && vpg > 0) {
+        const int span = bn_span(n_vec);
+        const dim3 grid((unsigned)((vpg + span - 1) / span), (unsigned)((n_vec + vpg - 1) / vpg));
+        if (!res) hipLaunchKernelGGL((bn_apply_span_kernel<T, 0>), grid, dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, nullptr, nullptr, nullptr, n_vec, cvec, vpg, C, relu, mask_out, span);
+        else if (!rscale) hipLaunchKernelGGL((bn_apply_span_kernel<T, 1>), grid, dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, nullptr, nullptr, n_vec, cvec, vpg, C, relu, mask_out, span);
+        else hipLaunchKernelGGL((bn_apply_span_kernel<T, 2>), grid, dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, rscale, rshift, n_vec, cvec, vpg, C, relu, mask_out, span);
+        return;
+    }
     const int blocks = (int)((n_vec + 255) / 256 < 8192 ? (n_vec + 255) / 256 : 8192);
     if (!res) hipLaunchKernelGGL((bn_apply_kernel<T, 0>), dim3(blocks), dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, nullptr, nullptr, nullptr, n_vec, cvec, vpg, C, relu, mask_out);
     else if (!rscale) hipLaunchKernelGGL((bn_apply_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, nullptr, nullptr, n_vec, cvec, vpg, C, relu, mask_out);
@@ -140,50 +215,97 @@ extern "C" int fb_bn_running_update(float* running_mean, float* running_var, con
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// backward reduce: block = 128 pixels x all channels.  thread -> (channel vector lane, pixel sub-row)
+// backward reduce: workgroup = PB pixels (128 .. 1024, one statistics group) x all channels; thread -> (pixel sub-row, channel vector).
+// With 256 % cvec == 0 the vectors of the workgroup's pixels are one linear run and a thread keeps its channel vector: mean / invstd
+// live in registers, four (dy, x, mask) triples are in flight per trip.  One partial row per workgroup, summed in fixed order by
+// fb_bn_bwd_finalize.  fb_bn_bwd_reduce_rows() tells the caller how many rows that is.
+static inline int bn_reduce_pixels(long long n_pixels, long long ppg) {
+    int pb = 128;
+    while (pb < 1024 && ppg % (2 * pb) == 0 && n_pixels / (2 * pb) >= 2048) pb *= 2;
+    return pb;
+}
+extern "C" int32_t fb_bn_bwd_reduce_rows(int64_t n_pixels, int64_t pixels_per_group) {
+    if (n_pixels <= 0 || pixels_per_group <= 0) return 0;
+    const int pb = bn_reduce_pixels(n_pixels, pixels_per_group);
+    return (int32_t)((n_pixels + pb - 1) / pb);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint4* __restrict__ dout, const uint4* __restrict__ y,
                                                             const unsigned char* __restrict__ mask,
                                                             const uint4* __restrict__ x, const float* __restrict__ mean_tab,
                                                             const float* __restrict__ invstd, int ch_total, int ch_off,
                                                             float* __restrict__ partial, long long n_pixels, int C, long long ppg,
-                                                            int n_mblocks) {
+                                                            int n_mblocks, int PB) {
     constexpr int V = ET<T>::VEC;
     extern __shared__ float sm[];   // [rows][C][2]
     const int cvec = C / V;
-    const int rows = 256 / cvec > 0 ? 256 / cvec : 1;      // pixel sub-rows handled in parallel
-    const int lanes = cvec < 256 ? cvec : 256;
-    const long long p0 = (long long)blockIdx.x * 128;
+    const long long p0 = (long long)blockIdx.x * PB;
     const long long g = p0 / ppg;
-    for (int cv = threadIdx.x % lanes; cv < cvec; cv += lanes) {
-        const int row = threadIdx.x / lanes;
-        const int c0 = cv * V;
+    const long long p1 = p0 + PB < n_pixels ? p0 + PB : n_pixels;
+    auto mask_at = [&](long long i) -> unsigned {
+        if (mask) return mask[i];
+        if (!y) return 0xffu;
+        float yv[V];
+        ET<T>::unpack(y[i], yv);
+        unsigned mk = 0;
+#pragma unroll
+        for (int k = 0; k < V; ++k) mk |= (yv[k] > 0.f ? 1u : 0u) << k;
+        return mk;
+    };
+    int rows;
+    if (256 % cvec == 0) {
+        rows = 256 / cvec;
+        const int cv = threadIdx.x % cvec, row = threadIdx.x / cvec, c0 = cv * V;
         float mu[V], is[V], s1[V], s2[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) { mu[k] = mean_tab[g * ch_total + ch_off + c0 + k]; is[k] = invstd[g * C + c0 + k]; s1[k] = 0.f; s2[k] = 0.f; }
-        if (row < rows) {
-            for (int pr = row; pr < 128; pr += rows) {
-                const long long pidx = p0 + pr;
-                if (pidx >= n_pixels) break;
-                const long long i = pidx * cvec + cv;
-                float d[V], xv[V], yv[V];
-                ET<T>::unpack(dout[i], d); ET<T>::unpack(x[i], xv);
-                unsigned mk = 0xffu;
-                if (mask) mk = mask[i];
-                else if (y) {
-                    ET<T>::unpack(y[i], yv);
-                    mk = 0;
+        auto one = [&](const uint4& dr, const uint4& xr, unsigned mk) {
+            float d[V], xv[V];
+            ET<T>::unpack(dr, d); ET<T>::unpack(xr, xv);
 #pragma unroll
-                    for (int k = 0; k < V; ++k) mk |= (yv[k] > 0.f ? 1u : 0u) << k;
-                }
-#pragma unroll
-                for (int k = 0; k < V; ++k) {
-                    const float dy = ((mk >> k) & 1u) ? d[k] : 0.f;
-                    s1[k] += dy; s2[k] += dy * ((xv[k] - mu[k]) * is[k]);
-                }
+            for (int k = 0; k < V; ++k) {
+                const float dy = ((mk >> k) & 1u) ? d[k] : 0.f;
+                s1[k] += dy; s2[k] += dy * ((xv[k] - mu[k]) * is[k]);
             }
+        };
+        const long long hi = p1 * cvec;
+        long long i = p0 * cvec + threadIdx.x;
+        for (; i + (BN_SPAN_U - 1) * 256 < hi; i += BN_SPAN_U * 256) {
+            uint4 dr[BN_SPAN_U], xr[BN_SPAN_U];
+            unsigned mk[BN_SPAN_U];
 #pragma unroll
-            for (int k = 0; k < V; ++k) { sm[(row * C + c0 + k) * 2] = s1[k]; sm[(row * C + c0 + k) * 2 + 1] = s2[k]; }
+            for (int u = 0; u < BN_SPAN_U; ++u) { dr[u] = ld_stream(dout + i + u * 256); xr[u] = ld_stream(x + i + u * 256); mk[u] = mask_at(i + u * 256); }
+#pragma unroll
+            for (int u = 0; u < BN_SPAN_U; ++u) one(dr[u], xr[u], mk[u]);
+        }
+        for (; i < hi; i += 256) one(dout[i], x[i], mask_at(i));
+#pragma unroll
+        for (int k = 0; k < V; ++k) { sm[(row * C + c0 + k) * 2] = s1[k]; sm[(row * C + c0 + k) * 2 + 1] = s2[k]; }
+    } else {                        // channel counts whose vectors do not divide the workgroup: one sub-row, channel loop
+        rows = 256 / cvec > 0 ? 256 / cvec : 1;
+        const int lanes = cvec < 256 ? cvec : 256;
+        for (int cv = threadIdx.x % lanes; cv < cvec; cv += lanes) {
+            const int row = threadIdx.x / lanes;
+            const int c0 = cv * V;
+            float mu[V], is[V], s1[V], s2[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) { mu[k] = mean_tab[g * ch_total + ch_off + c0 + k]; is[k] = invstd[g * C + c0 + k]; s1[k] = 0.f; s2[k] = 0.f; }
+            if (row < rows) {
+                for (long long pidx = p0 + row; pidx < p1; pidx += rows) {
+                    const long long i = pidx * cvec + cv;
+                    float d[V], xv[V];
+                    ET<T>::unpack(dout[i], d); ET<T>::unpack(x[i], xv);
+                    const unsigned mk = mask_at(i);
+#pragma unroll
+                    for (int k = 0; k < V; ++k) {
+                        const float dy = ((mk >> k) & 1u) ? d[k] : 0.f;
+                        s1[k] += dy; s2[k] += dy * ((xv[k] - mu[k]) * is[k]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < V; ++k) { sm[(row * C + c0 + k) * 2] = s1[k]; sm[(row * C + c0 + k) * 2 + 1] = s2[k]; }
+            }
         }
     }
     __syncthreads();
@@ -203,15 +325,16 @@ extern "C" int fb_bn_bwd_reduce(const void* dout, const void* y, const void* mas
     const int V = dtype == FB_F32 ? 4 : 8;
     if (C % V != 0) FB_FAIL(FB_ERR_SHAPE, "fb_bn_bwd_reduce: C=%d", C);
     const int cvec = C / V, rows = 256 / cvec > 0 ? 256 / cvec : 1;
-    const int n_mblocks = (int)((n_pixels + 127) / 128);
+    const int PB = bn_reduce_pixels(n_pixels, pixels_per_group);
+    const int n_mblocks = fb_bn_bwd_reduce_rows(n_pixels, pixels_per_group);
     const size_t smem = (size_t)rows * C * 2 * sizeof(float);
     if (smem > 64 * 1024) FB_FAIL(FB_ERR_UNSUPPORTED, "fb_bn_bwd_reduce: C=%d too large", C);
     if (dtype == FB_F32)
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<float>), dim3(n_mblocks), dim3(256), smem, (hipStream_t)stream, (const uint4*)dout, (const uint4*)y,
-                           (const unsigned char*)mask, (const uint4*)x, mean_tab, invstd, ch_total, ch_off, partial, (long long)n_pixels, C, (long long)pixels_per_group, n_mblocks);
+                           (const unsigned char*)mask, (const uint4*)x, mean_tab, invstd, ch_total, ch_off, partial, (long long)n_pixels, C, (long long)pixels_per_group, n_mblocks, PB);
     else
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_tag>), dim3(n_mblocks), dim3(256), smem, (hipStream_t)stream, (const uint4*)dout, (const uint4*)y,
-                           (const unsigned char*)mask, (const uint4*)x, mean_tab, invstd, ch_total, ch_off, partial, (long long)n_pixels, C, (long long)pixels_per_group, n_mblocks);
+                           (const unsigned char*)mask, (const uint4*)x, mean_tab, invstd, ch_total, ch_off, partial, (long long)n_pixels, C, (long long)pixels_per_group, n_mblocks, PB);
     FB_CHECK_LAUNCH("fb_bn_bwd_reduce");
     return FB_OK;
 }
@@ -275,12 +398,75 @@ __global__ void bn_bwd_apply_kernel(const uint4* __restrict__ dout, const uint4*
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_span_kernel(const uint4* __restrict__ dout, const uint4* __restrict__ y,
+                                                                const unsigned char* __restrict__ mask, const uint4* __restrict__ x,
+                                                                const float* __restrict__ coef, uint4* __restrict__ dx, uint4* __restrict__ dy_out,
+                                                                long long n_vec, int cvec, long long vec_per_group, int C, int span) {
+    constexpr int V = ET<T>::VEC;
+    const long long g = blockIdx.y, base = g * vec_per_group;
+    const long long lim = n_vec - base < vec_per_group ? n_vec - base : vec_per_group;
+    const long long lo = (long long)blockIdx.x * span;
+    const long long hi = lo + span < lim ? lo + span : lim;
+    const int c0 = (int)(threadIdx.x % cvec) * V;
+    float cf[3 * V];
+    load_coef<3 * V>(coef + (g * C + c0) * 3, cf);
+    dout += base; x += base; dx += base;
+    if (mask) mask += base;
+    if (y) y += base;
+    if (dy_out) dy_out += base;
+    auto one = [&](const uint4& dr, const uint4& xr, unsigned mk, long long i) {
+        float d[V], xv[V], o[V], dyv[V];
+        ET<T>::unpack(dr, d); ET<T>::unpack(xr, xv);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float dy = ((mk >> k) & 1u) ? d[k] : 0.f;
+            dyv[k] = dy;
+            o[k] = cf[3 * k] * dy + cf[3 * k + 1] * xv[k] + cf[3 * k + 2];
+        }
+        st_stream(dx + i, ET<T>::pack(o));
+        if (dy_out) st_stream(dy_out + i, ET<T>::pack(dyv));
+    };
+    auto mask_at = [&](long long i) -> unsigned {
+        if (mask) return mask[i];
+        if (!y) return 0xffu;
+        float yv[V];
+        ET<T>::unpack(y[i], yv);
+        unsigned mk = 0;
+#pragma unroll
+        for (int k = 0; k < V; ++k) mk |= (yv[k] > 0.f ? 1u : 0u) << k;
+        return mk;
+    };
+    long long i = lo + threadIdx.x;
+    for (; i + (BN_SPAN_U - 1) * 256 < hi; i += BN_SPAN_U * 256) {
+        uint4 dr[BN_SPAN_U], xr[BN_SPAN_U];
+        unsigned mk[BN_SPAN_U];
+#pragma unroll
+        for (int u = 0; u < BN_SPAN_U; ++u) { dr[u] = ld_stream(dout + i + u * 256); xr[u] = ld_stream(x + i + u * 256); mk[u] = mask_at(i + u * 256); }
+#pragma unroll
+        for (int u = 0; u < BN_SPAN_U; ++u) one(dr[u], xr[u], mk[u], i + u * 256);
+    }
+    for (; i < hi; i += 256) one(dout[i], x[i], mask_at(i), i);
+}
+
 extern "C" int fb_bn_bwd_apply(const void* dout, const void* y, const void* mask, const void* x, const float* coef, void* dx, void* dy_out,
                                int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t dtype, void* stream) {
     if (!dout || !x || !coef || !dx) FB_FAIL(FB_ERR_ARG, "fb_bn_bwd_apply: null pointer");
     const int V = dtype == FB_F32 ? 4 : 8;
     const int cvec = C / V;
     const long long n_vec = n_pixels * cvec, vpg = pixels_per_group * cvec;
+    if (256 % cvec == 0 && vpg > 0) {
+        const int span = bn_span(n_vec);
+        const dim3 grid((unsigned)((vpg + span - 1) / span), (unsigned)((n_vec + vpg - 1) / vpg));
+        if (dtype == FB_F32)
+            hipLaunchKernelGGL((bn_bwd_apply_span_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const uint4*)dout, (const uint4*)y,
+                               (const unsigned char*)mask, (const uint4*)x, coef, (uint4*)dx, (uint4*)dy_out, n_vec, cvec, vpg, C, span);
+        else
+            hipLaunchKernelGGL((bn_bwd_apply_span_kernel<bf16_tag>), grid, dim3(256), 0, (hipStream_t)stream, (const uint4*)dout, (const uint4*)y,
+                               (const unsigned char*)mask, (const uint4*)x, coef, (uint4*)dx, (uint4*)dy_out, n_vec, cvec, vpg, C, span);
+        FB_CHECK_LAUNCH("fb_bn_bwd_apply");
+        return FB_OK;
+    }
     const int blocks = (int)((n_vec + 255) / 256 < 8192 ? (n_vec + 255) / 256 : 8192);
     if (dtype == FB_F32)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)dout, (const uint4*)y,

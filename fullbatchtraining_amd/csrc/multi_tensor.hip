@@ -239,3 +239,40 @@ extern "C" int fb_mt_scale(float* x, int64_t n, float a, void* stream) {
     FB_CHECK_LAUNCH("fb_mt_scale");
     return FB_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Sharpness-aware minimisation around the full-batch closure (reference additional_optimizers/sam.py:56-82): the ascent step
+// e_w = g_c * rho / (|g_c| + 1e-12), theta += e_w with g_c the closure's (clipped, training.py:198-206) gradient, and the exact
+// way back theta -= e_w.  All scalars come from the device norm: no host round trip between the two gradient evaluations.
+__global__ void mt_sam_ascent_kernel(float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ e_w, long long n,
+                                     const float* __restrict__ gnorm2, float grad_clip, float rho) {
+    const float norm = sqrtf(gnorm2[0]);
+    const float coef = (grad_clip >= 0.f && norm > grad_clip) ? grad_clip / (norm + 1e-6f) : 1.f;
+    const float scale = rho / (norm * coef + 1e-12f);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float e = (grad[i] * coef) * scale;
+        e_w[i] = e;
+        theta[i] += e;
+    }
+}
+extern "C" int fb_mt_sam_ascent(float* theta, const float* grad, float* e_w, int64_t n, const float* gnorm2, float grad_clip, float rho,
+                                void* stream) {
+    if (!theta || !grad || !e_w || !gnorm2) FB_FAIL(FB_ERR_ARG, "fb_mt_sam_ascent: null pointer");
+    if (rho < 0.f) FB_FAIL(FB_ERR_ARG, "fb_mt_sam_ascent: rho=%g must be non-negative", (double)rho);
+    const int64_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(mt_sam_ascent_kernel, dim3((unsigned)(nb < 4096 ? (nb < 1 ? 1 : nb) : 4096)), dim3(256), 0, (hipStream_t)stream, theta, grad,
+                       e_w, (long long)n, gnorm2, grad_clip, rho);
+    FB_CHECK_LAUNCH("fb_mt_sam_ascent");
+    return FB_OK;
+}
+__global__ void mt_sam_restore_kernel(float* __restrict__ theta, const float* __restrict__ e_w, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) theta[i] -= e_w[i];
+}
+extern "C" int fb_mt_sam_restore(float* theta, const float* e_w, int64_t n, void* stream) {
+    if (!theta || !e_w) FB_FAIL(FB_ERR_ARG, "fb_mt_sam_restore: null pointer");
+    const int64_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(mt_sam_restore_kernel, dim3((unsigned)(nb < 4096 ? (nb < 1 ? 1 : nb) : 4096)), dim3(256), 0, (hipStream_t)stream, theta, e_w,
+                       (long long)n);
+    FB_CHECK_LAUNCH("fb_mt_sam_restore");
+    return FB_OK;
+}

@@ -355,6 +355,10 @@ class Engine:
         flat = self.mom.detach().cpu()
         return [self._unflatten(flat, name) for name in self.plan.param_names]
 
+    def sam_state(self):
+        flat = self.e_w.detach().cpu()
+        return [self._unflatten(flat, name) for name in self.plan.param_names]
+
     def load_momentum(self, tensors):
         flat = torch.zeros(self.plan.P)
         for name, t in zip(self.plan.param_names, tensors):
@@ -457,7 +461,7 @@ class Engine:
         n = G * self.chunk
         px = n * L.hout * L.wout
         ppg = self.chunk * L.hout * L.wout
-        n_mblocks = (px + 127) // 128
+        n_mblocks = lib.load().fb_bn_bwd_reduce_rows(px, ppg)
         bits = self.masks.get(mask.data_ptr()) if mask is not None else None      # bitmask written by the forward bn_apply
         y = None if bits is not None else mask
         call("fb_bn_bwd_reduce", dout.data_ptr(), _ptr(y), _ptr(bits), L.x.data_ptr(), self.mean_tab[pidx].data_ptr(), L.invstd.data_ptr(),
@@ -667,6 +671,18 @@ class Engine:
              self.norms2.data_ptr(), -1.0 if grad_clip is None else float(grad_clip), float(lr), float(weight_decay), float(momentum),
              float(dampening), 1 if nesterov else 0, 1 if self.first_step else 0)
         self.first_step = False
+
+    def sam_ascent(self, rho, grad_clip=None):
+        """SAM first step (reference additional_optimizers/sam.py:56-69) on the arena: theta += e_w with e_w = rho * g / |g| of the
+        (clipped) averaged gradient; needs ``self.norms2[0]`` = |avg|^2 (``grad_and_param_sqnorm``).  e_w is kept for the way back."""
+        if getattr(self, "e_w", None) is None:
+            self.e_w = torch.zeros_like(self.theta)
+        call("fb_mt_sam_ascent", self.theta.data_ptr(), self.avg.data_ptr(), self.e_w.data_ptr(), self.plan.P, self.norms2.data_ptr(),
+             -1.0 if grad_clip is None else float(grad_clip), float(rho))
+
+    def sam_restore(self):
+        """SAM second step, first half (sam.py:72-77): theta -= e_w (the same rounding as the reference's ``p.sub_(e_w)``)."""
+        call("fb_mt_sam_restore", self.theta.data_ptr(), self.e_w.data_ptr(), self.plan.P)
 
     # ------------------------------------------------------------------------------------------------------ evaluation --
     def evaluate_batch(self, patches, labels):

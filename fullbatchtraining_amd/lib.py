@@ -60,9 +60,11 @@ _SIGS = {
     "fb_mt_norms2": [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p],
     "fb_mt_clip_sgd": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_float, c_float, c_float, c_float, c_float, c_int, c_int, c_void_p],
     "fb_mt_scale": [c_void_p, c_i64, c_float, c_void_p],
+    "fb_mt_sam_ascent": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_float, c_float, c_void_p],
+    "fb_mt_sam_restore": [c_void_p, c_void_p, c_i64, c_void_p],
 }
 EXPORTS = tuple(_SIGS) + ("fb_last_error_string", "fb_abi_version", "fb_profile_enable", "fb_profile_read", "fb_ws_conv_stat_floats",
-                          "fb_ws_wgrad_slab_floats", "fb_ws_bn_partial_floats", "fb_ws_mt_floats")
+                          "fb_ws_wgrad_slab_floats", "fb_ws_bn_partial_floats", "fb_ws_mt_floats", "fb_bn_bwd_reduce_rows")
 PROF_CLASSES = ("igemm_fwd", "igemm_dgrad", "wgrad")
 
 
@@ -106,6 +108,7 @@ def load():
         lib.fb_ws_wgrad_slab_floats.argtypes, lib.fb_ws_wgrad_slab_floats.restype = [C.POINTER(WgradArgs)], c_i64
         lib.fb_ws_bn_partial_floats.argtypes, lib.fb_ws_bn_partial_floats.restype = [c_i64, c_int], c_i64
         lib.fb_ws_mt_floats.argtypes, lib.fb_ws_mt_floats.restype = [c_int], c_i64
+        lib.fb_bn_bwd_reduce_rows.argtypes, lib.fb_bn_bwd_reduce_rows.restype = [c_i64, c_i64], c_int
         _lib = lib
     return _lib
 

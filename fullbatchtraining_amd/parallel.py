@@ -108,8 +108,9 @@ def combine_running_stats(r0, r_local, plan, updates_per_chunk, momentum=0.1, gr
     return out
 
 
-def sharded_update(trainer, loss_k, correct_k, sq_k, lr):
-    """Product wiring of the above for ``FullBatchTrainer`` (HIP kernels as ShardOps)."""
+def sharded_update(trainer, loss_k, correct_k, sq_k, lr, weight_decay=None):
+    """Product wiring of the above for ``FullBatchTrainer`` (HIP kernels as ShardOps).  ``weight_decay`` overrides hyp.optim's (the
+    LARS / LARC wrappers step without it)."""
     from .lib import call
     eng, hyp, plan = trainer.engine, trainer.cfg.hyp, trainer.shard
     o = hyp.optim
@@ -124,7 +125,7 @@ def sharded_update(trainer, loss_k, correct_k, sq_k, lr):
 
     def update(lo, n, gnorm2):
         eng.norms2[0:1].copy_(gnorm2)
-        eng.sgd_step(lr, o.weight_decay, o.momentum, o.dampening, o.nesterov, hyp.grad_clip, lo=lo, n=n)
+        eng.sgd_step(lr, o.weight_decay if weight_decay is None else weight_decay, o.momentum, o.dampening, o.nesterov, hyp.grad_clip, lo=lo, n=n)
 
     # parameter norm of the (replicated) pre-update parameters for the stats
     call("fb_mt_norms2", eng.theta.data_ptr(), None, P, eng.norms2.data_ptr(), eng.mt_ws.data_ptr())

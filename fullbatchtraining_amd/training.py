@@ -77,12 +77,18 @@ def optim_interface(model, cfg_hyp):
     if cfg_hyp.optim.name != "Gradient Descent" or cfg_hyp.optim.get("line_search", "none") != "none":
         raise NotImplementedError(f"optimizer {cfg_hyp.optim.name!r}/{cfg_hyp.optim.get('line_search')!r}: only plain gradient "
                                   "descent with Nesterov momentum is fused into the engine")
-    if cfg_hyp.optim_modification.name != "none":
-        raise NotImplementedError(f"optim_modification {cfg_hyp.optim_modification.name!r} is outside the engine's scope")
+    mod = cfg_hyp.optim_modification.name
+    if mod not in ("none", "SAM", "LARS", "LARC"):
+        raise ValueError(f"Invalid optim_modification {mod} provided.")
     if cfg_hyp.only_linear_layers_weight_decay:
         raise NotImplementedError("only_linear_layers_weight_decay=True needs per-tensor weight decay (not on the hot path)")
     params = {k: v for k, v in cfg_hyp.optim.items() if k not in ("name", "line_search")}
-    optimizer = torch.optim.SGD(model.parameters(), **params)
+    optimizer = wrapped = torch.optim.SGD(model.parameters(), **params)
+    if mod == "SAM":
+        wrapped = SAM(optimizer, rho=cfg_hyp.optim_modification.rho)
+    elif mod in ("LARS", "LARC"):
+        wrapped = LARS(optimizer, trust_coefficient=cfg_hyp.optim_modification.trust_coefficient, clip=mod == "LARC",
+                       eps=cfg_hyp.optim_modification.eps)
     sched = cfg_hyp.scheduler
     if sched == "cosine-decay-floored":
         scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, cfg_hyp.steps, eta_min=cfg_hyp.optim.lr / 25)
@@ -101,7 +107,51 @@ def optim_interface(model, cfg_hyp):
         raise ValueError(f"Invalid scheduler {sched} provided.")
     if cfg_hyp.warmup > 0:
         scheduler = GradualWarmupScheduler(optimizer, multiplier=1.0, total_epoch=cfg_hyp.warmup, after_scheduler=scheduler)
-    return optimizer, scheduler
+    return wrapped, scheduler            # the scheduler drives the wrapped SGD (reference optimizers.py:67 `optimizer.optim`)
+
+
+class _OptimizerWrapper:
+    """State container with the reference wrappers' surface (``.optim``, shared ``param_groups``, attribute pass-through, pickling
+    via the wrapped optimizer; reference additional_optimizers/sam.py:34-54, lars.py:41-59).  The arithmetic runs in the engine."""
+
+    def __init__(self, optimizer):
+        self.optim = optimizer
+        self.param_groups = optimizer.param_groups
+
+    def __getstate__(self):
+        return self.optim.__getstate__()
+
+    def __setstate__(self, state):
+        self.optim.__setstate__(state)
+
+    def __repr__(self):
+        return self.optim.__repr__()
+
+    def __getattr__(self, name):
+        if name == "optim":
+            raise AttributeError(name)
+        return getattr(self.optim, name)
+
+
+class SAM(_OptimizerWrapper):
+    """Sharpness-aware minimisation (reference additional_optimizers/sam.py): the step evaluates the full-batch closure twice --
+    ``FullBatchTrainer.step`` runs closure -> ``Engine.sam_ascent`` -> closure -> ``Engine.sam_restore`` -> SGD update."""
+
+    def __init__(self, optimizer, rho=0.05):
+        assert rho >= 0.0, f"Invalid rho, should be non-negative: {rho}"
+        super().__init__(optimizer)
+        self.rho = rho
+
+
+class LARS(_OptimizerWrapper):
+    """LARS / LARC wrapper (reference additional_optimizers/lars.py).  Around a closure the reference's wrapper has exactly one
+    effect: it rescales ``p.grad`` of the PREVIOUS step, zeroes the group weight decay and then calls ``SGD.step(closure)``, whose
+    closure assigns fresh gradients (training.py:183-184) -- the update is plain SGD without weight decay, independent of
+    ``trust_coefficient`` / ``clip`` / ``eps`` (pinned against the reference in tests/golden/scenarios_n4.npz)."""
+
+    def __init__(self, optimizer, trust_coefficient=0.02, clip=False, eps=1e-8):
+        super().__init__(optimizer)
+        self.trust_coefficient, self.clip, self.eps = trust_coefficient, clip, eps
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -113,6 +163,9 @@ def _sync_optimizer_state(engine, model, optimizer):
         return
     for p, buf in zip(model.parameters(), engine.momentum_state()):
         optimizer.state[p]["momentum_buffer"] = buf.to(p.device, p.dtype)
+    if getattr(engine, "e_w", None) is not None:       # SAM keeps its last ascent step in the wrapped optimizer's state (sam.py:66)
+        for p, e in zip(model.parameters(), engine.sam_state()):
+            optimizer.state[p]["e_w"] = e.to(p.device, p.dtype)
 
 
 def _save_to_checkpoint(model, optimizer, scheduler, scaler, counter, file="checkpoints/fb.pth", engine=None):
@@ -173,6 +226,8 @@ def _check_scope(cfg):
                                       "(other BN batches than the main loop)")
         if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             raise NotImplementedError("grad_reg.acc_strength in the sharded path")
+    if hyp.optim_modification.name == "SAM" and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        raise NotImplementedError("optim_modification=SAM in the sharded path")
     if hyp.batch_clip is not None or hyp.norm_bias.strength > 0 or hyp.grad_noise["additive"] is not None \
             or hyp.grad_noise["multiplicative"] is not None or hyp.evaluate_ema:
         raise NotImplementedError("batch_clip / norm_bias / grad_noise / EMA evaluation are off the hot path")
@@ -265,19 +320,37 @@ class FullBatchTrainer:
         gr = hyp.grad_reg
         if self.world > 1:
             self._running0 = torch.stack([eng.running_mean, eng.running_var]).clone()
-        loss_k, correct_k, sq_k = eng.full_gradient(self.patches, self.labels, lr, gr.block_strength, gr.eps, gr.implementation,
-                                                    acc_strength=gr.acc_strength)
-        self._pre_sqnorm = None
-        if gr.acc_strength != 0:             # |pre_grads|^2 for full_loss (reference training.py:98-101)
-            lib.call("fb_mt_norms2", eng.pre.data_ptr(), None, eng.plan.P, eng.norms2.data_ptr(), eng.mt_ws.data_ptr())
-            self._pre_sqnorm = eng.norms2[0:1].clone()
+        mod = hyp.optim_modification.name
+
+        def closure():
+            """``gradient_evaluation`` (reference training.py:217-225) up to the clip, which is fused into the consumer of ``eng.avg``."""
+            out = eng.full_gradient(self.patches, self.labels, lr, gr.block_strength, gr.eps, gr.implementation, acc_strength=gr.acc_strength)
+            self._pre_sqnorm = None
+            if gr.acc_strength != 0:             # |pre_grads|^2 for full_loss (reference training.py:98-101)
+                lib.call("fb_mt_norms2", eng.pre.data_ptr(), None, eng.plan.P, eng.norms2.data_ptr(), eng.mt_ws.data_ptr())
+                self._pre_sqnorm = eng.norms2[0:1].clone()
+            return out
+
+        loss_k, correct_k, sq_k = closure()
         if self.world > 1:
             from .parallel import sharded_update
-            loss_k, correct_k, sq_k = sharded_update(self, loss_k, correct_k, sq_k, lr)
+            loss_k, correct_k, sq_k = sharded_update(self, loss_k, correct_k, sq_k, lr,
+                                                    weight_decay=0.0 if mod in ("LARS", "LARC") else None)
         else:
-            norms = eng.grad_and_param_sqnorm()
             o = hyp.optim
-            eng.sgd_step(lr, o.weight_decay, o.momentum, o.dampening, o.nesterov, hyp.grad_clip)
+            eng.grad_and_param_sqnorm()
+            if mod == "SAM":                     # sam.py:84-92: closure, first_step, closure, second_step; stats are recorded twice
+                self._record_stats(loss_k, correct_k, sq_k, eng.norms2, lr, train_time)
+                eng.sam_ascent(self.optimizer.rho, hyp.grad_clip)
+                loss_k, correct_k, sq_k = closure()
+                eng.grad_and_param_sqnorm()      # param_norm of the second record is taken at theta + e_w, like the reference's
+                self._record_stats(loss_k, correct_k, sq_k, eng.norms2, lr, train_time)
+                eng.sam_restore()
+                eng.sgd_step(lr, o.weight_decay, o.momentum, o.dampening, o.nesterov, hyp.grad_clip)
+                self.scheduler.step()
+                return
+            # LARS / LARC: the wrapper zeroes the weight decay around SGD.step(closure) and nothing else survives the closure (see LARS)
+            eng.sgd_step(lr, 0.0 if mod in ("LARS", "LARC") else o.weight_decay, o.momentum, o.dampening, o.nesterov, hyp.grad_clip)
         self._record_stats(loss_k, correct_k, sq_k, eng.norms2, lr, train_time)
         self.scheduler.step()
 

@@ -80,7 +80,7 @@ int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream);
  * no launch.  The library never allocates device memory.
  *   fb_ws_conv_stat_floats   : stat_partial of fb_conv2d(mode 0)  = 2 * ceil(n_img*Hd*Wd / 128) * Cd
  *   fb_ws_wgrad_slab_floats  : dw_partial of fb_conv2d_wgrad      = (n_img/imgs_per_group) * split_k * Cd * R*S * Cs
- *   fb_ws_bn_partial_floats  : partial of fb_bn_bwd_reduce        = 2 * ceil(n_pixels / 128) * C
+ *   fb_ws_bn_partial_floats  : partial of fb_bn_bwd_reduce        = 2 * ceil(n_pixels / 128) * C   (upper bound)
  *   fb_ws_mt_floats          : ws of the fb_mt_* reductions       = max(n_groups, 2) * FB_MT_BLOCKS */
 int64_t fb_ws_conv_stat_floats(const fb_conv_args* a);
 int64_t fb_ws_wgrad_slab_floats(const fb_wgrad_args* a);
@@ -115,7 +115,9 @@ int fb_bn_apply(const void* x, void* y, const float* scale, const float* shift, 
  * exactly the order in which the reference's sequential loop touches the buffers. */
 int fb_bn_running_update(float* running_mean, float* running_var, const float* mean_tab, const float* var_tab, int32_t n_passes,
                          int64_t pass_stride, const float* unbias, int32_t n_groups, int32_t ch_total, float momentum, void* stream);
-/* backward: partial sums of dy and dy*xhat with dy = dout * (y > 0) when y != NULL (threshold_backward). */
+/* backward: partial sums of dy and dy*xhat with dy = dout * (y > 0) when y != NULL (threshold_backward).  One partial row per
+ * workgroup of 128..1024 pixels: fb_bn_bwd_reduce_rows() is the row count to hand to fb_bn_bwd_finalize as n_mblocks. */
+int32_t fb_bn_bwd_reduce_rows(int64_t n_pixels, int64_t pixels_per_group);
 int fb_bn_bwd_reduce(const void* dout, const void* y, const void* mask, const void* x, const float* mean_tab, const float* invstd,
                      int32_t ch_total, int32_t ch_off, float* partial, int64_t n_pixels, int32_t C,
                      int64_t pixels_per_group, int32_t dtype, void* stream);
@@ -185,6 +187,10 @@ int fb_mt_clip_sgd(float* theta, float* grad, float* mom, int64_t n, const float
                    float weight_decay, float momentum, float dampening, int32_t nesterov, int32_t first_step, void* stream);
 /* y = a*x (+ y*b)  flat helpers used by the sharded path (scale local mean by K_r/K) */
 int fb_mt_scale(float* x, int64_t n, float a, void* stream);
+/* SAM around the closure (additional_optimizers/sam.py:56-82).  ascent: with g_c = grad * clip coefficient (as
+ * fb_mt_clip_sgd, training.py:198-206; grad_clip < 0: none) e_w = g_c * rho / (|g_c| + 1e-12), theta += e_w; restore: theta -= e_w. */
+int fb_mt_sam_ascent(float* theta, const float* grad, float* e_w, int64_t n, const float* gnorm2, float grad_clip, float rho, void* stream);
+int fb_mt_sam_restore(float* theta, const float* e_w, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -458,12 +458,48 @@ class LRSchedule:
 # One full-batch step (reference training.py:121-239) and a small training loop
 # ----------------------------------------------------------------------------------------------------------------------
 def full_batch_step(spec, params, buffers, momentum, X, Y, hyp, lr, stats, chunk, q=identity, chunk_range=None):
-    """One optimizer step: accumulate over chunks, record stats, clip, Nesterov SGD.
+    """One optimizer step = ``optimizer.step(gradient_evaluation)`` (reference training.py:226-237).
 
-    ``hyp``: dict(weight_decay, momentum, nesterov, dampening, block_strength, eps, implementation, grad_clip).
-    ``chunk``: images per chunk (= min(data.batch_size, hyp.sub_batch) for the default one-chunk-per-block layout).
-    Returns the averaged (and clipped) gradient list.
+    ``hyp``: dict(weight_decay, momentum, nesterov, dampening, block_strength, eps, implementation, grad_clip[, acc_strength,
+    optim_modification=dict(name=...)]).  ``chunk``: images per chunk.  Returns the averaged (and clipped) gradient list the update used.
+
+    ``optim_modification`` (reference optimizers.py:57-67):
+      * none: torch SGD evaluates the closure once, then steps.
+      * SAM (additional_optimizers/sam.py:84-92): closure -> e = rho * g / (|g| + 1e-12) (g already clipped by the closure) -> p += e ->
+        closure again (stats recorded a second time, BN buffers updated again) -> p -= e -> SGD step with the second gradient.
+      * LARS / LARC (additional_optimizers/lars.py:61-94): the wrapper rescales ``p.grad`` -- the gradients of the PREVIOUS step -- zeroes
+        the group weight decay, and only then calls ``SGD.step(closure)``; the closure assigns fresh ``p.grad`` tensors
+        (training.py:183-184), so the rescaling never reaches the update and the step is plain SGD WITHOUT weight decay.
     """
+    mod = (hyp.get("optim_modification") or {}).get("name", "none")
+
+    def closure():
+        return _gradient_evaluation(spec, params, buffers, X, Y, hyp, lr, stats, chunk, q, chunk_range)
+
+    if mod == "SAM":
+        g1 = closure()
+        grad_norm = torch.norm(torch.stack([g.norm(p=2) for g in g1]), p=2)          # sam.py:94-104
+        scale = hyp["optim_modification"]["rho"] / (grad_norm + 1e-12)
+        e_w = [g * scale for g in g1]
+        for p, e in zip(params.values(), e_w):
+            p.add_(e)
+        avg = closure()
+        for p, e in zip(params.values(), e_w):
+            p.sub_(e)
+        sgd_step(params, avg, momentum, lr, hyp)
+    elif mod in ("LARS", "LARC"):
+        avg = closure()                       # replaces whatever the wrapper did to the stale gradients
+        sgd_step(params, avg, momentum, lr, dict(hyp, weight_decay=0.0))
+    elif mod == "none":
+        avg = closure()
+        sgd_step(params, avg, momentum, lr, hyp)
+    else:
+        raise ValueError(mod)
+    return avg
+
+
+def _gradient_evaluation(spec, params, buffers, X, Y, hyp, lr, stats, chunk, q=identity, chunk_range=None):
+    """The closure (reference training.py:217-225): ``_accumulate_full_gradient`` + ``_record_stats`` + ``_modify_gradient_params``."""
     names = list(params)
     n_chunks = X.shape[0] // chunk  # drop_last=True, reference data_preparation.py:68 (SURVEY T1)
     acc = hyp.get("acc_strength", 0.0)
@@ -516,7 +552,6 @@ def full_batch_step(spec, params, buffers, momentum, X, Y, hyp, lr, stats, chunk
             stats["clipped_step"].append(1)
         else:
             stats["clipped_step"].append(0)
-    sgd_step(params, avg, momentum, lr, hyp)
     return avg
 
 

@@ -22,9 +22,10 @@ def golden():
     with open(os.path.join(here, "meta.json")) as handle:
         meta = json.load(handle)
     data = dict(np.load(os.path.join(here, "scenarios.npz")))
-    extra = os.path.join(here, "scenarios_extra.npz")            # scenarios added later (make_golden.py --extra)
-    if os.path.isfile(extra):
-        data.update(np.load(extra))
-        with open(os.path.join(here, "meta_extra.json")) as handle:
-            meta["scenarios"].update(json.load(handle)["scenarios"])
+    for tag in ("extra", "n4"):                                  # scenarios added later (make_golden.py --extra / --n4)
+        extra = os.path.join(here, f"scenarios_{tag}.npz")
+        if os.path.isfile(extra):
+            data.update(np.load(extra))
+            with open(os.path.join(here, f"meta_{tag}.json")) as handle:
+                meta["scenarios"].update(json.load(handle)["scenarios"])
     return data, meta

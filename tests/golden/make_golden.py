@@ -97,8 +97,22 @@ SCENARIOS_EXTRA = {
 }
 
 
+# optimizer wrappers that consume the full-batch closure (optimizers.py:57-67, additional_optimizers/sam.py:84-92,
+# lars.py:61-94); own files again (scenarios_n4.npz, meta_n4.json, `--n4`).  SAM evaluates the closure twice per step (stats are
+# recorded twice); LARS/LARC call the wrapped SGD with the closure AFTER rescaling p.grad, so the closure's fresh gradients replace
+# the rescaled ones and the wrapper's only effect is the weight decay it zeroes around the step.
+SCENARIOS_N4 = {
+    "fb_sam": (128, 16, ["hyp=fbclip", "hyp/optim_modification=SAM", "hyp.steps=3", "hyp.warmup=1", "data.batch_size=32", "hyp.sub_batch=32"], 11),
+    "fb_sam_gradreg": (128, 16, ["hyp=fb1", "hyp/optim_modification=SAM", "hyp.optim_modification.rho=0.1", "hyp.steps=2", "hyp.warmup=0",
+                                 "hyp.grad_reg.block_strength=0.5", "data.batch_size=64", "hyp.sub_batch=64"], 13),
+    "fb_lars": (128, 16, ["hyp=fb1", "hyp/optim_modification=LARS", "hyp.steps=3", "hyp.warmup=0", "data.batch_size=64", "hyp.sub_batch=64"], 15),
+    "fb_larc": (128, 16, ["hyp=fbclip", "hyp/optim_modification=LARC", "hyp.steps=3", "hyp.warmup=0", "data.batch_size=64", "hyp.sub_batch=64"], 17),
+}
+ALL_SCENARIOS = {**SCENARIOS, **SCENARIOS_EXTRA, **SCENARIOS_N4}
+
+
 def run_scenario(fullbatch, compose, scen, out, dtype=torch.float):
-    n, pixels, overrides, mseed = (SCENARIOS[scen] if scen in SCENARIOS else SCENARIOS_EXTRA[scen])
+    n, pixels, overrides, mseed = ALL_SCENARIOS[scen]
     name = scen if dtype == torch.float else f"{scen}@f64"
     tmp = tempfile.mkdtemp()
     extra = ["impl.accumulation_dtype=double"] if dtype == torch.double else []  # else the f64 run accumulates/updates in fp32
@@ -227,6 +241,22 @@ def main_extra():
     print("wrote", os.path.join(HERE, "scenarios_extra.npz"), os.path.join(HERE, "meta_extra.json"))
 
 
+def main_n4():
+    torch.set_num_threads(8)
+    fullbatch = import_reference()
+    from fullbatchtraining_amd.cfg import compose
+
+    out = {}
+    for name in SCENARIOS_N4:
+        run_scenario(fullbatch, compose, name, out)
+        run_scenario(fullbatch, compose, name, out, dtype=torch.double)
+    np.savez_compressed(os.path.join(HERE, "scenarios_n4.npz"), **out)
+    meta = dict(scenarios={k: dict(n=v[0], pixels=v[1], overrides=v[2], model_seed=v[3]) for k, v in SCENARIOS_N4.items()})
+    with open(os.path.join(HERE, "meta_n4.json"), "w") as handle:
+        json.dump(meta, handle, indent=1)
+    print("wrote", os.path.join(HERE, "scenarios_n4.npz"), os.path.join(HERE, "meta_n4.json"))
+
+
 def main():
     torch.set_num_threads(8)
     fullbatch = import_reference()
@@ -255,4 +285,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main_extra() if "--extra" in sys.argv else main()
+    main_n4() if "--n4" in sys.argv else (main_extra() if "--extra" in sys.argv else main())

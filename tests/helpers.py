@@ -24,7 +24,7 @@ def hyp_from_cfg(cfg):
     return dict(lr=o.lr, weight_decay=o.weight_decay, momentum=o.momentum, nesterov=o.nesterov, dampening=o.dampening,
                 block_strength=cfg.hyp.grad_reg.block_strength, eps=cfg.hyp.grad_reg.eps,
                 implementation=cfg.hyp.grad_reg.implementation, grad_clip=cfg.hyp.grad_clip,
-                acc_strength=cfg.hyp.grad_reg.acc_strength)
+                acc_strength=cfg.hyp.grad_reg.acc_strength, optim_modification=dict(cfg.hyp.optim_modification))
 
 
 def rel_err(a, b):

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), name
     assert set(lib.EXPORTS) == declared
-    assert handle.fb_abi_version() == 3
+    assert handle.fb_abi_version() == 4
 
 
 def test_workspace_size_queries():
@@ -38,6 +38,9 @@ def test_workspace_size_queries():
     wg = lib.WgradArgs(n_img=256, imgs_per_group=128, split_k=5, Cd=128, R=3, S=3, Cs=64)
     assert h.fb_ws_wgrad_slab_floats(lib.C.byref(wg)) == 2 * 5 * 128 * 9 * 64
     assert h.fb_ws_bn_partial_floats(1000, 64) == 2 * 8 * 64
+    # fb_bn_bwd_reduce: 128..1024 pixels per partial row, whole rows inside one statistics group, >= 2048 rows when possible
+    assert h.fb_bn_bwd_reduce_rows(4992 * 1024, 128 * 1024) == 4992 and h.fb_bn_bwd_reduce_rows(4992 * 256, 128 * 256) == 2496
+    assert h.fb_bn_bwd_reduce_rows(4992 * 16, 128 * 16) == 624 and h.fb_bn_bwd_reduce_rows(1000, 128) == 8
     assert h.fb_ws_mt_floats(1) == 2 * lib.MT_BLOCKS and h.fb_ws_mt_floats(39) == 39 * lib.MT_BLOCKS
 
 
@@ -107,6 +110,34 @@ def test_out_of_scope_options_raise():
     cfg.hyp.optim.name = "L-BFGS"
     with pytest.raises(NotImplementedError):
         optim_interface(torch.nn.Linear(2, 2), cfg.hyp)
+
+
+def test_optimizer_wrappers_have_the_reference_surface():
+    """optim_modification = SAM / LARS / LARC (reference optimizers.py:57-67): wrapper objects with ``.optim``, shared param_groups,
+    attribute pass-through to the wrapped SGD, scheduler bound to the wrapped optimizer, state_dict of the wrapped optimizer."""
+    from fullbatchtraining_amd.cfg import compose
+    from fullbatchtraining_amd.training import LARS, SAM, optim_interface
+
+    net = torch.nn.Linear(2, 2)
+    for mod, cls in (("SAM", SAM), ("LARS", LARS), ("LARC", LARS)):
+        cfg = compose(["hyp=fbclip", f"hyp/optim_modification={mod}"])
+        assert cfg.hyp.optim_modification.name == mod
+        optimizer, scheduler = optim_interface(net, cfg.hyp)
+        assert isinstance(optimizer, cls) and isinstance(optimizer.optim, torch.optim.SGD)
+        assert optimizer.param_groups is optimizer.optim.param_groups and optimizer.state is optimizer.optim.state
+        assert optimizer.state_dict().keys() == optimizer.optim.state_dict().keys()
+        assert scheduler.optimizer is optimizer.optim
+        lr0 = optimizer.param_groups[0]["lr"]
+        scheduler.step()
+        assert optimizer.param_groups[0]["lr"] != lr0            # warm-up drives the shared groups
+    sam, _ = optim_interface(net, compose(["hyp=fb1", "hyp/optim_modification=SAM", "hyp.optim_modification.rho=0.1"]).hyp)
+    assert sam.rho == 0.1
+    larc, _ = optim_interface(net, compose(["hyp=fb1", "hyp/optim_modification=LARC"]).hyp)
+    assert larc.clip is True and larc.trust_coefficient == 0.02 and larc.eps == 1e-8
+    bad = compose(["hyp=fb1"])
+    bad.hyp.optim_modification.name = "Lookahead"
+    with pytest.raises(ValueError):
+        optim_interface(net, bad.hyp)
 
 
 def test_shard_plan_partitions_chunks():

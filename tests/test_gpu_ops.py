@@ -219,7 +219,7 @@ def test_batchnorm_fwd_bwd(dtype, C, hw, ipg, groups):
              part2.data_ptr(), px, C, ppg, lib.dtype_code(dtype))
     gout = torch.zeros(groups, 2 * C + 64, device="cuda")
     coef = torch.zeros(groups, C, 3, device="cuda")
-    lib.call("fb_bn_bwd_finalize", part2.data_ptr(), nblk, groups, C, float(ppg), scale.data_ptr(), mean_tab.data_ptr(), invstd.data_ptr(),
+    lib.call("fb_bn_bwd_finalize", part2.data_ptr(), lib.load().fb_bn_bwd_reduce_rows(px, ppg), groups, C, float(ppg), scale.data_ptr(), mean_tab.data_ptr(), invstd.data_ptr(),
              ch_total, ch_off, gout.data_ptr(), gout.data_ptr() + 4 * C, gout.shape[1], coef.data_ptr())
     dx = torch.empty_like(xd)
     dy_out = torch.empty_like(xd)
@@ -421,3 +421,28 @@ def _dp(t):
     d = t.cuda()
     _KEEP.append(d)
     return d.data_ptr()
+
+
+@pytest.mark.parametrize("clip", [None, 0.25, 1e3])
+def test_sam_ascent_and_restore(clip):
+    """fb_mt_sam_ascent / fb_mt_sam_restore vs the reference's first_step / second_step arithmetic (sam.py:56-77) after the
+    closure's clip (training.py:198-206)."""
+    lib = _lib()
+    torch.manual_seed(5)
+    n, rho = 100_003, 0.05
+    theta, g = torch.randn(n), torch.randn(n) * 0.01
+    td, gd, ed = theta.cuda(), g.cuda(), torch.zeros(n, device="cuda")
+    norms2, ws = torch.zeros(2, device="cuda"), torch.zeros(lib.load().fb_ws_mt_floats(1), device="cuda")
+    lib.call("fb_mt_norms2", gd.data_ptr(), None, n, norms2.data_ptr(), ws.data_ptr())
+    lib.call("fb_mt_sam_ascent", td.data_ptr(), gd.data_ptr(), ed.data_ptr(), n, norms2.data_ptr(), -1.0 if clip is None else clip, rho)
+    gc = g.clone()
+    norm = gc.norm()
+    if clip is not None and norm > clip:
+        gc.mul_(clip / (norm + 1e-6))
+    e_ref = gc * (rho / (gc.norm() + 1e-12))
+    assert rel(ed.cpu(), e_ref) < 1e-6 and abs(float(ed.norm()) - rho) < 1e-6
+    assert torch.allclose(td.cpu(), theta + e_ref, rtol=0, atol=1e-6)
+    climbed = td.clone()
+    lib.call("fb_mt_sam_restore", td.data_ptr(), ed.data_ptr(), n)
+    assert torch.equal(td, climbed - ed)                       # the reference's p.sub_(e_w), same rounding
+    assert torch.allclose(td.cpu(), theta, rtol=0, atol=1e-6)
