@@ -276,3 +276,78 @@ extern "C" int fb_mt_sam_restore(float* theta, const float* e_w, int64_t n, void
     FB_CHECK_LAUNCH("fb_mt_sam_restore");
     return FB_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Options of the closure's gradient modification that are off by default (reference training.py:187-211) and the
+// EMA of the evaluated model (training/utils.py:22-29).
+// L-infinity clip norm: out[0] = (max |a_i|)^2, so that the consumers of the squared L2 norm (fb_mt_clip_sgd, fb_mt_sam_ascent,
+// the statistics) work unchanged on sqrt(out[0]).
+__global__ __launch_bounds__(256) void mt_absmax_kernel(const float* __restrict__ a, long long n, float* __restrict__ ws) {
+    __shared__ float sm[256];
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(a[i]));
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] = fmaxf(sm[threadIdx.x], sm[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ws[blockIdx.x] = sm[0];
+}
+__global__ void mt_absmax_finalize_kernel(const float* __restrict__ ws, int nb, float* __restrict__ out) {
+    __shared__ float sm[64];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 64) m = fmaxf(m, ws[i]);
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 64; ++i) m = fmaxf(m, sm[i]);
+        out[0] = m * m;
+    }
+}
+extern "C" int fb_mt_absmax2(const float* a, int64_t n, float* out, float* ws, void* stream) {
+    if (!a || !out || !ws) FB_FAIL(FB_ERR_ARG, "fb_mt_absmax2: null pointer");
+    const int64_t want = (n + 255) / 256;
+    const int nb = (int)(want < 1 ? 1 : (want > FB_MT_BLOCKS ? FB_MT_BLOCKS : want));
+    hipLaunchKernelGGL(mt_absmax_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, (long long)n, ws);
+    hipLaunchKernelGGL(mt_absmax_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ws, nb, out);
+    FB_CHECK_LAUNCH("fb_mt_absmax2");
+    return FB_OK;
+}
+
+// external norm bias (training.py:188-196): norm_type 1: grad += strength * sign(|theta|^2 - bias^2); else grad += strength * 2 (|theta|^2 -
+// bias^2) * theta.  pnorm2 = |theta|^2 over ALL parameters (device scalar); the range [grad, grad + n) is one parameter tensor -- the
+// constant of norm_type 1 must not land in the alignment padding of the arena.
+__global__ void mt_norm_bias_kernel(float* __restrict__ grad, const float* __restrict__ theta, long long n, const float* __restrict__ pnorm2,
+                                    float strength, float bias, int norm_type) {
+    const float diff = pnorm2[0] - bias * bias;
+    const float c = norm_type == 1 ? strength * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) : strength * (2.f * diff);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        grad[i] += norm_type == 1 ? c : c * theta[i];
+}
+extern "C" int fb_mt_norm_bias(float* grad, const float* theta, int64_t n, const float* pnorm2, float strength, float bias, int32_t norm_type,
+                               void* stream) {
+    if (!grad || !theta || !pnorm2) FB_FAIL(FB_ERR_ARG, "fb_mt_norm_bias: null pointer");
+    const int64_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(mt_norm_bias_kernel, dim3((unsigned)(nb < 4096 ? (nb < 1 ? 1 : nb) : 4096)), dim3(256), 0, (hipStream_t)stream, grad, theta,
+                       (long long)n, pnorm2, strength, bias, norm_type);
+    FB_CHECK_LAUNCH("fb_mt_norm_bias");
+    return FB_OK;
+}
+
+// ema = momentum * ema + one_minus * src, two roundings and an add like the reference's tensor expression (no fma contraction)
+__global__ void mt_ema_kernel(float* __restrict__ ema, const float* __restrict__ src, long long n, float momentum, float one_minus) {
+#pragma clang fp contract(off)     // hipcc contracts a*b + c*d into an fma by default (and __fmul_rn / __fadd_rn are plain operators)
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float a = momentum * ema[i], b = one_minus * src[i];
+        ema[i] = a + b;
+    }
+}
+extern "C" int fb_mt_ema(float* ema, const float* src, int64_t n, float momentum, float one_minus, void* stream) {
+    if (!ema || !src) FB_FAIL(FB_ERR_ARG, "fb_mt_ema: null pointer");
+    const int64_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(mt_ema_kernel, dim3((unsigned)(nb < 4096 ? (nb < 1 ? 1 : nb) : 4096)), dim3(256), 0, (hipStream_t)stream, ema, src, (long long)n,
+                       momentum, one_minus);
+    FB_CHECK_LAUNCH("fb_mt_ema");
+    return FB_OK;
+}

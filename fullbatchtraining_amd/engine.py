@@ -672,6 +672,35 @@ class Engine:
              float(dampening), 1 if nesterov else 0, 1 if self.first_step else 0)
         self.first_step = False
 
+    def clip_norm_inf(self):
+        """``hyp.grad_clip_norm=inf`` (reference training.py:199-200): put (max|avg|)^2 into the clip-norm slot ``self.norms2[0]``."""
+        call("fb_mt_absmax2", self.avg.data_ptr(), self.plan.P, self.norms2.data_ptr(), self.mt_ws.data_ptr())
+
+    def norm_bias(self, strength, norm_type, bias):
+        """External norm bias on the averaged gradient (reference training.py:188-196); ``self.norms2[1]`` must hold |theta|^2.
+        One launch per parameter tensor: the constant of norm_type 1 must not land in the arena's alignment padding."""
+        pn2 = self.norms2.data_ptr() + 4
+        for name in self.plan.param_names:
+            off, n = self.plan.offsets[name], math.prod(self.plan.param_shapes[name])
+            call("fb_mt_norm_bias", self.avg.data_ptr() + 4 * off, self.theta.data_ptr() + 4 * off, n, pn2, float(strength), float(bias),
+                 int(norm_type))
+
+    def ema_update(self, momentum):
+        """``_update_ema`` (reference training/utils.py:22-29) for parameters and BN running statistics; the first call makes the
+        copy the reference takes at the start of training (training.py:72-73) -- call ``ema_init`` before the first step."""
+        m, om = float(momentum), float(1 - momentum)
+        for ema, src in ((self.theta_ema, self.theta), (self.running_mean_ema, self.running_mean), (self.running_var_ema, self.running_var)):
+            call("fb_mt_ema", ema.data_ptr(), src.data_ptr(), src.numel(), m, om)
+
+    def ema_init(self):
+        self.theta_ema, self.running_mean_ema, self.running_var_ema = self.theta.clone(), self.running_mean.clone(), self.running_var.clone()
+
+    def swap_ema(self):
+        """Exchange the live parameters / running statistics with their EMA (evaluation of the EMA model; call twice)."""
+        self.theta, self.theta_ema = self.theta_ema, self.theta
+        self.running_mean, self.running_mean_ema = self.running_mean_ema, self.running_mean
+        self.running_var, self.running_var_ema = self.running_var_ema, self.running_var
+
     def sam_ascent(self, rho, grad_clip=None):
         """SAM first step (reference additional_optimizers/sam.py:56-69) on the arena: theta += e_w with e_w = rho * g / |g| of the
         (clipped) averaged gradient; needs ``self.norms2[0]`` = |avg|^2 (``grad_and_param_sqnorm``).  e_w is kept for the way back."""

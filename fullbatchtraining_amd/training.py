@@ -5,7 +5,7 @@ Mirrors, for ``hyp.train_stochastic=False``:
   gradient_evaluation        :226-234   (closure: accumulate, stats, clip)          -> Engine.full_gradient / sgd_step
   _accumulate_full_gradient  :121-185
   _record_stats              :85-119    (same keys, same formulas)
-  _modify_gradient_params    :187-215   (global-norm clip; norm-bias and gradient noise are off-path -> NotImplementedError)
+  _modify_gradient_params    :187-215   (norm bias, global L2 / L-infinity clip; gradient noise -> NotImplementedError)
   evaluate                   :343-388
   get_loss_fn                :391-413   (default CrossEntropyLoss only; it is fused into the head kernel)
   optim_interface            fullbatch/training/optimizers.py:10-93 (Gradient Descent / line_search none; cosine-*, warm-up)
@@ -228,11 +228,15 @@ def _check_scope(cfg):
             raise NotImplementedError("grad_reg.acc_strength in the sharded path")
     if hyp.optim_modification.name == "SAM" and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
         raise NotImplementedError("optim_modification=SAM in the sharded path")
-    if hyp.batch_clip is not None or hyp.norm_bias.strength > 0 or hyp.grad_noise["additive"] is not None \
-            or hyp.grad_noise["multiplicative"] is not None or hyp.evaluate_ema:
-        raise NotImplementedError("batch_clip / norm_bias / grad_noise / EMA evaluation are off the hot path")
-    if hyp.grad_clip is not None and float(hyp.grad_clip_norm) != 2.0:
-        raise NotImplementedError("only the global L2 clip (grad_clip_norm=2) is fused")
+    if hyp.batch_clip is not None:
+        raise NotImplementedError("hyp.batch_clip: the reference's own full-batch loop fails on it (NameError in _record_stats)")
+    if hyp.grad_noise["additive"] is not None or hyp.grad_noise["multiplicative"] is not None:
+        raise NotImplementedError("grad_noise draws from the reference's per-tensor RNG stream; not reproducible on the arena")
+    if hyp.grad_clip is not None and float(hyp.grad_clip_norm) not in (2.0, float("inf")):
+        raise NotImplementedError("grad_clip_norm: the global L2 and L-infinity clips are implemented")
+    sharded = torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+    if sharded and (hyp.norm_bias.strength > 0 or (hyp.grad_clip is not None and float(hyp.grad_clip_norm) != 2.0)):
+        raise NotImplementedError("norm_bias / L-infinity clip in the sharded path")
     if hyp.shuffle:
         raise NotImplementedError("hyp.shuffle=True changes chunk composition every step; resident data is sequential")
 
@@ -338,12 +342,23 @@ class FullBatchTrainer:
                                                     weight_decay=0.0 if mod in ("LARS", "LARC") else None)
         else:
             o = hyp.optim
-            eng.grad_and_param_sqnorm()
+
+            def modify():
+                """``_modify_gradient_params`` up to the clip coefficient (reference training.py:187-204): norm bias on the averaged
+                gradient, then the clip norm (L2 or L-infinity) into ``eng.norms2[0]``; ``eng.norms2[1]`` = |theta|^2."""
+                eng.grad_and_param_sqnorm()
+                if hyp.norm_bias.strength > 0:
+                    eng.norm_bias(hyp.norm_bias.strength, hyp.norm_bias.norm_type, hyp.norm_bias.bias)
+                    eng.grad_and_param_sqnorm()
+                if hyp.grad_clip is not None and float(hyp.grad_clip_norm) == float("inf"):
+                    eng.clip_norm_inf()
+
+            modify()
             if mod == "SAM":                     # sam.py:84-92: closure, first_step, closure, second_step; stats are recorded twice
                 self._record_stats(loss_k, correct_k, sq_k, eng.norms2, lr, train_time)
                 eng.sam_ascent(self.optimizer.rho, hyp.grad_clip)
                 loss_k, correct_k, sq_k = closure()
-                eng.grad_and_param_sqnorm()      # param_norm of the second record is taken at theta + e_w, like the reference's
+                modify()                         # param_norm of the second record is taken at theta + e_w, like the reference's
                 self._record_stats(loss_k, correct_k, sq_k, eng.norms2, lr, train_time)
                 eng.sam_restore()
                 eng.sgd_step(lr, o.weight_decay, o.momentum, o.dampening, o.nesterov, hyp.grad_clip)
@@ -413,14 +428,21 @@ class FullBatchTrainer:
         eng = self.engine
         cap = eng.G * eng.chunk
         loss_sum, correct, n = 0.0, 0.0, 0
-        for i in range(0, X.shape[0], cap):
-            xb, yb = X[i:i + cap], Y[i:i + cap]
-            l, c = eng.evaluate_batch(stem_patches(xb, eng.plan.stem, eng.dt), yb)
-            loss_sum += l * yb.shape[0]
-            correct += c
-            n += yb.shape[0]
-            if self.cfg.dryrun:
-                break
+        ema = bool(self.cfg.hyp.evaluate_ema) and getattr(eng, "theta_ema", None) is not None
+        if ema:                                  # eval_model = ema_model (reference training.py:290-292)
+            eng.swap_ema()
+        try:
+            for i in range(0, X.shape[0], cap):
+                xb, yb = X[i:i + cap], Y[i:i + cap]
+                l, c = eng.evaluate_batch(stem_patches(xb, eng.plan.stem, eng.dt), yb)
+                loss_sum += l * yb.shape[0]
+                correct += c
+                n += yb.shape[0]
+                if self.cfg.dryrun:
+                    break
+        finally:
+            if ema:
+                eng.swap_ema()
         stats["valid_loss"] += [loss_sum / n]
         stats["valid_acc"] += [correct / n]
         return stats
@@ -521,9 +543,13 @@ def train(model, trainloader, validloader, setup, cfg):
         file = os.path.join(cfg.original_cwd, "checkpoints", cfg.impl.checkpoint.name)
         _load_from_checkpoint(model, optimizer, scheduler, None, Counter, cfg.hyp.steps, device="cpu", file=file, engine=eng)
 
+    if cfg.hyp.evaluate_ema:                     # the reference's deepcopy of the (possibly just loaded) model, training.py:72-73
+        eng.ema_init()
     while Counter.step < cfg.hyp.steps:
         trainer.step()
         Counter.step += 1
+        if cfg.hyp.evaluate_ema:                 # training.py:289-294: update after every step, evaluate the EMA model
+            eng.ema_update(cfg.hyp.eval_ema_momentum)
         if (Counter.step - 1) % cfg.impl.validate_every_nth_step == 0 or Counter.step >= cfg.hyp.steps or cfg.dryrun:
             trainer.evaluate()
         if trainer.rank == 0:

@@ -191,6 +191,13 @@ int fb_mt_scale(float* x, int64_t n, float a, void* stream);
  * fb_mt_clip_sgd, training.py:198-206; grad_clip < 0: none) e_w = g_c * rho / (|g_c| + 1e-12), theta += e_w; restore: theta -= e_w. */
 int fb_mt_sam_ascent(float* theta, const float* grad, float* e_w, int64_t n, const float* gnorm2, float grad_clip, float rho, void* stream);
 int fb_mt_sam_restore(float* theta, const float* e_w, int64_t n, void* stream);
+/* gradient-modification options that are off by default (training.py:187-211):
+ *   fb_mt_absmax2  : out[0] = (max|a_i|)^2 -- the L-infinity clip norm (grad_clip_norm=inf, training.py:199-200) in the slot of |a|^2
+ *   fb_mt_norm_bias: external norm bias on ONE parameter tensor (training.py:188-196); pnorm2 = device |theta|^2 of all parameters
+ * and the model EMA used for evaluation (training/utils.py:22-29): ema = momentum*ema + one_minus*src. */
+int fb_mt_absmax2(const float* a, int64_t n, float* out, float* ws, void* stream);
+int fb_mt_norm_bias(float* grad, const float* theta, int64_t n, const float* pnorm2, float strength, float bias, int32_t norm_type, void* stream);
+int fb_mt_ema(float* ema, const float* src, int64_t n, float momentum, float one_minus, void* stream);
 
 #ifdef __cplusplus
 }

@@ -542,9 +542,23 @@ def _gradient_evaluation(spec, params, buffers, X, Y, hyp, lr, stats, chunk, q=i
     stats["param_norm"].append(float(param_norm))
     stats["grad_norm"].append(float(full_grad_norm.sqrt()))
     stats["full_loss"].append(float(full_loss))
-    # _modify_gradient_params (clip part), training.py:198-211
+    # _modify_gradient_params, training.py:187-211: external norm bias, then the clip
+    nb = hyp.get("norm_bias") or {}
+    if nb.get("strength", 0.0) > 0.0:  # training.py:188-196
+        param_norm_l2 = sum(p.pow(2).sum() for p in params.values())
+        if nb["norm_type"] == 1:
+            diff_value_sign = (param_norm_l2 - nb["bias"] ** 2).sign()
+            for g in avg:
+                g.add_(nb["strength"] * diff_value_sign)
+        else:
+            factor = 2 * (param_norm_l2 - nb["bias"] ** 2)
+            for g, p in zip(avg, params.values()):
+                g.add_(nb["strength"] * factor * p)
     if hyp.get("grad_clip") is not None:
-        grad_norm = torch.norm(torch.stack([torch.norm(g, 2) for g in avg]), 2)
+        if float(hyp.get("grad_clip_norm", 2)) == float("inf"):  # training.py:199-200
+            grad_norm = max(g.abs().max() for g in avg)
+        else:
+            grad_norm = torch.norm(torch.stack([torch.norm(g, 2) for g in avg]), 2)
         stats["preclip_gradnorm"].append(float(grad_norm))
         if grad_norm > hyp["grad_clip"]:
             for g in avg:
@@ -589,12 +603,23 @@ def train(spec, state, X, Y, hyp, steps, chunk, scheduler="cosine-decay", warmup
     momentum = [None] * len(params)
     sched = LRSchedule(hyp["lr"], scheduler, steps, warmup)
     stats = defaultdict(list)
+    ema = hyp.get("evaluate_ema", False)
+    if ema:  # training.py:72-73: a deep copy of the model at the start of training
+        ema_params = {k: v.clone() for k, v in params.items()}
+        ema_buffers = {k: v.clone() for k, v in buffers.items()}
     for step in range(steps):
         full_batch_step(spec, params, buffers, momentum, X, Y, hyp, sched.lr, stats, chunk, q)
         stats["lr"].append(sched.lr)
         sched.step()
+        eval_params, eval_buffers = params, buffers
+        if ema:  # _update_ema, training/utils.py:22-29: parameters AND buffers (the long num_batches_tracked truncates on copy_)
+            m = hyp["eval_ema_momentum"]
+            for src, dst in ((params, ema_params), (buffers, ema_buffers)):
+                for k in src:
+                    dst[k].copy_(m * dst[k] + (1 - m) * src[k])
+            eval_params, eval_buffers = ema_params, ema_buffers
         if Xv is not None and (step % validate_every == 0 or step + 1 >= steps):
-            vl, va = evaluate(spec, params, buffers, Xv, Yv, q=q)
+            vl, va = evaluate(spec, eval_params, eval_buffers, Xv, Yv, q=q)
             stats["valid_loss"].append(vl)
             stats["valid_acc"].append(va)
     stats["_momentum"] = momentum

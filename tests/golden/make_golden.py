@@ -108,7 +108,20 @@ SCENARIOS_N4 = {
     "fb_lars": (128, 16, ["hyp=fb1", "hyp/optim_modification=LARS", "hyp.steps=3", "hyp.warmup=0", "data.batch_size=64", "hyp.sub_batch=64"], 15),
     "fb_larc": (128, 16, ["hyp=fbclip", "hyp/optim_modification=LARC", "hyp.steps=3", "hyp.warmup=0", "data.batch_size=64", "hyp.sub_batch=64"], 17),
 }
-ALL_SCENARIOS = {**SCENARIOS, **SCENARIOS_EXTRA, **SCENARIOS_N4}
+# Options of the closure's gradient modification and of the evaluation that are off by default: the
+# L-infinity clip (training.py:199-200), the external norm bias (training.py:188-196) and evaluation of an exponential moving
+# average of the model (training.py:289-294, training/utils.py:22-29).  Files scenarios_a9.npz / meta_a9.json (`--a9`).
+SCENARIOS_A9 = {
+    "fb_clip_inf": (128, 16, ["hyp=fbclip", "hyp.grad_clip=0.01", "hyp.grad_clip_norm=inf", "hyp.steps=3", "hyp.warmup=0", "data.batch_size=64",
+                              "hyp.sub_batch=64"], 19),
+    "fb_normbias1": (128, 16, ["hyp=fbclip", "hyp.norm_bias.strength=0.01", "hyp.norm_bias.norm_type=1", "hyp.norm_bias.bias=10", "hyp.steps=3",
+                               "hyp.warmup=0", "data.batch_size=64", "hyp.sub_batch=64"], 21),
+    "fb_normbias2": (128, 16, ["hyp=fb1", "hyp.norm_bias.strength=1e-4", "hyp.norm_bias.norm_type=2", "hyp.norm_bias.bias=70", "hyp.steps=3",
+                               "hyp.warmup=0", "hyp.optim.weight_decay=0.0", "data.batch_size=64", "hyp.sub_batch=64"], 23),
+    "fb_ema": (128, 16, ["hyp=fb1", "hyp.evaluate_ema=True", "hyp.eval_ema_momentum=0.6", "hyp.steps=3", "hyp.warmup=0", "data.batch_size=64",
+                         "hyp.sub_batch=64"], 25),
+}
+ALL_SCENARIOS = {**SCENARIOS, **SCENARIOS_EXTRA, **SCENARIOS_N4, **SCENARIOS_A9}
 
 
 def run_scenario(fullbatch, compose, scen, out, dtype=torch.float):
@@ -257,6 +270,22 @@ def main_n4():
     print("wrote", os.path.join(HERE, "scenarios_n4.npz"), os.path.join(HERE, "meta_n4.json"))
 
 
+def main_a9():
+    torch.set_num_threads(8)
+    fullbatch = import_reference()
+    from fullbatchtraining_amd.cfg import compose
+
+    out = {}
+    for name in SCENARIOS_A9:
+        run_scenario(fullbatch, compose, name, out)
+        run_scenario(fullbatch, compose, name, out, dtype=torch.double)
+    np.savez_compressed(os.path.join(HERE, "scenarios_a9.npz"), **out)
+    meta = dict(scenarios={k: dict(n=v[0], pixels=v[1], overrides=v[2], model_seed=v[3]) for k, v in SCENARIOS_A9.items()})
+    with open(os.path.join(HERE, "meta_a9.json"), "w") as handle:
+        json.dump(meta, handle, indent=1)
+    print("wrote", os.path.join(HERE, "scenarios_a9.npz"), os.path.join(HERE, "meta_a9.json"))
+
+
 def main():
     torch.set_num_threads(8)
     fullbatch = import_reference()
@@ -285,4 +314,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main_n4() if "--n4" in sys.argv else (main_extra() if "--extra" in sys.argv else main())
+    if "--a9" in sys.argv:
+        main_a9()
+    else:
+        main_n4() if "--n4" in sys.argv else (main_extra() if "--extra" in sys.argv else main())

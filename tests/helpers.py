@@ -24,7 +24,9 @@ def hyp_from_cfg(cfg):
     return dict(lr=o.lr, weight_decay=o.weight_decay, momentum=o.momentum, nesterov=o.nesterov, dampening=o.dampening,
                 block_strength=cfg.hyp.grad_reg.block_strength, eps=cfg.hyp.grad_reg.eps,
                 implementation=cfg.hyp.grad_reg.implementation, grad_clip=cfg.hyp.grad_clip,
-                acc_strength=cfg.hyp.grad_reg.acc_strength, optim_modification=dict(cfg.hyp.optim_modification))
+                acc_strength=cfg.hyp.grad_reg.acc_strength, optim_modification=dict(cfg.hyp.optim_modification),
+                grad_clip_norm=cfg.hyp.grad_clip_norm, norm_bias=dict(cfg.hyp.norm_bias), evaluate_ema=cfg.hyp.evaluate_ema,
+                eval_ema_momentum=cfg.hyp.eval_ema_momentum)
 
 
 def rel_err(a, b):

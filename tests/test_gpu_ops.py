@@ -446,3 +446,25 @@ def test_sam_ascent_and_restore(clip):
     lib.call("fb_mt_sam_restore", td.data_ptr(), ed.data_ptr(), n)
     assert torch.equal(td, climbed - ed)                       # the reference's p.sub_(e_w), same rounding
     assert torch.allclose(td.cpu(), theta, rtol=0, atol=1e-6)
+
+
+def test_absmax_norm_bias_and_ema_kernels():
+    """fb_mt_absmax2 (L-inf clip norm, training.py:199-200), fb_mt_norm_bias (training.py:188-196), fb_mt_ema (training/utils.py:22-29)."""
+    lib = _lib()
+    torch.manual_seed(9)
+    n = 300_001
+    g, theta, ema = torch.randn(n) * 0.01, torch.randn(n), torch.randn(n)
+    g[123_457] = -0.75
+    gd, td, ed = g.cuda(), theta.cuda(), ema.cuda()
+    out, ws = torch.zeros(2, device="cuda"), torch.zeros(lib.load().fb_ws_mt_floats(1), device="cuda")
+    lib.call("fb_mt_absmax2", gd.data_ptr(), n, out.data_ptr(), ws.data_ptr())
+    assert float(out[0]) == 0.75 * 0.75
+    pn2 = torch.tensor([float(theta.pow(2).sum())], device="cuda")
+    for norm_type, bias in ((1, 10.0), (1, 1e4), (2, 70.0)):
+        gd = g.cuda()
+        lib.call("fb_mt_norm_bias", gd.data_ptr(), td.data_ptr(), n, pn2.data_ptr(), 0.01, bias, norm_type)
+        diff = pn2.cpu()[0] - bias ** 2
+        ref = g + (0.01 * diff.sign() if norm_type == 1 else (0.01 * (2 * diff)) * theta)
+        assert torch.allclose(gd.cpu(), ref, rtol=1e-6, atol=1e-7)
+    lib.call("fb_mt_ema", ed.data_ptr(), td.data_ptr(), n, 0.99, float(1 - 0.99))
+    assert torch.equal(ed.cpu(), 0.99 * ema + (1 - 0.99) * theta)            # the reference expression, bit for bit

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 STAT_KEYS = ("train_loss", "train_acc", "param_norm", "grad_norm", "full_loss", "preclip_gradnorm", "clipped_step")
 
 
-def _run(meta, name, extra=(), tmp_path=None):
+def _run(meta, name, extra=(), tmp_path=None, valid_full=False):
     from fullbatchtraining_amd.cfg import compose
     from fullbatchtraining_amd.models import construct_model
     from fullbatchtraining_amd.training import train
@@ -29,7 +29,7 @@ def _run(meta, name, extra=(), tmp_path=None):
     model = construct_model(cfg.model, 3, 10)
     x, y = make_data(sc["n"], sc["pixels"])
     setup = dict(device=torch.device("cuda:0"), dtype=torch.float, memory_format=torch.contiguous_format)
-    stats = train(model, (x, y), (x[:64], y[:64]), setup, cfg)
+    stats = train(model, (x, y), (x, y) if valid_full else (x[:64], y[:64]), setup, cfg)
     return cfg, model, stats
 
 
@@ -37,7 +37,11 @@ def _run(meta, name, extra=(), tmp_path=None):
                                             ("fb_gradreg_c32", 8e-3, 4), ("fb_central", 3e-3, 2), ("fb_legacy", 8e-3, 1),
                                             ("fb_acc", 8e-3, 3), ("fb_acc_central", 3e-3, 2),        # acc_strength pre-pass
                                             # optimizer wrappers around the closure: SAM records two closures per step
-                                            ("fb_sam", 1e-3, 3), ("fb_sam_gradreg", 8e-3, 2), ("fb_lars", 2e-4, 1), ("fb_larc", 2e-4, 2)])
+                                            ("fb_sam", 1e-3, 3), ("fb_sam_gradreg", 8e-3, 2), ("fb_lars", 2e-4, 1), ("fb_larc", 2e-4, 2),
+                                            # off-by-default options of the gradient modification: L-inf clip, norm bias
+                                            # (the L-inf norm is ONE gradient element: its fp32 noise, ~1e-3, scales the whole update -- the CPU oracle in fp32
+                                            # lands 3.6e-3 from the reference's float64 loss at step 3 as well)
+                                            ("fb_clip_inf", 1e-2, 2), ("fb_normbias1", 1e-3, 1), ("fb_normbias2", 1e-3, 2)])
 def test_train_matches_reference_run_f32(golden, name, tol, group, tmp_path):
     data, meta = golden
     cfg, model, stats = _run(meta, name, [f"impl.engine.chunk_group={group}"], tmp_path)
@@ -46,10 +50,14 @@ def test_train_matches_reference_run_f32(golden, name, tol, group, tmp_path):
             continue
         r64, r32 = data[f"{name}@f64/stat/{key}"], data[f"{name}/stat/{key}"]
         print(f"{name} {key}: engine {np.array(stats[key])} ref32 {r32} ref64 {r64}")
-        if key == "train_acc" and "gradreg_c32" in name:
-            continue  # the reference's own fp32 and float64 runs disagree on the accuracy here
+        if key == "train_acc" and ("gradreg_c32" in name or "clip_inf" in name):
+            continue  # the reference's own fp32 and float64 runs disagree on the accuracy here / single-sample flips on the noise floor
         # within `tol`, or within 5x the reference's own fp32-vs-float64 spread on this statistic, whichever is larger
         bound = np.maximum(tol * np.abs(r64) + 1e-6, 5 * np.abs(r32 - r64))
+        if key == "preclip_gradnorm" and "clip_inf" in name:
+            # max |g_i| of later steps: which element is the largest is itself decided on the noise floor (reference fp32 vs float64:
+            # 2.5 %, CPU oracle fp32: 7 % at step 3); only the first step is a sharp check of fb_mt_absmax2
+            bound[1:] = 0.1 * np.abs(r64[1:])
         assert np.all(np.abs(np.array(stats[key]) - r64) <= bound), (key, stats[key], r32, r64)
     n_chunks = len([k for k in stats if k.startswith("grad_norm_train_")])
     assert n_chunks == meta["scenarios"][name]["n"] // min(cfg.data.batch_size, cfg.hyp.sub_batch)
@@ -77,6 +85,22 @@ def test_train_matches_reference_run_f32(golden, name, tol, group, tmp_path):
     assert len(stats["valid_loss"]) >= 1 and np.isfinite(stats["valid_loss"][-1])
     # closure contract: p.grad populated with the last full gradient
     assert all(p.grad is not None and p.grad.shape == p.shape for p in model.parameters())
+
+
+def test_train_ema_evaluation_matches_reference(golden, tmp_path):
+    """hyp.evaluate_ema (reference training.py:289-294, training/utils.py:22-29): the validation statistics come from an EMA of
+    parameters and BN buffers, the training statistics from the live model."""
+    data, meta = golden
+    name = "fb_ema"
+    cfg, model, stats = _run(meta, name, ["impl.engine.chunk_group=2"], tmp_path, valid_full=True)
+    for key in ("train_loss", "param_norm", "grad_norm", "full_loss", "valid_loss", "valid_acc"):
+        r64, r32 = data[f"{name}@f64/stat/{key}"], data[f"{name}/stat/{key}"]
+        print(f"{name} {key}: engine {np.array(stats[key])} ref32 {r32} ref64 {r64}")
+        bound = np.maximum(1e-3 * np.abs(r64) + 1e-6, 5 * np.abs(r32 - r64))
+        assert len(stats[key]) == len(r64) and np.all(np.abs(np.array(stats[key]) - r64) <= bound), (key, stats[key], r32, r64)
+    # the live model (not the EMA) is what train() leaves in the container
+    err = rel_err(summarise([v.double() for v in model.state_dict().values()])[1], data[f"{name}@f64/final_sample"])
+    assert err < max(10 * rel_err(data[f"{name}/final_sample"], data[f"{name}@f64/final_sample"]), 1e-5)
 
 
 def test_train_bf16_tracks_fp32_statistics(golden, tmp_path):

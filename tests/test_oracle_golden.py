@@ -110,7 +110,8 @@ def test_reference_fp32_noise_floor_on_record(golden):
 
 TRAIN_CASES = ["fb_plain", "fb_gradreg", "fb_clip_warm", "fb_gradreg_c32", "fb_central", "fb_legacy",
                "fb_acc", "fb_acc_central",      # acc_strength pre-pass (scenarios_extra.npz)
-               "fb_sam", "fb_sam_gradreg", "fb_lars", "fb_larc"]     # optimizer wrappers around the closure (scenarios_n4.npz)
+               "fb_sam", "fb_sam_gradreg", "fb_lars", "fb_larc",     # optimizer wrappers around the closure (scenarios_n4.npz)
+               "fb_clip_inf", "fb_normbias1", "fb_normbias2", "fb_ema"]      # L-inf clip, norm bias, EMA evaluation (scenarios_a9.npz)
 
 
 @pytest.mark.parametrize("name", TRAIN_CASES)
@@ -120,10 +121,11 @@ def test_training_float64_pin(golden, name):
     cfg, model, state, x, y = _setup(meta, name, F64)
     spec = orc.Spec(cfg.model.depth)
     chunk = min(cfg.data.batch_size, cfg.hyp.sub_batch)
-    stats = orc.train(spec, state, x, y, hyp_from_cfg(cfg), cfg.hyp.steps, chunk, cfg.hyp.scheduler, cfg.hyp.warmup)
+    stats = orc.train(spec, state, x, y, hyp_from_cfg(cfg), cfg.hyp.steps, chunk, cfg.hyp.scheduler, cfg.hyp.warmup, Xv=x, Yv=y,
+                      validate_every=1000)       # the generator validates on the training tensors after step 1 and after the last step
     key = f"{name}@f64"
     tol = 1e-7 if "legacy" not in name else 1e-6
-    for stat in ("train_loss", "train_acc", "param_norm", "grad_norm", "full_loss", "preclip_gradnorm", "clipped_step"):
+    for stat in ("train_loss", "train_acc", "param_norm", "grad_norm", "full_loss", "preclip_gradnorm", "clipped_step", "valid_loss", "valid_acc"):
         if f"{key}/stat/{stat}" in data:
             assert np.allclose(stats[stat], data[f"{key}/stat/{stat}"], rtol=tol, atol=1e-12), (stat, stats[stat])
     for k in range(x.shape[0] // chunk):
