@@ -189,8 +189,18 @@ def main():
                                   "avg_launch_us": round(1000 * ms / launches, 2),
                                   "tflops": round(flops[k] * scale / (ms * 1e-3) / 1e12, 1)}
             dom = max(kernels, key=lambda k: kernels[k]["ms_total"])
+            # HBM bytes per launch of the same kernel class from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, one counter per rocprofv3
+            # pass as MI355X_MICROARCH.md prescribes; tools/pmc_bench.sh writes the file, profiles/ keeps the copy behind the number)
+            traffic, traffic_src = None, None
+            try:
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")) as handle:
+                    pmc = json.load(handle)
+                if trainer.dtype == torch.bfloat16 and args.grad_reg == 0 and world == 1 and eng.G == 39:   # the profiled configuration
+                    traffic, traffic_src = pmc["classes"][dom]["bytes_per_launch"], "profiles/hbm_traffic.json: " + pmc["command"]
+            except (OSError, KeyError, ValueError):
+                pass
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": None,
+                               "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                                "flop_per_launch": flops[dom] / max(kernels[dom]["launches"] + kernels[dom]["dropped"], 1),
                                "avg_launch_us": kernels[dom]["avg_launch_us"], "kernels": kernels,
                                "measured": "HIP events inside the timed region (--serialize)" if args.serialize else

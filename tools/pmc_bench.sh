@@ -26,4 +26,32 @@ for k, v in sorted(agg.items(), key=lambda kv: -(2 * sum(kv[1].get("FETCH_SIZE",
     if gb > 0.5: print(f"| \`{k}\` | {n} | {2 * sum(f) / max(len(f), 1) / 1e3:.1f} | {sum(w) / max(len(w), 1) / 1e3:.1f} | {gb:.1f} |")
 print(f"\\ntotal {tot:.1f} GB (FETCH_SIZE doubled per MI355X_MICROARCH.md: 128-byte requests are tallied as 64 B on gfx950; KB units)")
 PY
-cat $out/summary.md | cut -c1-200
+# per-launch HBM bytes of the three MFMA kernel classes bench.py reports (copy to profiles/hbm_traffic.json: bench.py reads it for
+# roofline.traffic).  Forward / input-gradient launches share kernels; one chunk group issues its 20 forward convolutions before
+# its 19 input-gradient ones, so the class follows from the position in dispatch order.
+python3 - <<PY > $out/hbm_traffic.json
+import csv, json, collections
+per = collections.defaultdict(lambda: [0.0, 0.0])          # dispatch id -> [fetch KB, write KB]
+name = {}
+for p, col in (("p1", 0), ("p2", 1)):
+    for r in csv.DictReader(open(f"$out/{p}/{p}_counter_collection.csv")):
+        if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            per[int(r["Dispatch_Id"])][col] += float(r["Counter_Value"])
+            name[int(r["Dispatch_Id"])] = r["Kernel_Name"]
+cls = collections.defaultdict(list)
+k = 0
+for d in sorted(per):
+    n = name[d]
+    b = (2 * per[d][0] + per[d][1]) * 1e3                      # KB -> bytes, FETCH_SIZE doubled (MI355X_MICROARCH.md, gfx950)
+    if n.startswith("void conv_wgrad") :
+        cls["wgrad"].append(b)
+    elif any(t in n for t in ("conv3x3s1_halo4", "conv3x3s1_c64_halo5", "conv_igemm_v3", "conv_igemm_kernel")):
+        cls["igemm_fwd" if k % 39 < 20 else "igemm_dgrad"].append(b)
+        if "halo5_kernel<0" in n: assert k % 39 < 20, (k, n)
+        if "halo5_kernel<1" in n: assert k % 39 >= 20, (k, n)
+        k += 1
+print(json.dumps({"command": "tools/pmc_bench.sh $tag (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per pass, bench.py --steps 1 --warmup 0 --serialize)",
+                  "unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)",
+                  "classes": {c: {"launches": len(v), "bytes_per_launch": sum(v) / len(v)} for c, v in cls.items()}}, indent=1))
+PY
+cat $out/summary.md | cut -c1-200; cat $out/hbm_traffic.json
