@@ -5,27 +5,29 @@
 // finite-difference regulariser relies on (both passes see identically ordered sums).
 #include "common.h"
 
-// Two-stage fixed-order sum of the per-pixel-block partials of one (group, channel): 256 threads = 16 channels x 16 segments;
-// segment s adds blocks s, s+16, ... in double, then the 16 segment sums are added in order.  Valid on threads with seg == 0.
+// Two-stage fixed-order sum of the per-pixel-block partials of one (group, channel): blockDim.x threads = 16 channels x SEGS segments
+// (SEGS = blockDim.x / 16: 16 or 64); segment s adds blocks s, s+SEGS, ... in double, then the SEGS segment sums are added in order.
+// Valid on threads with seg == 0.  64 segments for long columns: with 16 a thread walked 64+ dependent loads (13-37 us per launch).
 __device__ __forceinline__ bool partial_sum2(const float* __restrict__ part, int n_mblocks, int blocks_per_group, int C, int g,
                                              int& c, double& s, double& q) {
-    __shared__ double red[2][16][16];
+    __shared__ double red[2][64][16];
+    const int segs = (int)blockDim.x >> 4;
     const int cl = threadIdx.x & 15, seg = threadIdx.x >> 4;
     c = blockIdx.x * 16 + cl;
     double a = 0.0, b = 0.0;
     if (c < C) {
         const float* ps = part + ((long long)g * blocks_per_group) * C + c;
         const float* pq = part + ((long long)n_mblocks + (long long)g * blocks_per_group) * C + c;
-        for (int k = seg; k < blocks_per_group; k += 16) { a += (double)ps[(long long)k * C]; b += (double)pq[(long long)k * C]; }
+        for (int k = seg; k < blocks_per_group; k += segs) { a += (double)ps[(long long)k * C]; b += (double)pq[(long long)k * C]; }
     }
     red[0][seg][cl] = a; red[1][seg][cl] = b;
     __syncthreads();
     if (seg != 0 || c >= C) return false;
     s = 0.0; q = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { s += red[0][k][cl]; q += red[1][k][cl]; }
+    for (int k = 0; k < segs; ++k) { s += red[0][k][cl]; q += red[1][k][cl]; }
     return true;
 }
+static inline int bn_finalize_threads(int blocks_per_group) { return blocks_per_group >= 256 ? 1024 : 256; }
 
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void bn_fwd_finalize_kernel(const float* __restrict__ part, int n_mblocks, int blocks_per_group, int C, double inv_count,
@@ -55,7 +57,7 @@ extern "C" int fb_bn_fwd_finalize(const float* stat_partial, int32_t n_mblocks, 
     if (!stat_partial || !gamma || !beta || !mean_tab || !var_tab || !scale || !shift || !invstd) FB_FAIL(FB_ERR_ARG, "fb_bn_fwd_finalize: null pointer");
     if (n_mblocks % n_groups != 0) FB_FAIL(FB_ERR_SHAPE, "fb_bn_fwd_finalize: %d pixel blocks not divisible by %d groups", n_mblocks, n_groups);
     dim3 grid((C + 15) / 16, n_groups);
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, grid, dim3(256), 0, (hipStream_t)stream, stat_partial, n_mblocks, n_mblocks / n_groups, C,
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, grid, dim3(bn_finalize_threads(n_mblocks / n_groups)), 0, (hipStream_t)stream, stat_partial, n_mblocks, n_mblocks / n_groups, C,
                        1.0 / count, gamma, beta, (long long)param_group_stride, eps, mean_tab, var_tab, ch_total, ch_off, scale, shift, invstd);
     FB_CHECK_LAUNCH("fb_bn_fwd_finalize");
     return FB_OK;
@@ -361,7 +363,7 @@ extern "C" int fb_bn_bwd_finalize(const float* partial, int32_t n_mblocks, int32
     if (!partial || !scale || !mean_tab || !invstd || !dgamma || !dbeta || !coef) FB_FAIL(FB_ERR_ARG, "fb_bn_bwd_finalize: null pointer");
     if (n_mblocks % n_groups != 0) FB_FAIL(FB_ERR_SHAPE, "fb_bn_bwd_finalize: blocks/groups");
     dim3 grid((C + 15) / 16, n_groups);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, grid, dim3(256), 0, (hipStream_t)stream, partial, n_mblocks, n_mblocks / n_groups, C, 1.0 / count,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, grid, dim3(bn_finalize_threads(n_mblocks / n_groups)), 0, (hipStream_t)stream, partial, n_mblocks, n_mblocks / n_groups, C, 1.0 / count,
                        scale, mean_tab, invstd, ch_total, ch_off, dgamma, dbeta, (long long)grad_group_stride, coef);
     FB_CHECK_LAUNCH("fb_bn_bwd_finalize");
     return FB_OK;

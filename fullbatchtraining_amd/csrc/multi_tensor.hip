@@ -10,12 +10,20 @@ static inline int mt_blocks(int64_t n) {
 }
 
 // second stage: out[g*NV + v] = sum_b ws[(g*NV+v)*FB_MT_BLOCKS + b] in double, fixed order
-__global__ void mt_finalize_kernel(const float* __restrict__ ws, float* __restrict__ out, int nblocks, int count) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
+// (one 256-thread workgroup per output: thread t adds partials t, t+256, ..., then a fixed binary tree -- one thread walking all
+// FB_MT_BLOCKS partials took 90 us per launch)
+__global__ __launch_bounds__(256) void mt_finalize_kernel(const float* __restrict__ ws, float* __restrict__ out, int nblocks, int count) {
+    __shared__ double sm[256];
+    const int i = blockIdx.x;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += (double)ws[(long long)i * FB_MT_BLOCKS + b];
-    out[i] = (float)s;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += (double)ws[(long long)i * FB_MT_BLOCKS + b];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) sm[threadIdx.x] += sm[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[i] = (float)sm[0];
 }
 
 // ---- |scale*x[g] + add_scale*add|^2 ---------------------------------------------------------------------------------------
@@ -45,7 +53,7 @@ extern "C" int fb_mt_sqnorm(const float* x, int64_t group_stride, int32_t n_grou
     const int nb = mt_blocks(n);
     hipLaunchKernelGGL(mt_sqnorm_kernel, dim3(nb, n_groups), dim3(256), 0, (hipStream_t)stream, x, (long long)group_stride, (long long)n, scale, add,
                        add_scale, ws);
-    hipLaunchKernelGGL(mt_finalize_kernel, dim3((n_groups + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, out, nb, n_groups);
+    hipLaunchKernelGGL(mt_finalize_kernel, dim3(n_groups), dim3(256), 0, (hipStream_t)stream, ws, out, nb, n_groups);
     FB_CHECK_LAUNCH("fb_mt_sqnorm");
     return FB_OK;
 }
@@ -110,7 +118,7 @@ extern "C" int fb_mt_accumulate(float* avg, const float* g, int64_t group_stride
             hipLaunchKernelGGL((mt_accumulate_kernel<false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, avg, gj, (long long)group_stride, ng,
                                (long long)n, counter0 + j0, ws);
     }
-    if (sq_out) hipLaunchKernelGGL(mt_finalize_kernel, dim3((n_groups + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, sq_out, nb, n_groups);
+    if (sq_out) hipLaunchKernelGGL(mt_finalize_kernel, dim3(n_groups), dim3(256), 0, (hipStream_t)stream, ws, sq_out, nb, n_groups);
     FB_CHECK_LAUNCH("fb_mt_accumulate");
     return FB_OK;
 }
@@ -190,7 +198,7 @@ extern "C" int fb_mt_norms2(const float* a, const float* b, int64_t n, float* ou
     const int64_t want = (n + 255) / 256;
     const int nb = (int)(want < 1 ? 1 : (want > FB_MT_BLOCKS ? FB_MT_BLOCKS : want));
     hipLaunchKernelGGL(mt_norms2_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, b, (long long)n, ws);
-    hipLaunchKernelGGL(mt_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ws, out, nb, 2);
+    hipLaunchKernelGGL(mt_finalize_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, ws, out, nb, 2);
     FB_CHECK_LAUNCH("fb_mt_norms2");
     return FB_OK;
 }
