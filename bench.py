@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--grad-reg", type=float, default=0.0, help="block_strength of the finite-difference regulariser (config 3)")
-    ap.add_argument("--chunk-group", type=int, default=39)
+    ap.add_argument("--chunk-group", type=int, default=98)
     ap.add_argument("--images", type=int, default=N_IMAGES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -195,7 +195,7 @@ def main():
             try:
                 with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")) as handle:
                     pmc = json.load(handle)
-                if trainer.dtype == torch.bfloat16 and args.grad_reg == 0 and world == 1 and eng.G == 39:   # the profiled configuration
+                if trainer.dtype == torch.bfloat16 and args.grad_reg == 0 and world == 1 and eng.G == 98:   # the profiled configuration
                     traffic, traffic_src = pmc["classes"][dom]["bytes_per_launch"], "profiles/hbm_traffic.json: " + pmc["command"]
             except (OSError, KeyError, ValueError):
                 pass

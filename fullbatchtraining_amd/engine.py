@@ -58,6 +58,14 @@ class Block:
         self.convs, self.shortcut, self.stride, self.cin, self.hin, self.win = convs, shortcut, stride, cin, hin, win
 
 
+def max_group(plan, chunk, dtype):
+    """Largest chunk group whose biggest activation tensor (NHWC, compute dtype) stays below 2^31 bytes: the LDS-DMA kernels address
+    their operands with 32-bit buffer offsets and hand larger tensors to the slower pointer-based kernels."""
+    per_image = max(max(L.hout * L.wout * L.cout, L.hin * L.win * L.cin_pad) for L in plan.layers)
+    per_image = max(per_image, plan.stem.hout * plan.stem.wout * plan.stem.cin_pad)
+    return max(1, ((1 << 31) - 1) // (chunk * per_image * torch.empty((), dtype=dtype).element_size()))
+
+
 class Plan:
     """Static layer plan + arena offsets derived from the parameter container (``fullbatchtraining_amd.models.ResNet``)."""
 

@@ -19,16 +19,20 @@ import torch
 import torch.distributed as dist
 
 
-def group_size(n_chunks, chunk_group):
-    """Chunks per batched launch for a rank that owns ``n_chunks``: equal-sized groups (no ragged last launch), as many as
-    brings the size closest to ``chunk_group`` -- 390 chunks run as 10 x 39, a rank's 49 chunks (8 GPUs) as one group of 49
-    rather than 39 + 10.  The size stays below 1.5 x chunk_group (f32 activations of 58 chunks are still < 2^31 bytes, the
-    range of the kernels' buffer descriptors)."""
+def group_size(n_chunks, chunk_group, cap=None):
+    """Chunks per batched launch for a rank that owns ``n_chunks``: equal-sized groups (at most one chunk of difference), as many as
+    brings the size closest to ``chunk_group`` -- 390 chunks run as 4 x 98, a rank's 49 chunks (8 GPUs) as one group of 49.  The size
+    stays below 1.5 x chunk_group and never exceeds ``cap`` (the largest group whose activation tensors stay below 2^31 bytes, the
+    range of the 32-bit buffer offsets of the fast kernels: ``engine.max_group``)."""
     if n_chunks <= 0:
-        return max(1, chunk_group)
+        return max(1, min(chunk_group, cap or chunk_group))
     g = max(1, min(chunk_group, n_chunks))
     n_groups = max(1, int(n_chunks / g + 0.5))
-    return -(-n_chunks // n_groups)
+    g = -(-n_chunks // n_groups)
+    if cap is not None and g > cap:
+        n_groups = -(-n_chunks // max(1, cap))
+        g = -(-n_chunks // n_groups)
+    return g
 
 
 class ShardPlan:

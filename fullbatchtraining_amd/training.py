@@ -299,7 +299,9 @@ class FullBatchTrainer:
             log.warning("grad_reg finite differences need matching fp32 passes (perturbation ~1e-6 per weight): running fp32.")
         from .parallel import ShardPlan, group_size
         self.shard = ShardPlan(self.n_chunks, self.world, self.rank)
-        G = group_size(self.shard.count, int(cfg.impl.get("engine", {}).get("chunk_group", 39)))
+        from .engine import Plan, max_group
+        G = group_size(self.shard.count, int(cfg.impl.get("engine", {}).get("chunk_group", 98)),
+                       cap=max_group(Plan(model, X.shape[-1]), self.chunk, self.dtype))
         self.engine = Engine(model, X.shape[-1], self.chunk, G, compute_dtype=self.dtype, device=self.device, fd_sets=fd_sets)
         stem = self.engine.plan.stem
         lo, hi = self.shard.first * self.chunk, (self.shard.first + self.shard.count) * self.chunk

@@ -119,6 +119,16 @@ def test_out_of_scope_options_raise():
         optim_interface(torch.nn.Linear(2, 2), cfg.hyp)
 
 
+def test_group_cap_keeps_activations_in_32bit_range():
+    from fullbatchtraining_amd.cfg import compose
+    from fullbatchtraining_amd.engine import Plan, max_group
+    from fullbatchtraining_amd.models import construct_model
+
+    plan = Plan(construct_model(compose([]).model, 3, 10), 32)
+    assert max_group(plan, 128, torch.float32) == 63 and max_group(plan, 128, torch.bfloat16) == 127
+    assert max_group(plan, 32, torch.float32) == 255
+
+
 def test_optimizer_wrappers_have_the_reference_surface():
     """optim_modification = SAM / LARS / LARC (reference optimizers.py:57-67): wrapper objects with ``.optim``, shared param_groups,
     attribute pass-through to the wrapped SGD, scheduler bound to the wrapped optimizer, state_dict of the wrapped optimizer."""
@@ -158,6 +168,8 @@ def test_shard_plan_partitions_chunks():
     assert [ShardPlan(390, 8, r).count for r in range(8)] == [49] * 6 + [48] * 2
     from fullbatchtraining_amd.parallel import group_size
     assert [group_size(c, 39) for c in (390, 195, 98, 97, 49, 48, 7, 1, 58, 59)] == [39, 39, 33, 49, 49, 48, 7, 1, 58, 30]
+    assert [group_size(c, 98) for c in (390, 195, 98, 97, 49)] == [98, 98, 98, 97, 49]
+    assert [group_size(c, 98, cap=63) for c in (390, 195, 98, 49, 0)] == [56, 49, 49, 49, 63]      # f32: 63 chunks of 128 x 64 x 32 x 32
     for c in range(1, 400):                      # equal groups, never more than 1.5 x the configured size
         g = group_size(c, 39)
         assert 1 <= g < 59 and -(-c // g) * g - c < -(-c // g)
