@@ -132,6 +132,44 @@ def test_bottleneck_standard_stem_chunk_gradients_vs_oracle():
         assert rel_err(got[g][-2].numpy(), truth[g][0][-2].numpy()) < 1e-4
 
 
+def test_resnet152_at_224_directional_derivative():
+    """BASELINE config 5 at its real shape (ResNet-152, 'standard' stem, 224x224 inputs, one chunk of 128 images, exact-f32 path as the
+    regulariser uses it): too large for the CPU oracle inside a test, so a size-independent property ties the backward kernels to the
+    forward ones -- the change of the chunk loss between theta + c g and theta - c g equals <g, theta+ - theta-> (the ACTUAL fp32
+    difference of the two parameter vectors: |g| is ~1500 at initialisation, so a step that moves the loss by 1e-3 changes most
+    weights by less than their fp32 spacing and the rounded step has to be accounted for).  Measured 1.0003; 0.989 / 1.025 at a
+    4x larger / smaller step (curvature / fp32 resolution of the loss)."""
+    pixels, chunk, G = 224, 128, 1
+    cfg, model, eng, stem_patches = _build(152, pixels, chunk, G, torch.float32, stem="standard")
+    x, y = make_data(chunk, pixels)
+    patches = stem_patches(x.cuda(), eng.plan.stem, torch.float32)
+    yd = y.cuda()
+
+    def loss_and_grad():
+        eng.prep_weights(eng.theta, 1)
+        eng.group_gradient(patches, yd, G, eng.g)
+        torch.cuda.synchronize()
+        return float(eng.loss[0]), eng.g[0].clone()
+
+    loss0, g = loss_and_grad()
+    gn = float(g.double().norm())
+    assert np.isfinite(loss0) and np.isfinite(gn) and gn > 0
+    theta0 = eng.theta.clone()
+    c = 5e-4 * max(1.0, abs(loss0)) / gn ** 2
+    tp, tm = theta0 + c * g, theta0 - c * g
+    predicted = float((g.double() * (tp.double() - tm.double())).sum())
+    eng.theta.copy_(tp)
+    lp, _ = loss_and_grad()
+    eng.theta.copy_(tm)
+    lm, _ = loss_and_grad()
+    eng.theta.copy_(theta0)
+    print(f"resnet152@224: loss {loss0:.5f}, |g| {gn:.2f}, (L+ - L-) / <g, theta+ - theta-> = {(lp - lm) / predicted:.4f}")
+    assert abs((lp - lm) / predicted - 1.0) < 2e-2, (lp, lm, predicted)
+    # determinism at this size: a second evaluation reproduces loss and gradient bit for bit
+    loss1, g1 = loss_and_grad()
+    assert loss1 == loss0 and torch.equal(g1, g)
+
+
 def test_imagenet_shaped_maps_chunk_gradient_vs_oracle():
     """ResNet-18 with the 'standard' (ImageNet) stem on 96x96 inputs: feature maps 48 -> (MaxPool) 24, 12, 6, 3 -- non-power-of-two
     sizes like the 56/28/14/7 of the 224x224 configurations (every stride-2 transition halves an even size, as there; the
