@@ -72,6 +72,10 @@ def main():
     ap.add_argument("--grad-reg", type=float, default=0.0, help="block_strength of the finite-difference regulariser (config 3)")
     ap.add_argument("--chunk-group", type=int, default=98)
     ap.add_argument("--images", type=int, default=N_IMAGES)
+    ap.add_argument("--model", default="resnet18", help="other workloads than the headline one (e.g. BASELINE config 5: --model resnet152 "
+                                                        "--stem standard --pixels 224 --images 1024 --grad-reg 0.5): not the benchmark line")
+    ap.add_argument("--stem", default="CIFAR", choices=["CIFAR", "standard"])
+    ap.add_argument("--pixels", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--serialize", action="store_true",
@@ -113,12 +117,15 @@ def main():
         overrides += ["hyp=gradreg", "hyp.warmup=0", f"hyp.steps={n_sched}", f"hyp.grad_reg.block_strength={args.grad_reg}"]
     if world > 1:
         overrides += ["impl/setup=distributed"]
+    headline = (args.model, args.stem, args.pixels) == ("resnet18", "CIFAR", 32)
+    if not headline:
+        overrides += [f"model={args.model}", f"model.stem={args.stem}", f"data.pixels={args.pixels}"]
     cfg = compose(overrides, original_cwd=os.path.join(ROOT, "gpurun_out"), name="bench")
     os.makedirs(cfg.original_cwd, exist_ok=True)
 
     # synthetic CIFAR-shaped data, generated identically on every rank
     gen = torch.Generator().manual_seed(1234)
-    X = torch.randn(args.images, 3, 32, 32, generator=gen)
+    X = torch.randn(args.images, 3, args.pixels, args.pixels, generator=gen)
     Y = torch.randint(0, 10, (args.images,), generator=gen)
     torch.manual_seed(1)
     model = construct_model(cfg.model, 3, 10)
@@ -167,12 +174,13 @@ def main():
         steps_per_sec = args.steps / elapsed
         passes = 1 if args.grad_reg == 0 else 2
         out = {
-            "metric": "full-batch GD images/sec (ResNet-18 CIFAR-10 shaped, all chunks accumulated per step)",
+            "metric": "full-batch GD images/sec (ResNet-18 CIFAR-10 shaped, all chunks accumulated per step)" if headline else
+                      f"full-batch GD images/sec ({args.model}, {args.stem} stem, {args.pixels}x{args.pixels} synthetic inputs; NOT the headline workload)",
             "value": round(images_per_step * steps_per_sec, 1), "unit": "images/s",
             "steps_per_sec": round(steps_per_sec, 4), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "bf16" if trainer.dtype == torch.bfloat16 else "f32", "data": "synthetic",
-            "config": {"workload": f"ResNet-18 CIFAR-10 full-batch GD step, {trainer.n_chunks} chunks x {trainer.chunk} = {images_per_step} "
+            "config": {"workload": f"{'ResNet-18 CIFAR-10' if headline else args.model + ' ' + str(args.pixels) + 'px'} full-batch GD step, {trainer.n_chunks} chunks x {trainer.chunk} = {images_per_step} "
                                    f"images/step (drop_last), grad_reg block_strength={args.grad_reg}, fp32 master/accumulate",
                        "chunk_group": eng.G, "parallelism": f"dp{world} (contiguous chunk ranges, reduce-scatter + all-gather)"},
             "train_loss_last": trainer.stats["train_loss"][-1],
@@ -195,7 +203,7 @@ def main():
             try:
                 with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")) as handle:
                     pmc = json.load(handle)
-                if trainer.dtype == torch.bfloat16 and args.grad_reg == 0 and world == 1 and eng.G == 98:   # the profiled configuration
+                if trainer.dtype == torch.bfloat16 and args.grad_reg == 0 and world == 1 and eng.G == 98 and headline:   # the profiled configuration
                     traffic, traffic_src = pmc["classes"][dom]["bytes_per_launch"], "profiles/hbm_traffic.json: " + pmc["command"]
             except (OSError, KeyError, ValueError):
                 pass
@@ -206,7 +214,7 @@ def main():
                                "measured": "HIP events inside the timed region (--serialize)" if args.serialize else
                                            "HIP events over one extra step after the timed region, weight-gradient stream folded into the "
                                            "main stream (inside the timed region wgrad overlaps dgrad/BN backward)",
-                               "step_mfma_frac": round(3328997376 * passes * images_per_step * steps_per_sec / world / (peak * 1e12), 4)}
+                               "step_mfma_frac": round((3328997376 if headline else sum(conv_flops(eng.plan, 1).values())) * passes * images_per_step * steps_per_sec / world / (peak * 1e12), 4)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
