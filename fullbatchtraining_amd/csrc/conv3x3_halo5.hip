@@ -17,6 +17,7 @@
 
 struct Halo5Params {
     const char* src; const char* wgt; char* dst; const char* addend; float* stat;
+    const unsigned char* addend_mask;                        // ADD == 2: ReLU bitmask of the addend (1 byte per 8 channels)
     int n_img, mode, addend_mode, n_mblocks, n_tiles;
 #ifdef FB_H5_TRACE
     long long* trace;                                       // tools/h5_trace.hip: 8 timestamps per tile
@@ -55,9 +56,10 @@ constexpr int H5_HALO_BYTES = H5_NGRP * 1024, H5_WT_BYTES = 64 * 128, H5_WGT_BYT
 constexpr int H5_KH = (H5_NGRP + 3) / 4;                                               // halo pieces per wave (11; wave 3: 10)
 }  // namespace
 
-// MODE 0: forward (BN partial sums), MODE 1: input gradient (flipped taps; ADD: + addend of the same shape).  Compile-time so that
+// MODE 0: forward (BN partial sums), MODE 1: input gradient (flipped taps; ADD 1: + addend of the same shape, ADD 2: + addend where
+// its ReLU bitmask is set -- the masked gradient of the residual branch without a materialised copy).  Compile-time so that
 // the epilogue slices are straight-line code the scheduler can thread through the MFMA batches.
-template <int MODE, bool ADD>
+template <int MODE, int ADD>
 __global__ __launch_bounds__(256) void conv3x3s1_c64_halo5_kernel(const Halo5Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int W = H5_W, PITCH = H5_PITCH;
@@ -141,12 +143,17 @@ __global__ __launch_bounds__(256) void conv3x3s1_c64_halo5_kernel(const Halo5Par
     // addend (input gradient of the residual branch): loaded three pixel fragments (six batches) ahead of its use -- a load issued
     // where it is consumed would stall the whole in-order stream for an HBM round trip
     h5_u32x2 ad[4][2];
+    unsigned adm[4];                                        // ADD == 2: the four mask bytes of this lane's pixel and channel half
     auto ad_issue = [&](auto jc, const int Lp) {
         constexpr int J = decltype(jc)::value;
-        if constexpr (ADD && J < 8) {
+        if constexpr (ADD != 0 && J < 8) {
             const __amdgpu_buffer_rsrc_t rsrcE = __builtin_amdgcn_make_buffer_rsrc((void*)(p.addend + (long long)Lp * 256 * 128), 0, 256 * 128, 0x00020000);
 #pragma unroll
             for (int i = 0; i < 2; ++i) ad[J & 3][i] = __builtin_amdgcn_raw_buffer_load_b64(rsrcE, voffD + i * 32, J * 2048, 0);
+            if constexpr (ADD == 2) {
+                const __amdgpu_buffer_rsrc_t rsrcM = __builtin_amdgcn_make_buffer_rsrc((void*)(p.addend_mask + (long long)Lp * 256 * 8), 0, 256 * 8, 0x00020000);
+                adm[J & 3] = __builtin_amdgcn_raw_buffer_load_b32(rsrcM, ((ph * 128 + t) * 8 + ch * 4), J * 128, 0);
+            }
         }
     };
     auto epi_prefetch = [&](const int Lp) { h5_static_for<0, 3>([&](auto jc) { ad_issue(jc, Lp); }); };
@@ -169,8 +176,17 @@ __global__ __launch_bounds__(256) void conv3x3s1_c64_halo5_kernel(const Halo5Par
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     float v[4] = {accp[i][J][0], accp[i][J][1], accp[i][J][2], accp[i][J][3]};
-                    if constexpr (ADD) {
-                        const h5_u32x2 a = ad[J & 3][i];
+                    if constexpr (ADD != 0) {
+                        h5_u32x2 a = ad[J & 3][i];
+                        if constexpr (ADD == 2) {
+                            // mask byte k = 2i + (g >> 1) of the loaded word covers channels 8k..8k+7 of this wave's 32; this lane's
+                            // four channels are its low (g even) or high (g odd) nibble.  v_bfe_i32 turns a bit into an all-ones mask.
+                            const unsigned bits = adm[J & 3] >> ((2 * i + (g >> 1)) * 8 + (g & 1) * 4);
+                            const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 0, 1), m1 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 1, 1);
+                            const unsigned m2 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 2, 1), m3 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 3, 1);
+                            a[0] &= (m0 & 0x0000ffffu) | (m1 & 0xffff0000u);
+                            a[1] &= (m2 & 0x0000ffffu) | (m3 & 0xffff0000u);
+                        }
                         v[0] += __uint_as_float(a[0] << 16); v[1] += __uint_as_float(a[0] & 0xffff0000u);
                         v[2] += __uint_as_float(a[1] << 16); v[3] += __uint_as_float(a[1] & 0xffff0000u);
                     }
@@ -291,13 +307,20 @@ __global__ __launch_bounds__(256) void conv3x3s1_c64_halo5_kernel(const Halo5Par
 }
 
 // returns 1 if the kernel handled the call: bf16, 64 -> 64 channels, 32x32 maps, one weight set, no pooled addend
-int fb_try_conv3x3_halo5(const fb_conv_args* a, hipStream_t st) {
+int fb_conv3x3_halo5_takes(const fb_conv_args* a) {
     static const bool disabled = getenv("FB_DISABLE_HALO5") != nullptr;
     if (disabled || a->dtype != FB_BF16) return 0;
     if (a->R != 3 || a->S != 3 || a->stride != 1 || a->pad != 1) return 0;
     if (a->Hs != 32 || a->Ws != 32 || a->Hd != 32 || a->Wd != 32 || a->Cs != 64 || a->Cd != 64) return 0;
     if (a->imgs_per_wset > 0 && a->imgs_per_wset < a->n_img) return 0;          // per-chunk weight sets: the filter would not stay resident
     if (a->addend && a->addend_mode != 1) return 0;
+    if (a->addend_mask && (!a->addend || a->mode != 1)) return 0;
+    if (a->mode == 0 && !a->stat_partial) return 0;                            // (the forward variant always writes statistics)
+    return 1;
+}
+
+int fb_try_conv3x3_halo5(const fb_conv_args* a, hipStream_t st) {
+    if (!fb_conv3x3_halo5_takes(a)) return 0;
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -307,6 +330,7 @@ int fb_try_conv3x3_halo5(const fb_conv_args* a, hipStream_t st) {
     Halo5Params p;
     p.src = (const char*)a->src; p.wgt = (const char*)a->wgt; p.dst = (char*)a->dst; p.addend = (const char*)a->addend;
     p.stat = a->mode == 0 ? a->stat_partial : nullptr;
+    p.addend_mask = (const unsigned char*)a->addend_mask;
     p.n_img = a->n_img; p.mode = a->mode; p.addend_mode = a->addend ? 1 : 0;
     p.n_tiles = a->n_img * 4;
     p.n_mblocks = p.n_tiles * 2;
@@ -316,12 +340,13 @@ int fb_try_conv3x3_halo5(const fb_conv_args* a, hipStream_t st) {
 #endif
     const dim3 grid(p.n_tiles < n_cu ? p.n_tiles : n_cu);
     if (a->mode == 0) {
-        if (!a->stat_partial) return 0;                                        // (the forward variant always writes statistics)
-        hipLaunchKernelGGL((conv3x3s1_c64_halo5_kernel<0, false>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((conv3x3s1_c64_halo5_kernel<0, 0>), grid, dim3(256), 0, st, p);
+    } else if (a->addend && a->addend_mask) {
+        hipLaunchKernelGGL((conv3x3s1_c64_halo5_kernel<1, 2>), grid, dim3(256), 0, st, p);
     } else if (a->addend) {
-        hipLaunchKernelGGL((conv3x3s1_c64_halo5_kernel<1, true>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((conv3x3s1_c64_halo5_kernel<1, 1>), grid, dim3(256), 0, st, p);
     } else {
-        hipLaunchKernelGGL((conv3x3s1_c64_halo5_kernel<1, false>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((conv3x3s1_c64_halo5_kernel<1, 0>), grid, dim3(256), 0, st, p);
     }
     return 1;
 }

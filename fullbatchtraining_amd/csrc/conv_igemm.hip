@@ -194,6 +194,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
 int fb_try_conv3x3_halo4(const fb_conv_args* a, hipStream_t st);   // conv3x3_halo4.hip
 int fb_try_conv3x3_halo5(const fb_conv_args* a, hipStream_t st);   // conv3x3_halo5.hip
+int fb_conv3x3_halo5_takes(const fb_conv_args* a);
+
+// 1 if fb_conv2d accepts `addend_mask` for these arguments (only the resident-filter 64-channel kernel applies the mask so far)
+extern "C" int32_t fb_conv_masked_addend_supported(const fb_conv_args* a) {
+    if (!a || !a->addend || !a->addend_mask || a->addend_mode != 1) return 0;
+    return fb_conv3x3_halo5_takes(a);
+}
 
 template <typename T> static int launch_conv(const ConvParams& p, int classes, hipStream_t st) {
     const int mblocks = (p.M + 127) / 128;
@@ -213,6 +220,8 @@ extern "C" int fb_conv2d(const fb_conv_args* a, void* stream) {
     if (a->Cs % 32 != 0) FB_FAIL(FB_ERR_SHAPE, "fb_conv2d: Cs=%d must be a multiple of 32", a->Cs);
     if (a->Cd % 64 != 0) FB_FAIL(FB_ERR_SHAPE, "fb_conv2d: Cd=%d must be a multiple of 64", a->Cd);
     if (a->mode != 0 && a->mode != 1) FB_FAIL(FB_ERR_ARG, "fb_conv2d: mode %d", a->mode);
+    if (a->addend_mask && !fb_conv_masked_addend_supported(a))
+        FB_FAIL(FB_ERR_UNSUPPORTED, "fb_conv2d: addend_mask is not implemented for this shape (ask fb_conv_masked_addend_supported)");
     if (a->stride != 1 && a->stride != 2) FB_FAIL(FB_ERR_UNSUPPORTED, "fb_conv2d: stride %d", a->stride);
     ConvParams p;
     p.src = (const char*)a->src; p.wgt = (const char*)a->wgt; p.dst = (char*)a->dst; p.addend = (const char*)a->addend;

@@ -508,16 +508,29 @@ class Engine:
             launch()
             self._wgrad_event = self.wstream.record_event()
 
-    def _dgrad(self, L, dx, G, wsets, addend=None, addend_mode=0):
+    def _dgrad_args(self, L, src, wptr, dst, addend, G, wsets, addend_mode, addend_mask=None):
+        n = G * self.chunk
+        return lib.ConvArgs(src, wptr, dst, addend, None, n, L.hout, L.wout, L.cout, L.hin, L.win, L.cin_pad,
+                            L.R, L.S, L.stride, L.pad, 1, self.chunk if wsets > 1 else n, self.plan.wc_total if wsets > 1 else 0,
+                            addend_mode, self.dtc, addend_mask)
+
+    def _dgrad(self, L, dx, G, wsets, addend=None, addend_mode=0, addend_mask=None):
         n = G * self.chunk
         out = self.pool.get((n, L.hin, L.win, L.cin_pad))
         wd = self.w_dgrad[1 if wsets > 1 else 0]
         wptr = wd.data_ptr() + wd.element_size() * L.wc_off
-        a = lib.ConvArgs(dx.data_ptr(), wptr, out.data_ptr(), _ptr(addend), None, n, L.hout, L.wout, L.cout, L.hin, L.win, L.cin_pad,
-                         L.R, L.S, L.stride, L.pad, 1, self.chunk if wsets > 1 else n, self.plan.wc_total if wsets > 1 else 0,
-                         addend_mode, self.dtc)
+        a = self._dgrad_args(L, dx.data_ptr(), wptr, out.data_ptr(), _ptr(addend), G, wsets, addend_mode, _ptr(addend_mask))
         call("fb_conv2d", lib.C.byref(a))
         return out
+
+    def _masked_addend_ok(self, L, G, wsets):
+        """Can the input-gradient convolution of L add the residual-branch gradient through its ReLU bitmask (``addend_mask``)?  Then
+        the BN backward above it does not have to write the masked copy ``dy`` (2 bytes per element of an HBM-bound pass)."""
+        if os.environ.get("FB_MASKED_ADDEND", "1") == "0":
+            return False
+        one = self.theta.data_ptr()                  # any non-null pointers: host-side check only
+        a = self._dgrad_args(L, one, one, one, one, G, wsets, 1, one)
+        return bool(lib.load().fb_conv_masked_addend_supported(lib.C.byref(a)))
 
     def backward(self, patches, G, wsets, theta, gout, pidx):
         """Explicit backward through the DAG; per-chunk gradients are written to ``gout[g]`` (shape [G, P])."""
@@ -533,8 +546,15 @@ class Engine:
             b = plan.blocks[bi]
             a0 = plan.blocks[bi - 1].out if bi > 0 else (self.stem_pooled if plan.stem_pool else self.stem_out)
             last = b.convs[-1]
-            dx, dy = self._bn_bwd(last, d, b.out, G, gout, pidx, want_dy=True)   # dy = d * (out > 0)
-            pool.put(d)
+            first = b.convs[0]
+            # dy = d * (out > 0) is the gradient entering the residual branch.  It is only materialised where its consumer cannot apply
+            # the ReLU bitmask of ``b.out`` itself: the shortcut's BN backward always can, the identity branch's input-gradient
+            # convolution where fb_conv_masked_addend_supported says so.
+            out_bits = self.masks.get(b.out.data_ptr())
+            lazy = out_bits is not None and (b.shortcut is not None or self._masked_addend_ok(first, G, wsets))
+            dx, dy = self._bn_bwd(last, d, b.out, G, gout, pidx, want_dy=not lazy)
+            if not lazy:
+                pool.put(d)
             srcs = [a0] + b.mids
             cur_dx = dx
             for i in range(len(b.convs) - 1, -1, -1):
@@ -546,20 +566,22 @@ class Engine:
                     pool.put(cur_dx, event=ev_cur)
                     cur_dx, _ = self._bn_bwd(b.convs[i - 1], d_mid, b.mids[i - 1], G, gout, pidx, want_dy=False)
                     pool.put(d_mid)
-            first = b.convs[0]
             if b.shortcut is not None:
                 S = b.shortcut
-                dxs, _ = self._bn_bwd(S, dy, None, G, gout, pidx, want_dy=False)
+                dxs, _ = self._bn_bwd(S, d, b.out, G, gout, pidx, want_dy=False) if lazy else self._bn_bwd(S, dy, None, G, gout, pidx, want_dy=False)
                 src = b.pooled if b.pooled is not None else a0
                 self._wgrad(S, src, dxs, G, gout)
                 d_p = self._dgrad(S, dxs, G, wsets)
                 pool.put(dxs, event=self._wgrad_event)
-                d = self._dgrad(first, cur_dx, G, wsets, addend=d_p, addend_mode=2 if b.pooled is not None else 1)
+                d_in = self._dgrad(first, cur_dx, G, wsets, addend=d_p, addend_mode=2 if b.pooled is not None else 1)
                 pool.put(d_p)
+            elif lazy:
+                d_in = self._dgrad(first, cur_dx, G, wsets, addend=d, addend_mode=1, addend_mask=out_bits)
             else:
-                d = self._dgrad(first, cur_dx, G, wsets, addend=dy, addend_mode=1)
+                d_in = self._dgrad(first, cur_dx, G, wsets, addend=dy, addend_mode=1)
             pool.put(cur_dx, event=ev_cur)
-            pool.put(dy)
+            pool.put(d if lazy else dy)
+            d = d_in
         S = plan.stem
         if plan.stem_pool:
             d_r = pool.get((n, S.hout, S.wout, 64))

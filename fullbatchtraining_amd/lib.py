@@ -19,7 +19,7 @@ class ConvArgs(C.Structure):
     _fields_ = [("src", c_void_p), ("wgt", c_void_p), ("dst", c_void_p), ("addend", c_void_p), ("stat_partial", c_void_p),
                 ("n_img", c_int), ("Hs", c_int), ("Ws", c_int), ("Cs", c_int), ("Hd", c_int), ("Wd", c_int), ("Cd", c_int),
                 ("R", c_int), ("S", c_int), ("stride", c_int), ("pad", c_int), ("mode", c_int),
-                ("imgs_per_wset", c_int), ("wset_stride", c_i64), ("addend_mode", c_int), ("dtype", c_int)]
+                ("imgs_per_wset", c_int), ("wset_stride", c_i64), ("addend_mode", c_int), ("dtype", c_int), ("addend_mask", c_void_p)]
 
 
 class WgradArgs(C.Structure):
@@ -67,7 +67,7 @@ _SIGS = {
     "fb_mt_ema": [c_void_p, c_void_p, c_i64, c_float, c_float, c_void_p],
 }
 EXPORTS = tuple(_SIGS) + ("fb_last_error_string", "fb_abi_version", "fb_profile_enable", "fb_profile_read", "fb_ws_conv_stat_floats",
-                          "fb_ws_wgrad_slab_floats", "fb_ws_bn_partial_floats", "fb_ws_mt_floats", "fb_bn_bwd_reduce_rows")
+                          "fb_ws_wgrad_slab_floats", "fb_ws_bn_partial_floats", "fb_ws_mt_floats", "fb_bn_bwd_reduce_rows", "fb_conv_masked_addend_supported")
 PROF_CLASSES = ("igemm_fwd", "igemm_dgrad", "wgrad")
 
 
@@ -112,6 +112,7 @@ def load():
         lib.fb_ws_bn_partial_floats.argtypes, lib.fb_ws_bn_partial_floats.restype = [c_i64, c_int], c_i64
         lib.fb_ws_mt_floats.argtypes, lib.fb_ws_mt_floats.restype = [c_int], c_i64
         lib.fb_bn_bwd_reduce_rows.argtypes, lib.fb_bn_bwd_reduce_rows.restype = [c_i64, c_i64], c_int
+        lib.fb_conv_masked_addend_supported.argtypes, lib.fb_conv_masked_addend_supported.restype = [C.POINTER(ConvArgs)], c_int
         _lib = lib
     return _lib
 
@@ -147,11 +148,12 @@ def dtype_code(dtype):
 # ---------------------------------------------------------------------------------------------------------------------
 # thin tensor-level wrappers (shapes are read from the tensors; NHWC activations)
 # ---------------------------------------------------------------------------------------------------------------------
-def conv2d(src, wgt, dst, R, S, stride, pad, mode, addend=None, addend_mode=0, stat_partial=None, imgs_per_wset=0, wset_stride=0):
+def conv2d(src, wgt, dst, R, S, stride, pad, mode, addend=None, addend_mode=0, stat_partial=None, imgs_per_wset=0, wset_stride=0,
+           addend_mask=None):
     n, hs, ws, cs = src.shape
     _, hd, wd, cd = dst.shape
     a = ConvArgs(_ptr(src), _ptr(wgt), _ptr(dst), _ptr(addend), _ptr(stat_partial), n, hs, ws, cs, hd, wd, cd, R, S, stride, pad, mode,
-                 imgs_per_wset, wset_stride, addend_mode, dtype_code(src.dtype))
+                 imgs_per_wset, wset_stride, addend_mode, dtype_code(src.dtype), _ptr(addend_mask))
     call("fb_conv2d", C.byref(a))
 
 

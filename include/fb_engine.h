@@ -59,8 +59,14 @@ typedef struct {
     int32_t R, S, stride, pad, mode;
     int32_t imgs_per_wset; int64_t wset_stride;   /* elements between weight sets; 0 = shared */
     int32_t addend_mode; int32_t dtype;
+    const void* addend_mask;   /* optional (addend_mode 1): ReLU bitmask of the addend as written by fb_bn_apply (1 byte per 16-byte
+                                * vector): dst += addend only where the bit is set, i.e. the masked residual gradient d * (out > 0) of
+                                * reference resnets.py:118-121 / autograd's threshold_backward without a materialised copy */
 } fb_conv_args;
 int fb_conv2d(const fb_conv_args* a, void* stream);
+/* 1 if fb_conv2d implements addend_mask for these arguments (otherwise it fails with FB_ERR_UNSUPPORTED and the caller masks the
+ * addend itself: fb_bn_bwd_apply's dy_out) */
+int32_t fb_conv_masked_addend_supported(const fb_conv_args* a);
 
 /* wgrad: dw[g][split][Cd][R*S][Cs] (fp32 partial slabs) = sum over the pixels of chunk g (split-K slice `split`) of
  * dy[p][Cd] (x) x[src(p,tap)][Cs]        (ATen convolution_backward, weight part).  Deterministic: no atomics.

@@ -468,3 +468,27 @@ def test_absmax_norm_bias_and_ema_kernels():
         assert torch.allclose(gd.cpu(), ref, rtol=1e-6, atol=1e-7)
     lib.call("fb_mt_ema", ed.data_ptr(), td.data_ptr(), n, 0.99, float(1 - 0.99))
     assert torch.equal(ed.cpu(), 0.99 * ema + (1 - 0.99) * theta)            # the reference expression, bit for bit
+
+
+def test_conv_masked_addend_equals_materialised_mask():
+    """fb_conv_args.addend_mask (input gradient of the 64-channel 32x32 layers): adding `addend` through the ReLU bitmask gives bit
+    for bit what adding the materialised d * (out > 0) gives; unsupported shapes say so instead of ignoring the mask."""
+    lib = _lib()
+    torch.manual_seed(11)
+    n = 16
+    dy = (torch.randn(n, 32, 32, 64, device="cuda") * 0.1).bfloat16()
+    w = (torch.randn(64, 9, 64, device="cuda") * 0.05).bfloat16()
+    d = torch.randn(n, 32, 32, 64, device="cuda").bfloat16()
+    out_act = torch.randn(n, 32, 32, 64, device="cuda")                       # stands in for the block output (sign = ReLU mask)
+    bits = ((out_act.reshape(-1, 8) > 0).to(torch.int32) << torch.arange(8, device="cuda")).sum(1).to(torch.uint8)
+    masked = torch.where(out_act > 0, d, torch.zeros_like(d))
+    a, b = torch.empty_like(d), torch.empty_like(d)
+    lib.conv2d(dy, w, a, 3, 3, 1, 1, 1, addend=masked, addend_mode=1)
+    lib.conv2d(dy, w, b, 3, 3, 1, 1, 1, addend=d, addend_mode=1, addend_mask=bits)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert not torch.equal(a, d)                                               # (the convolution did something)
+    dy2, w2 = dy[:, :16, :16].contiguous().repeat(1, 1, 1, 2), torch.randn(128, 9, 128, device="cuda").bfloat16()
+    d2 = torch.randn(n, 16, 16, 128, device="cuda").bfloat16()
+    with pytest.raises(lib.EngineError):                                       # 128 channels: not implemented, and loudly so
+        lib.conv2d(dy2, w2, torch.empty_like(d2), 3, 3, 1, 1, 1, addend=d2, addend_mode=1, addend_mask=bits)
