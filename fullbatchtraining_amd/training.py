@@ -20,6 +20,7 @@ import os
 import time
 from collections import defaultdict
 
+import numpy as np
 import torch
 from torch.optim.lr_scheduler import _LRScheduler
 
@@ -397,9 +398,9 @@ class FullBatchTrainer:
         loss_k, correct_k, sq_k, (gn2, pn2), pre2 = host[:K], host[K:2 * K], host[2 * K:3 * K], host[3 * K:3 * K + 2], host[3 * K + 2]
         for idx, entry in enumerate(sq_k.sqrt().tolist()):
             stats[f"grad_norm_train_{idx}"] += [entry]
-        step_loss = torch.zeros(())
-        for v in loss_k:                      # sequential fp32 sum, like `step_loss += chunk_loss`
-            step_loss = step_loss + v
+        # sequential fp32 sum, like the reference's `step_loss += chunk_loss` (np.cumsum accumulates strictly left to right; 390 torch
+        # scalar additions cost ~2 ms of host time per step, 6 % of a step at 8 GPUs)
+        step_loss = torch.tensor(float(np.cumsum(loss_k.numpy(), dtype=np.float32)[-1])) if K > 0 else torch.zeros(())
         full_grad_norm = sq_k.mean()
         param_norm = pn2
         train_loss = step_loss / K
