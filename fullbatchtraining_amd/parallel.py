@@ -85,13 +85,18 @@ def reduce_scatter_update_all_gather(avg, theta, plan, ops, group=None):
 
 
 def all_gather_chunk_stats(local, plan, group=None):
-    """local: [count_r] per-chunk values of this rank -> [K] in chunk order on every rank."""
+    """local: [count_r] (or [R, count_r]: R statistics in ONE collective) per-chunk values of this rank -> [K] (or [R, K]) in chunk
+    order on every rank."""
+    flat = local.dim() == 1
+    rows = local.reshape(1, -1) if flat else local
     width = max(plan.counts)
-    padded = torch.zeros(width, device=local.device, dtype=local.dtype)
-    padded[:local.numel()] = local
-    out = torch.empty(plan.world * width, device=local.device, dtype=local.dtype)
-    dist.all_gather_into_tensor(out, padded, group=group)
-    return torch.cat([out[r * width:r * width + plan.counts[r]] for r in range(plan.world)])
+    padded = torch.zeros(rows.shape[0], width, device=rows.device, dtype=rows.dtype)
+    padded[:, :rows.shape[1]] = rows
+    out = torch.empty(plan.world * padded.numel(), device=rows.device, dtype=rows.dtype)
+    dist.all_gather_into_tensor(out, padded.reshape(-1), group=group)
+    out = out.view(plan.world, rows.shape[0], width)
+    res = torch.cat([out[r, :, :plan.counts[r]] for r in range(plan.world)], dim=1)
+    return res[0] if flat else res
 
 
 def combine_running_stats(r0, r_local, plan, updates_per_chunk, momentum=0.1, group=None):
@@ -144,4 +149,5 @@ def sharded_update(trainer, loss_k, correct_k, sq_k, lr, weight_decay=None):
     eng.running_mean.copy_(combined[0])
     eng.running_var.copy_(combined[1])
     eng.num_batches_tracked += (plan.n_chunks - plan.count) * passes
-    return (all_gather_chunk_stats(loss_k, plan), all_gather_chunk_stats(correct_k, plan), all_gather_chunk_stats(sq_k, plan))
+    gathered = all_gather_chunk_stats(torch.stack([loss_k, correct_k, sq_k]), plan)        # one collective for the three statistics
+    return gathered[0], gathered[1], gathered[2]

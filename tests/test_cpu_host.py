@@ -215,6 +215,9 @@ def _worker(rank, world, port, K, P, out_dir):
     ops = ShardOps(scale=lambda t, a: t.mul_(a), sqnorm=lambda t: t.pow(2).sum(), update=update)
     gnorm2 = reduce_scatter_update_all_gather(avg, theta, plan, ops)
     full_stats = all_gather_chunk_stats(stats[plan.first:plan.first + plan.count].clone(), plan)
+    mine = stats[plan.first:plan.first + plan.count]
+    full_rows = all_gather_chunk_stats(torch.stack([mine, 2 * mine, mine + 1]), plan)          # several statistics, one collective
+    assert torch.equal(full_rows, torch.stack([stats, 2 * stats, stats + 1]))
     # rank-local EMA of BN statistics
     r_local = r0.clone()
     for k in range(plan.first, plan.first + plan.count):
