@@ -271,6 +271,23 @@ def _device_augmentation(cfg, trainloader):
     return out
 
 
+def _evaluate_batch(eng, xb, yb, test_time_flips):
+    """Loss sum and #correct of one validation batch (reference training.py:365-380).  ``test_time_flips``: the reference feeds the SUM
+    of the softmax outputs of the image and of its horizontal mirror to the loss function and the argmax (training.py:370-373); the
+    two forward passes run through the engine (the mirror is taken by the patch-gather kernel), the 10-way epilogue is host-side glue."""
+    if not test_time_flips:
+        l, c = eng.evaluate_batch(stem_patches(xb, eng.plan.stem, eng.dt), yb)
+        return l * yb.shape[0], c
+    n = xb.shape[0]
+    eng.evaluate_batch(stem_patches(xb, eng.plan.stem, eng.dt), yb)
+    left = eng.logits[:n].softmax(dim=1)
+    mirror = torch.ones(n, dtype=torch.int8, device=xb.device)
+    eng.evaluate_batch(stem_patches(xb.float().contiguous(), eng.plan.stem, eng.dt, aug=(None, None, mirror, 0, None)), yb)
+    outputs = left + eng.logits[:n].softmax(dim=1)
+    loss = torch.nn.functional.cross_entropy(outputs, yb)
+    return float(loss) * n, float((outputs.argmax(dim=-1) == yb).float().sum())
+
+
 class FullBatchTrainer:
     """Owns the engine, the resident dataset and the optimizer/scheduler state containers for one training run."""
 
@@ -421,12 +438,10 @@ class FullBatchTrainer:
             stats["clipped_step"] += [1 if grad_norm > hyp.grad_clip else 0]
 
     def evaluate(self, stats=None):
-        """Reference training.py:343-388 (no TTA): BN in eval mode, mean CE and accuracy over the validation set."""
+        """Reference training.py:343-388: BN in eval mode, mean CE and accuracy over the validation set (optionally with mirrored inputs)."""
         stats = self.stats if stats is None else stats
         if self.valid is None:
             return stats
-        if self.cfg.hyp.test_time_flips:
-            raise NotImplementedError("test_time_flips")
         X, Y = self.valid
         eng = self.engine
         cap = eng.G * eng.chunk
@@ -437,8 +452,8 @@ class FullBatchTrainer:
         try:
             for i in range(0, X.shape[0], cap):
                 xb, yb = X[i:i + cap], Y[i:i + cap]
-                l, c = eng.evaluate_batch(stem_patches(xb, eng.plan.stem, eng.dt), yb)
-                loss_sum += l * yb.shape[0]
+                l, c = _evaluate_batch(eng, xb, yb, bool(self.cfg.hyp.test_time_flips))
+                loss_sum += l
                 correct += c
                 n += yb.shape[0]
                 if self.cfg.dryrun:
@@ -456,8 +471,6 @@ def evaluate(model, dataloader, stats, setup, impl, hyp, dryrun=False):
     mean CE, fraction correct.  Used by verify_model_checkpoint.py; `train` evaluates through its own engine instead."""
     if stats is None:
         stats = defaultdict(list)
-    if getattr(hyp, "test_time_flips", False):
-        raise NotImplementedError("test_time_flips")
     device = setup["device"] if torch.device(setup["device"]).type == "cuda" else torch.device("cuda")
     X, Y = _stage(dataloader, device)
     dtype = torch.bfloat16 if impl.mixed_precision else torch.float32
@@ -466,8 +479,8 @@ def evaluate(model, dataloader, stats, setup, impl, hyp, dryrun=False):
     loss_sum, correct, n = 0.0, 0.0, 0
     for i in range(0, X.shape[0], batch):
         xb, yb = X[i:i + batch], Y[i:i + batch]
-        l, c = eng.evaluate_batch(stem_patches(xb, eng.plan.stem, eng.dt), yb)
-        loss_sum, correct, n = loss_sum + l * yb.shape[0], correct + c, n + yb.shape[0]
+        l, c = _evaluate_batch(eng, xb, yb, bool(getattr(hyp, "test_time_flips", False)))
+        loss_sum, correct, n = loss_sum + l, correct + c, n + yb.shape[0]
         if dryrun:
             break
     stats["valid_loss"] += [loss_sum / n]

@@ -583,12 +583,16 @@ def sgd_step(params, grads, momentum, lr, hyp):
         p.add_(d, alpha=-lr)
 
 
-def evaluate(spec, params, buffers, X, Y, batch=128, q=identity):
-    """Restates ``evaluate`` (reference training.py:343-388) for one process, no TTA."""
+def evaluate(spec, params, buffers, X, Y, batch=128, q=identity, test_time_flips=False):
+    """Restates ``evaluate`` (reference training.py:343-388) for one process.  ``test_time_flips`` (training.py:370-373): the SUM of
+    the softmax outputs of the image and of its horizontal mirror goes into the loss function and the argmax in place of logits."""
     step_loss, step_preds, datapoints = 0.0, 0.0, 0
     for i in range(0, X.shape[0], batch):
         xb, yb = X[i:i + batch], Y[i:i + batch]
         logits, _ = forward(spec, params, buffers, xb, q, update_bn=False, train=False)
+        if test_time_flips:
+            mirrored, _ = forward(spec, params, buffers, torch.flip(xb, [3]), q, update_bn=False, train=False)
+            logits = logits.softmax(dim=1) + mirrored.softmax(dim=1)
         loss, correct, _ = cross_entropy_fwd_bwd(logits, yb)
         step_loss += float(loss) * yb.shape[0]
         step_preds += float(correct)
@@ -619,7 +623,7 @@ def train(spec, state, X, Y, hyp, steps, chunk, scheduler="cosine-decay", warmup
                     dst[k].copy_(m * dst[k] + (1 - m) * src[k])
             eval_params, eval_buffers = ema_params, ema_buffers
         if Xv is not None and (step % validate_every == 0 or step + 1 >= steps):
-            vl, va = evaluate(spec, eval_params, eval_buffers, Xv, Yv, q=q)
+            vl, va = evaluate(spec, eval_params, eval_buffers, Xv, Yv, q=q, test_time_flips=hyp.get("test_time_flips", False))
             stats["valid_loss"].append(vl)
             stats["valid_acc"].append(va)
     stats["_momentum"] = momentum

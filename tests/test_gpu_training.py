@@ -103,6 +103,27 @@ def test_train_ema_evaluation_matches_reference(golden, tmp_path):
     assert err < max(10 * rel_err(data[f"{name}/final_sample"], data[f"{name}@f64/final_sample"]), 1e-5)
 
 
+def test_train_test_time_flips_matches_reference(golden, tmp_path):
+    """hyp.test_time_flips (reference training.py:370-373): validation on softmax(image) + softmax(mirror)."""
+    data, meta = golden
+    name = "fb_tta"
+    cfg, model, stats = _run(meta, name, ["impl.engine.chunk_group=2"], tmp_path, valid_full=True)
+    for key in ("train_loss", "valid_loss", "valid_acc"):
+        r64, r32 = data[f"{name}@f64/stat/{key}"], data[f"{name}/stat/{key}"]
+        print(f"{name} {key}: engine {np.array(stats[key])} ref32 {r32} ref64 {r64}")
+        bound = np.maximum(1e-3 * np.abs(r64) + 1e-6, 5 * np.abs(r32 - r64))
+        assert len(stats[key]) == len(r64) and np.all(np.abs(np.array(stats[key]) - r64) <= bound), (key, stats[key], r32, r64)
+    # the mirrored evaluation differs from the plain one (the option is live)
+    from fullbatchtraining_amd.training import evaluate
+    from fullbatchtraining_amd.cfg import compose
+    x, y = make_data(meta["scenarios"][name]["n"], meta["scenarios"][name]["pixels"])
+    setup = dict(device=torch.device("cuda:0"), dtype=torch.float, memory_format=torch.contiguous_format)
+    plain = evaluate(model, (x, y), None, setup, cfg.impl, compose(["hyp=fb1"]).hyp)
+    flips = evaluate(model, (x, y), None, setup, cfg.impl, cfg.hyp)
+    assert abs(flips["valid_loss"][-1] - stats["valid_loss"][-1]) < 1e-5 * abs(stats["valid_loss"][-1])
+    assert abs(plain["valid_loss"][-1] - flips["valid_loss"][-1]) > 1e-3
+
+
 def test_train_bf16_tracks_fp32_statistics(golden, tmp_path):
     """bf16 compute path (impl.mixed_precision=True): training statistics over 2 steps vs the reference's float64 run.
     Tolerance 2e-2 on losses/norms: storage rounding 2^-9 per activation, averaged over 4 chunks of 128."""
