@@ -702,6 +702,13 @@ class Engine:
              float(dampening), 1 if nesterov else 0, 1 if self.first_step else 0)
         self.first_step = False
 
+    def sgd_step_per_tensor(self, lr, weight_decays, momentum, dampening, nesterov, grad_clip=None):
+        """``sgd_step`` with one weight decay per parameter tensor (``model.parameters()`` order): one launch per tensor range."""
+        first = self.first_step
+        for name, wd in zip(self.plan.param_names, weight_decays):
+            self.first_step = first
+            self.sgd_step(lr, wd, momentum, dampening, nesterov, grad_clip, lo=self.plan.offsets[name], n=math.prod(self.plan.param_shapes[name]))
+
     def clip_norm_inf(self):
         """``hyp.grad_clip_norm=inf`` (reference training.py:199-200): put (max|avg|)^2 into the clip-norm slot ``self.norms2[0]``."""
         call("fb_mt_absmax2", self.avg.data_ptr(), self.plan.P, self.norms2.data_ptr(), self.mt_ws.data_ptr())

@@ -17,6 +17,7 @@ exact layout and the LR sequence is produced by the same torch code the referenc
 """
 import logging
 import os
+import re
 import time
 from collections import defaultdict
 
@@ -81,10 +82,17 @@ def optim_interface(model, cfg_hyp):
     mod = cfg_hyp.optim_modification.name
     if mod not in ("none", "SAM", "LARS", "LARC"):
         raise ValueError(f"Invalid optim_modification {mod} provided.")
-    if cfg_hyp.only_linear_layers_weight_decay:
-        raise NotImplementedError("only_linear_layers_weight_decay=True needs per-tensor weight decay (not on the hot path)")
     params = {k: v for k, v in cfg_hyp.optim.items() if k not in ("name", "line_search")}
-    optimizer = wrapped = torch.optim.SGD(model.parameters(), **params)
+    if cfg_hyp.only_linear_layers_weight_decay:      # reference optimizers.py:14-21: one param group per tensor, no decay on biases / gains
+        parameter_iterable = []
+        for key, value in model.named_parameters():
+            if len(re.findall("(bias|gain)|skip_gain", key)) > 0:
+                parameter_iterable += [{"params": [value], "weight_decay": 0.0}]
+            else:
+                parameter_iterable += [{"params": [value]}]
+    else:
+        parameter_iterable = model.parameters()
+    optimizer = wrapped = torch.optim.SGD(parameter_iterable, **params)
     if mod == "SAM":
         wrapped = SAM(optimizer, rho=cfg_hyp.optim_modification.rho)
     elif mod in ("LARS", "LARC"):
@@ -236,6 +244,8 @@ def _check_scope(cfg):
     if hyp.grad_clip is not None and float(hyp.grad_clip_norm) not in (2.0, float("inf")):
         raise NotImplementedError("grad_clip_norm: the global L2 and L-infinity clips are implemented")
     sharded = torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+    if sharded and hyp.only_linear_layers_weight_decay:
+        raise NotImplementedError("only_linear_layers_weight_decay in the sharded path (per-tensor weight decay across shard boundaries)")
     if sharded and (hyp.norm_bias.strength > 0 or (hyp.grad_clip is not None and float(hyp.grad_clip_norm) != 2.0)):
         raise NotImplementedError("norm_bias / L-infinity clip in the sharded path")
     if hyp.shuffle:
@@ -381,13 +391,23 @@ class FullBatchTrainer:
                 modify()                         # param_norm of the second record is taken at theta + e_w, like the reference's
                 self._record_stats(loss_k, correct_k, sq_k, eng.norms2, lr, train_time)
                 eng.sam_restore()
-                eng.sgd_step(lr, o.weight_decay, o.momentum, o.dampening, o.nesterov, hyp.grad_clip)
+                self._update(lr)
                 self.scheduler.step()
                 return
             # LARS / LARC: the wrapper zeroes the weight decay around SGD.step(closure) and nothing else survives the closure (see LARS)
-            eng.sgd_step(lr, 0.0 if mod in ("LARS", "LARC") else o.weight_decay, o.momentum, o.dampening, o.nesterov, hyp.grad_clip)
+            self._update(lr, zero_wd=mod in ("LARS", "LARC"))
         self._record_stats(loss_k, correct_k, sq_k, eng.norms2, lr, train_time)
         self.scheduler.step()
+
+    def _update(self, lr, zero_wd=False):
+        """Clip + Nesterov SGD on the arena; per-tensor weight decay when the optimizer has one param group per tensor
+        (``hyp.only_linear_layers_weight_decay``, reference optimizers.py:14-21)."""
+        eng, hyp, o = self.engine, self.cfg.hyp, self.cfg.hyp.optim
+        if hyp.only_linear_layers_weight_decay and not zero_wd:
+            wds = [g["weight_decay"] for g in self.optimizer.param_groups]
+            eng.sgd_step_per_tensor(lr, wds, o.momentum, o.dampening, o.nesterov, hyp.grad_clip)
+        else:
+            eng.sgd_step(lr, 0.0 if zero_wd else o.weight_decay, o.momentum, o.dampening, o.nesterov, hyp.grad_clip)
 
     def _regather_augmented(self):
         """A fresh RandomCrop offset / flip per image and step (the reference draws them in its DataLoader workers once per epoch =

@@ -24,6 +24,8 @@ is the one pinned to the reference.
 import math
 from collections import OrderedDict, defaultdict
 
+import re
+
 import torch
 import torch.nn.functional as F
 
@@ -571,8 +573,10 @@ def _gradient_evaluation(spec, params, buffers, X, Y, hyp, lr, stats, chunk, q=i
 
 def sgd_step(params, grads, momentum, lr, hyp):
     """torch.optim.SGD semantics (weight decay, momentum w/ first-step buffer = d, dampening, Nesterov)."""
-    mu, wd, damp = hyp["momentum"], hyp["weight_decay"], hyp.get("dampening", 0.0)
-    for i, (p, g) in enumerate(zip(params.values(), grads)):
+    mu, wd_all, damp = hyp["momentum"], hyp["weight_decay"], hyp.get("dampening", 0.0)
+    for i, ((name, p), g) in enumerate(zip(params.items(), grads)):
+        # only_linear_layers_weight_decay (reference optimizers.py:14-21): one param group per tensor, no decay on "bias"/"gain" names
+        wd = 0.0 if (hyp.get("only_linear_layers_weight_decay") and re.findall("(bias|gain)|skip_gain", name)) else wd_all
         d = g.add(p, alpha=wd) if wd != 0 else g.clone()
         if mu != 0:
             if momentum[i] is None:

@@ -118,6 +118,8 @@ SCENARIOS_A9 = {
                                "hyp.warmup=0", "data.batch_size=64", "hyp.sub_batch=64"], 21),
     "fb_normbias2": (128, 16, ["hyp=fb1", "hyp.norm_bias.strength=1e-4", "hyp.norm_bias.norm_type=2", "hyp.norm_bias.bias=70", "hyp.steps=3",
                                "hyp.warmup=0", "hyp.optim.weight_decay=0.0", "data.batch_size=64", "hyp.sub_batch=64"], 23),
+    "fb_linwd": (128, 16, ["hyp=fb1", "hyp.only_linear_layers_weight_decay=True", "hyp.optim.weight_decay=0.05", "hyp.steps=3", "hyp.warmup=0",
+                           "data.batch_size=64", "hyp.sub_batch=64"], 29),
     "fb_tta": (128, 16, ["hyp=fb1", "hyp.test_time_flips=True", "hyp.steps=2", "hyp.warmup=0", "data.batch_size=64", "hyp.sub_batch=64"], 27),
     "fb_ema": (128, 16, ["hyp=fb1", "hyp.evaluate_ema=True", "hyp.eval_ema_momentum=0.6", "hyp.steps=3", "hyp.warmup=0", "data.batch_size=64",
                          "hyp.sub_batch=64"], 25),

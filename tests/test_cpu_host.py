@@ -151,6 +151,14 @@ def test_optimizer_wrappers_have_the_reference_surface():
     assert sam.rho == 0.1
     larc, _ = optim_interface(net, compose(["hyp=fb1", "hyp/optim_modification=LARC"]).hyp)
     assert larc.clip is True and larc.trust_coefficient == 0.02 and larc.eps == 1e-8
+    # only_linear_layers_weight_decay (reference optimizers.py:14-21): one group per tensor, biases without decay
+    from fullbatchtraining_amd.models import construct_model
+    r18 = construct_model(compose([]).model, 3, 10)
+    opt, _ = optim_interface(r18, compose(["hyp=fb1", "hyp.only_linear_layers_weight_decay=True"]).hyp)
+    names = [k for k, _ in r18.named_parameters()]
+    assert len(opt.param_groups) == len(names) == 62
+    assert all((g["weight_decay"] == 0.0) == ("bias" in k) for g, k in zip(opt.param_groups, names))
+    assert sum(g["weight_decay"] == 0.0 for g in opt.param_groups) == 21             # 20 BN biases + fc.bias
     bad = compose(["hyp=fb1"])
     bad.hyp.optim_modification.name = "Lookahead"
     with pytest.raises(ValueError):

@@ -492,3 +492,36 @@ def test_conv_masked_addend_equals_materialised_mask():
     d2 = torch.randn(n, 16, 16, 128, device="cuda").bfloat16()
     with pytest.raises(lib.EngineError):                                       # 128 channels: not implemented, and loudly so
         lib.conv2d(dy2, w2, torch.empty_like(d2), 3, 3, 1, 1, 1, addend=d2, addend_mode=1, addend_mask=bits)
+
+
+def test_engine_per_tensor_weight_decay_matches_torch_sgd():
+    """Engine.sgd_step_per_tensor (hyp.only_linear_layers_weight_decay) vs torch.optim.SGD with one param group per tensor, two steps
+    (first-step momentum initialisation included)."""
+    from fullbatchtraining_amd.cfg import compose
+    from fullbatchtraining_amd.engine import Engine
+    from fullbatchtraining_amd.models import construct_model
+    from fullbatchtraining_amd.training import optim_interface
+
+    torch.manual_seed(3)
+    cfg = compose(["hyp=fb1", "hyp.only_linear_layers_weight_decay=True", "hyp.optim.weight_decay=0.05"])
+    model = construct_model(cfg.model, 3, 10)
+    eng = Engine(model, 16, 32, 1, compute_dtype=torch.float32)
+    opt, _ = optim_interface(model, cfg.hyp)
+    wds = [g["weight_decay"] for g in opt.param_groups]
+    o = cfg.hyp.optim
+    for step in range(2):
+        grads = [torch.randn_like(p) * 0.01 for p in model.parameters()]
+        flat = torch.zeros(eng.plan.P)
+        for name, g in zip(eng.plan.param_names, grads):
+            v = g.permute(0, 2, 3, 1).reshape(-1) if g.dim() == 4 else g.reshape(-1)
+            flat[eng.plan.offsets[name]:eng.plan.offsets[name] + v.numel()] = v
+        eng.avg.copy_(flat)
+        eng.sgd_step_per_tensor(0.1, wds, o.momentum, o.dampening, o.nesterov, None)
+        for p, g in zip(model.parameters(), grads):
+            p.grad = g
+        for g in opt.param_groups:
+            g["lr"] = 0.1
+        opt.step()
+    got = eng.theta.cpu()
+    for name, p in zip(eng.plan.param_names, model.parameters()):
+        assert torch.allclose(eng._unflatten(got, name), p.detach(), rtol=1e-6, atol=1e-7), name
