@@ -172,8 +172,11 @@ __global__ void head_logits_kernel(const float* __restrict__ feat, const float* 
     }
 }
 // one block per group: per-image log-softmax (thread per image), then a fixed-order sum of the per-image losses.
+// smoothing: label smoothing of LabelSmoothCrossEntropyLoss (reference modules.py:86-101: weight 1-s on the target, s/(C-1) elsewhere);
+// only_incorrect: IncorrectCrossEntropyLoss (modules.py:104-119: already correct samples contribute no loss and no gradient).
 __global__ void head_loss_kernel(const float* __restrict__ logits, const long long* __restrict__ labels, float* __restrict__ dlogits,
-                                 float* __restrict__ loss, float* __restrict__ correct, int ipg, int classes) {
+                                 float* __restrict__ loss, float* __restrict__ correct, int ipg, int classes, float smoothing,
+                                 int only_incorrect) {
     extern __shared__ float sm[];   // [ipg] losses, [ipg] corrects
     const int g = blockIdx.x;
     for (int n = threadIdx.x; n < ipg; n += blockDim.x) {
@@ -186,8 +189,15 @@ __global__ void head_loss_kernel(const float* __restrict__ logits, const long lo
         for (int j = 0; j < classes; ++j) se += expf(z[j] - m);
         const float lse = logf(se);
         const float inv_n = 1.f / (float)ipg;
-        for (int j = 0; j < classes; ++j) dz[j] = (expf(z[j] - m - lse) - (j == label ? 1.f : 0.f)) * inv_n;
-        sm[n] = -(z[label] - m - lse);
+        const float keep = (only_incorrect && am == label) ? 0.f : 1.f;
+        const float w_t = 1.f - smoothing, w_o = smoothing / ((float)classes - 1.f);
+        float li = 0.f;
+        for (int j = 0; j < classes; ++j) {
+            const float logp = z[j] - m - lse, w = j == label ? w_t : w_o;
+            dz[j] = (expf(logp) - w) * inv_n * keep;
+            if (w != 0.f) li -= w * logp;
+        }
+        sm[n] = li * keep;
         sm[ipg + n] = (am == label) ? 1.f : 0.f;
     }
     __syncthreads();
@@ -200,12 +210,13 @@ __global__ void head_loss_kernel(const float* __restrict__ logits, const long lo
 
 extern "C" int fb_head_loss(const float* feat, const float* fc_w, const float* fc_b, int64_t param_group_stride, const int64_t* labels,
                             float* logits, float* dlogits, float* loss, float* correct, int32_t n_groups, int32_t imgs_per_group,
-                            int32_t C, int32_t classes, void* stream) {
+                            int32_t C, int32_t classes, float label_smoothing, int32_t only_incorrect, void* stream) {
     if (!feat || !fc_w || !fc_b || !labels || !logits || !dlogits || !loss || !correct) FB_FAIL(FB_ERR_ARG, "fb_head_loss: null pointer");
+    if (label_smoothing < 0.f || label_smoothing >= 1.f || classes < 2) FB_FAIL(FB_ERR_ARG, "fb_head_loss: label_smoothing=%g, classes=%d", (double)label_smoothing, classes);
     hipLaunchKernelGGL(head_logits_kernel, dim3(imgs_per_group, n_groups), dim3(64), 0, (hipStream_t)stream, feat, fc_w, fc_b,
                        (long long)param_group_stride, logits, imgs_per_group, C, classes);
     hipLaunchKernelGGL(head_loss_kernel, dim3(n_groups), dim3(128), (size_t)2 * imgs_per_group * sizeof(float), (hipStream_t)stream, logits,
-                       (const long long*)labels, dlogits, loss, correct, imgs_per_group, classes);
+                       (const long long*)labels, dlogits, loss, correct, imgs_per_group, classes, label_smoothing, only_incorrect);
     FB_CHECK_LAUNCH("fb_head_loss");
     return FB_OK;
 }

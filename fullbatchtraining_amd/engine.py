@@ -229,6 +229,7 @@ class Engine:
         # HBM-bound BN backward kernels and the dgrad convolutions of the main stream (FB_WGRAD_STREAM=0: same stream)
         self.wstream = torch.cuda.Stream(device=self.device) if os.environ.get("FB_WGRAD_STREAM", "1") != "0" else None
         self._wgrad_event = None
+        self.label_smoothing, self.only_incorrect = 0.0, False      # loss function of the head kernel (reference get_loss_fn)
         self.load_from_model(model)
 
     # ------------------------------------------------------------------------------------------------------ buffers --
@@ -460,7 +461,9 @@ class Engine:
         pstride = plan.P if wsets > 1 else 0
         call("fb_head_loss", self.feat.data_ptr(), theta.data_ptr() + 4 * plan.fcw_off, theta.data_ptr() + 4 * plan.fcb_off, pstride,
              labels.data_ptr(), self.logits.data_ptr(), self.dlogits.data_ptr(), self.loss.data_ptr(), self.correct.data_ptr(), G,
-             self.chunk, plan.feat, plan.classes)
+             self.chunk, plan.feat, plan.classes,
+             # the training loss of get_loss_fn; evaluation always uses plain cross entropy (reference training.py:345)
+             0.0 if getattr(self, "_eval", False) else float(self.label_smoothing), 0 if getattr(self, "_eval", False) else int(self.only_incorrect))
         return a
 
     # ----------------------------------------------------------------------------------------------------- backward --

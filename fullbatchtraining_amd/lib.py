@@ -49,7 +49,7 @@ _SIGS = {
     "fb_maxpool3s2_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "fb_head_pool": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "fb_head_loss": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                     c_void_p],
+                     c_float, c_int, c_void_p],
     "fb_head_bwd": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                     c_void_p],
     "fb_mt_sqnorm": [c_void_p, c_i64, c_int, c_i64, c_float, c_void_p, c_float, c_void_p, c_void_p, c_void_p],

@@ -56,6 +56,11 @@ class GradRegularizer:
             sets = 2 if self.implementation == "central-differences" else 1
             self._engines[key] = Engine(self.model, inputs.shape[-1], inputs.shape[0], 1, compute_dtype=torch.float32,
                                         device=inputs.device, fd_sets=sets)
+            loss_fn = self.loss_fn      # the perturbed passes use the caller's loss (reference modules.py:228-230): CE / smoothing / incorrect-xent
+            if not (isinstance(loss_fn, torch.nn.CrossEntropyLoss) or hasattr(loss_fn, "smoothing")):
+                raise NotImplementedError(f"GradRegularizer: loss function {type(loss_fn).__name__} is not implemented by the head kernel")
+            self._engines[key].label_smoothing = getattr(loss_fn, "smoothing", 0.0)
+            self._engines[key].only_incorrect = getattr(loss_fn, "only_incorrect", False)
         return self._engines[key]
 
     @torch.no_grad()

@@ -7,7 +7,7 @@ Mirrors, for ``hyp.train_stochastic=False``:
   _record_stats              :85-119    (same keys, same formulas)
   _modify_gradient_params    :187-215   (norm bias, global L2 / L-infinity clip; gradient noise -> NotImplementedError)
   evaluate                   :343-388
-  get_loss_fn                :391-413   (default CrossEntropyLoss only; it is fused into the head kernel)
+  get_loss_fn                :391-413   (cross entropy, label smoothing, incorrect-xent: fused into the head kernel)
   optim_interface            fullbatch/training/optimizers.py:10-93 (Gradient Descent / line_search none; cosine-*, warm-up)
   _save_to_checkpoint / _load_from_checkpoint   fullbatch/training/utils.py:43-70 (same 5-list layout)
 
@@ -207,11 +207,36 @@ def _load_from_checkpoint(model, optimizer, scheduler, scaler, counter, max_step
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+class _HeadLoss(torch.nn.Module):
+    """The loss functions of the reference's ``get_loss_fn`` that the head kernel implements: mean cross entropy with label smoothing
+    ``s`` (LabelSmoothCrossEntropyLoss, reference modules.py:86-101) and optionally only on misclassified samples
+    (IncorrectCrossEntropyLoss, modules.py:104-119).  Callable like the reference's modules (host-side, for callers that hold a
+    loss_fn); the engine reads ``smoothing`` / ``only_incorrect`` and runs the fused kernel."""
+
+    def __init__(self, smoothing=0.0, only_incorrect=False):
+        super().__init__()
+        self.smoothing, self.only_incorrect = float(smoothing), bool(only_incorrect)
+
+    def forward(self, input, target):
+        log_prob = torch.nn.functional.log_softmax(input, dim=-1)
+        weight = torch.ones_like(input) * self.smoothing / (input.shape[-1] - 1.0)
+        weight.scatter_(-1, target.unsqueeze(-1), (1.0 - self.smoothing))
+        loss_per_sample = (-weight * log_prob).sum(dim=-1)
+        if self.only_incorrect:
+            loss_per_sample = loss_per_sample * (1 - (input.argmax(dim=1) == target).float())
+        return loss_per_sample.mean()
+
+
 def get_loss_fn(cfg_hyp, batch_size):
-    if cfg_hyp.label_smoothing not in [None, "", 0, 0.0] or cfg_hyp.loss_modification is not None:
-        raise NotImplementedError("label smoothing / loss modifications are off the hot path; the fused head kernel "
-                                  "implements torch.nn.CrossEntropyLoss() (mean)")
-    return torch.nn.CrossEntropyLoss()
+    """Reference training.py:391-413.  The maxup losses need the augmented-trials layout of the stochastic pipeline (off this path)."""
+    smoothing = cfg_hyp.label_smoothing if cfg_hyp.label_smoothing not in [None, ""] else 0.0
+    if cfg_hyp.loss_modification is None:
+        return torch.nn.CrossEntropyLoss() if smoothing == 0 else _HeadLoss(smoothing)
+    if cfg_hyp.loss_modification == "incorrect-xent":
+        return _HeadLoss(smoothing, only_incorrect=True)
+    if "maxup" in str(cfg_hyp.loss_modification):
+        raise NotImplementedError("maxup losses are off the full-batch hot path")
+    raise ValueError(f"Invalid loss modification {cfg_hyp.loss_modification}.")
 
 
 def _stage(loader, device):
@@ -306,7 +331,7 @@ class FullBatchTrainer:
         self.cfg, self.model = cfg, model
         self.device = torch.device(setup["device"]) if not isinstance(setup["device"], torch.device) else setup["device"]
         self.optimizer, self.scheduler = optim_interface(model, cfg.hyp)
-        get_loss_fn(cfg.hyp, cfg.data.batch_size)
+        self.loss_fn = get_loss_fn(cfg.hyp, cfg.data.batch_size)
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
         self.rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
         X, Y = _stage(trainloader, self.device)
@@ -331,6 +356,8 @@ class FullBatchTrainer:
         G = group_size(self.shard.count, int(cfg.impl.get("engine", {}).get("chunk_group", 98)),
                        cap=max_group(Plan(model, X.shape[-1]), self.chunk, self.dtype))
         self.engine = Engine(model, X.shape[-1], self.chunk, G, compute_dtype=self.dtype, device=self.device, fd_sets=fd_sets)
+        self.engine.label_smoothing = getattr(self.loss_fn, "smoothing", 0.0)
+        self.engine.only_incorrect = getattr(self.loss_fn, "only_incorrect", False)
         stem = self.engine.plan.stem
         lo, hi = self.shard.first * self.chunk, (self.shard.first + self.shard.count) * self.chunk
         self.patches = torch.empty(hi - lo, stem.hout, stem.wout, stem.cin_pad, device=self.device, dtype=self.dtype) if hi > lo else None

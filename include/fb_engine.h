@@ -155,10 +155,11 @@ int fb_maxpool3s2_bwd(const void* x, const void* dy, void* dx, int32_t n_img, in
 /* AdaptiveAvgPool2d(1) + flatten (resnets.py:185-186): feat[n][C] fp32 */
 int fb_head_pool(const void* a, float* feat, int32_t n_img, int32_t HW, int32_t C, int32_t dtype, void* stream);
 /* fc + log_softmax + nll (mean over the chunk) + argmax-correct (training.py:78-80): logits, dlogits [n][classes],
- * loss[g], correct[g] */
+ * loss[g], correct[g].  The loss functions of get_loss_fn (training.py:391-413): label_smoothing s -> LabelSmoothCrossEntropyLoss
+ * (modules.py:86-101; s = 0 is CrossEntropyLoss), only_incorrect -> IncorrectCrossEntropyLoss (modules.py:104-119). */
 int fb_head_loss(const float* feat, const float* fc_w, const float* fc_b, int64_t param_group_stride, const int64_t* labels,
                  float* logits, float* dlogits, float* loss, float* correct, int32_t n_groups, int32_t imgs_per_group,
-                 int32_t C, int32_t classes, void* stream);
+                 int32_t C, int32_t classes, float label_smoothing, int32_t only_incorrect, void* stream);
 /* dW_fc[g], db_fc[g] into the gradient arena and d_a = (dlogits @ W)/HW broadcast over the HW pixels */
 int fb_head_bwd(const float* feat, const float* dlogits, const float* fc_w, int64_t param_group_stride, float* dfc_w,
                 float* dfc_b, int64_t grad_group_stride, void* d_a, int32_t n_groups, int32_t imgs_per_group, int32_t HW,

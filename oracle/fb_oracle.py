@@ -191,18 +191,24 @@ def avgpool2_bwd(dy):
     return dy.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3) * 0.25
 
 
-def cross_entropy_fwd_bwd(logits, labels):
-    """mean-reduced CE = log_softmax + nll_loss (reference training.py:403, used :79) and its gradient."""
-    n = logits.shape[0]
+def cross_entropy_fwd_bwd(logits, labels, smoothing=0.0, only_incorrect=False):
+    """mean-reduced CE = log_softmax + nll_loss (reference training.py:403, used :79) and its gradient.
+
+    ``smoothing``: LabelSmoothCrossEntropyLoss (reference modules.py:86-101): target weight 1-s, s/(C-1) on the other classes.
+    ``only_incorrect``: IncorrectCrossEntropyLoss (modules.py:104-119): samples the model already classifies correctly contribute
+    zero loss (and gradient); the mean still runs over all samples."""
+    n, classes = logits.shape
     m = logits.max(dim=1, keepdim=True).values
     z = logits - m
     lse = z.exp().sum(dim=1, keepdim=True).log()
     logp = z - lse
-    loss = -logp[torch.arange(n), labels].mean()
-    dlogits = logp.exp()
-    dlogits[torch.arange(n), labels] -= 1.0
-    dlogits /= n
-    correct = (logits.argmax(dim=-1) == labels).float().sum()  # reference training.py:80
+    weight = torch.full_like(logits, smoothing / (classes - 1.0))
+    weight[torch.arange(n), labels] = 1.0 - smoothing
+    hit = logits.argmax(dim=-1) == labels
+    keep = (~hit).to(logits.dtype) if only_incorrect else torch.ones(n, dtype=logits.dtype)
+    loss = ((-weight * logp).sum(dim=-1) * keep).mean()
+    dlogits = (logp.exp() - weight) * keep[:, None] / n
+    correct = hit.float().sum()  # reference training.py:80
     return loss, correct, dlogits
 
 
@@ -319,7 +325,7 @@ def backward(spec, params, tape, dlogits, q=identity):
 def chunk_gradient(spec, params, buffers, x, y, q=identity, update_bn=True):
     """Restates ``_compute_batched_gradient`` (reference training.py:76-83): fwd, CE, #correct, gradient list."""
     logits, tape = forward(spec, params, buffers, x, q, update_bn, train=True)
-    loss, correct, dlogits = cross_entropy_fwd_bwd(logits, y)
+    loss, correct, dlogits = cross_entropy_fwd_bwd(logits, y, getattr(spec, "label_smoothing", 0.0), getattr(spec, "only_incorrect", False))
     grads = backward(spec, params, tape, dlogits, q)
     return [grads[name] for name in params], loss, correct
 
@@ -609,6 +615,9 @@ def train(spec, state, X, Y, hyp, steps, chunk, scheduler="cosine-decay", warmup
     """Small driver mirroring reference training.py:217-239 + 296-298; mutates ``state`` in place; returns stats."""
     params, buffers = split_state(state)
     momentum = [None] * len(params)
+    # get_loss_fn (reference training.py:391-413): the training loss; evaluate() always uses plain cross entropy (training.py:345)
+    spec.label_smoothing = float(hyp.get("label_smoothing") or 0.0)
+    spec.only_incorrect = hyp.get("loss_modification") == "incorrect-xent"
     sched = LRSchedule(hyp["lr"], scheduler, steps, warmup)
     stats = defaultdict(list)
     ema = hyp.get("evaluate_ema", False)

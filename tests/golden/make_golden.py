@@ -120,6 +120,10 @@ SCENARIOS_A9 = {
                                "hyp.warmup=0", "hyp.optim.weight_decay=0.0", "data.batch_size=64", "hyp.sub_batch=64"], 23),
     "fb_linwd": (128, 16, ["hyp=fb1", "hyp.only_linear_layers_weight_decay=True", "hyp.optim.weight_decay=0.05", "hyp.steps=3", "hyp.warmup=0",
                            "data.batch_size=64", "hyp.sub_batch=64"], 29),
+    "fb_smooth": (128, 16, ["hyp=fb1", "hyp.label_smoothing=0.1", "hyp.steps=2", "hyp.warmup=0", "hyp.grad_reg.block_strength=0.5",
+                            "data.batch_size=64", "hyp.sub_batch=64"], 31),
+    "fb_incorrect": (128, 16, ["hyp=fbclip", "hyp.label_smoothing=0.05", "hyp.loss_modification=incorrect-xent", "hyp.steps=3", "hyp.warmup=0",
+                               "data.batch_size=64", "hyp.sub_batch=64"], 33),
     "fb_tta": (128, 16, ["hyp=fb1", "hyp.test_time_flips=True", "hyp.steps=2", "hyp.warmup=0", "data.batch_size=64", "hyp.sub_batch=64"], 27),
     "fb_ema": (128, 16, ["hyp=fb1", "hyp.evaluate_ema=True", "hyp.eval_ema_momentum=0.6", "hyp.steps=3", "hyp.warmup=0", "data.batch_size=64",
                          "hyp.sub_batch=64"], 25),

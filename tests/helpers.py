@@ -27,7 +27,8 @@ def hyp_from_cfg(cfg):
                 acc_strength=cfg.hyp.grad_reg.acc_strength, optim_modification=dict(cfg.hyp.optim_modification),
                 grad_clip_norm=cfg.hyp.grad_clip_norm, norm_bias=dict(cfg.hyp.norm_bias), evaluate_ema=cfg.hyp.evaluate_ema,
                 eval_ema_momentum=cfg.hyp.eval_ema_momentum, test_time_flips=cfg.hyp.test_time_flips,
-                only_linear_layers_weight_decay=cfg.hyp.only_linear_layers_weight_decay)
+                only_linear_layers_weight_decay=cfg.hyp.only_linear_layers_weight_decay, label_smoothing=cfg.hyp.label_smoothing,
+                loss_modification=cfg.hyp.loss_modification)
 
 
 def rel_err(a, b):

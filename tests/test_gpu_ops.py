@@ -282,7 +282,7 @@ def test_pools_and_head(dtype):
     loss, correct = torch.empty(groups, device="cuda"), torch.empty(groups, device="cuda")
     boff = classes * C
     lib.call("fb_head_loss", feat.data_ptr(), thd.data_ptr(), thd.data_ptr() + 4 * boff, P, lab.data_ptr(), logits.data_ptr(),
-             dlogits.data_ptr(), loss.data_ptr(), correct.data_ptr(), groups, ipg, C, classes)
+             dlogits.data_ptr(), loss.data_ptr(), correct.data_ptr(), groups, ipg, C, classes, 0.0, 0)
     gout = torch.zeros(groups, P, device="cuda")
     d_a = torch.empty(n, hw, hw, C, dtype=dtype, device="cuda")
     lib.call("fb_head_bwd", feat.data_ptr(), dlogits.data_ptr(), thd.data_ptr(), P, gout.data_ptr(), gout.data_ptr() + 4 * boff, P,
@@ -525,3 +525,36 @@ def test_engine_per_tensor_weight_decay_matches_torch_sgd():
     got = eng.theta.cpu()
     for name, p in zip(eng.plan.param_names, model.parameters()):
         assert torch.allclose(eng._unflatten(got, name), p.detach(), rtol=1e-6, atol=1e-7), name
+
+
+@pytest.mark.parametrize("smoothing,only_incorrect", [(0.1, 0), (0.0, 1), (0.05, 1)])
+def test_head_loss_variants(smoothing, only_incorrect):
+    """fb_head_loss with the loss functions of get_loss_fn (reference training.py:391-413, modules.py:86-119) vs autograd on the
+    reference formulas."""
+    lib = _lib()
+    torch.manual_seed(13)
+    groups, ipg, C, classes = 3, 32, 64, 10
+    n = groups * ipg
+    feat = torch.randn(n, C)
+    W, b = torch.randn(classes, C) * 0.3, torch.randn(classes) * 0.1
+    labels = torch.randint(0, classes, (n,))
+    theta = torch.cat([W.reshape(-1), b])
+    thd, lab, fd = theta.cuda(), labels.cuda(), feat.cuda()
+    logits, dlogits = torch.empty(n, classes, device="cuda"), torch.empty(n, classes, device="cuda")
+    loss, correct = torch.empty(groups, device="cuda"), torch.empty(groups, device="cuda")
+    lib.call("fb_head_loss", fd.data_ptr(), thd.data_ptr(), thd.data_ptr() + 4 * classes * C, 0, lab.data_ptr(), logits.data_ptr(),
+             dlogits.data_ptr(), loss.data_ptr(), correct.data_ptr(), groups, ipg, C, classes, smoothing, only_incorrect)
+    for g in range(groups):
+        z = (feat[g * ipg:(g + 1) * ipg].double() @ W.double().t() + b.double()).requires_grad_(True)
+        y = labels[g * ipg:(g + 1) * ipg]
+        log_prob = torch.nn.functional.log_softmax(z, dim=-1)
+        weight = torch.ones_like(z) * smoothing / (classes - 1.0)
+        weight.scatter_(-1, y.unsqueeze(-1), 1.0 - smoothing)
+        per_sample = (-weight * log_prob).sum(dim=-1)
+        if only_incorrect:
+            per_sample = per_sample * (1 - (z.argmax(dim=1) == y).double())
+        ref = per_sample.mean()
+        ref.backward()
+        assert abs(float(loss[g]) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+        assert rel(dlogits[g * ipg:(g + 1) * ipg].cpu(), z.grad) < 1e-5
+        assert float(correct[g]) == float((z.argmax(dim=1) == y).sum())

@@ -111,7 +111,8 @@ def test_reference_fp32_noise_floor_on_record(golden):
 TRAIN_CASES = ["fb_plain", "fb_gradreg", "fb_clip_warm", "fb_gradreg_c32", "fb_central", "fb_legacy",
                "fb_acc", "fb_acc_central",      # acc_strength pre-pass (scenarios_extra.npz)
                "fb_sam", "fb_sam_gradreg", "fb_lars", "fb_larc",     # optimizer wrappers around the closure (scenarios_n4.npz)
-               "fb_clip_inf", "fb_normbias1", "fb_normbias2", "fb_ema", "fb_tta", "fb_linwd"]   # L-inf clip, norm bias, EMA / mirrored evaluation (scenarios_a9.npz)
+               "fb_clip_inf", "fb_normbias1", "fb_normbias2", "fb_ema", "fb_tta", "fb_linwd",
+               "fb_smooth", "fb_incorrect"]     # label smoothing / incorrect-xent loss (a12); L-inf clip, norm bias, EMA / mirrored evaluation (scenarios_a9.npz)
 
 
 @pytest.mark.parametrize("name", TRAIN_CASES)
