@@ -117,6 +117,25 @@ def combine_running_stats(r0, r_local, plan, updates_per_chunk, momentum=0.1, gr
     return out
 
 
+def replicated_reduce(trainer, loss_k, correct_k, sq_k):
+    """The exchange for the options that need the WHOLE averaged gradient on every rank (SAM's ascent step, the norm bias, the
+    L-infinity clip, per-tensor weight decay): local running mean x K_r/K -> ONE all-reduce(SUM) = the exact global mean, replicated;
+    BN running statistics recombined, per-chunk statistics gathered.  The caller then continues exactly like the 1-process step (the
+    update is replicated: 45 MB per pass, nothing next to the gradient evaluation)."""
+    from .lib import call
+    eng, hyp, plan = trainer.engine, trainer.cfg.hyp, trainer.shard
+    call("fb_mt_scale", eng.avg.data_ptr(), eng.avg.numel(), float(plan.count / plan.n_chunks))
+    dist.all_reduce(eng.avg)
+    passes = 1 + (0 if hyp.grad_reg.block_strength == 0 else (2 if hyp.grad_reg.implementation == "central-differences" else 1))
+    r_local = torch.stack([eng.running_mean, eng.running_var])
+    combined = combine_running_stats(trainer._running0, r_local, plan, passes)
+    eng.running_mean.copy_(combined[0])
+    eng.running_var.copy_(combined[1])
+    eng.num_batches_tracked += (plan.n_chunks - plan.count) * passes
+    gathered = all_gather_chunk_stats(torch.stack([loss_k, correct_k, sq_k]), plan)
+    return gathered[0], gathered[1], gathered[2]
+
+
 def sharded_update(trainer, loss_k, correct_k, sq_k, lr, weight_decay=None):
     """Product wiring of the above for ``FullBatchTrainer`` (HIP kernels as ShardOps).  ``weight_decay`` overrides hyp.optim's (the
     LARS / LARC wrappers step without it)."""

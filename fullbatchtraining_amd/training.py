@@ -260,19 +260,12 @@ def _check_scope(cfg):
                                       "(other BN batches than the main loop)")
         if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             raise NotImplementedError("grad_reg.acc_strength in the sharded path")
-    if hyp.optim_modification.name == "SAM" and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-        raise NotImplementedError("optim_modification=SAM in the sharded path")
     if hyp.batch_clip is not None:
         raise NotImplementedError("hyp.batch_clip: the reference's own full-batch loop fails on it (NameError in _record_stats)")
     if hyp.grad_noise["additive"] is not None or hyp.grad_noise["multiplicative"] is not None:
         raise NotImplementedError("grad_noise draws from the reference's per-tensor RNG stream; not reproducible on the arena")
     if hyp.grad_clip is not None and float(hyp.grad_clip_norm) not in (2.0, float("inf")):
         raise NotImplementedError("grad_clip_norm: the global L2 and L-infinity clips are implemented")
-    sharded = torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
-    if sharded and hyp.only_linear_layers_weight_decay:
-        raise NotImplementedError("only_linear_layers_weight_decay in the sharded path (per-tensor weight decay across shard boundaries)")
-    if sharded and (hyp.norm_bias.strength > 0 or (hyp.grad_clip is not None and float(hyp.grad_clip_norm) != 2.0)):
-        raise NotImplementedError("norm_bias / L-infinity clip in the sharded path")
     if hyp.shuffle:
         raise NotImplementedError("hyp.shuffle=True changes chunk composition every step; resident data is sequential")
 
@@ -392,8 +385,20 @@ class FullBatchTrainer:
                 self._pre_sqnorm = eng.norms2[0:1].clone()
             return out
 
+        # more than one rank: the plain step shards the update (reduce-scatter, shard-local clip + SGD, all-gather); the options that
+        # need the whole averaged gradient on every rank all-reduce it instead and then run the 1-process code below, replicated
+        replicated = self.world > 1 and (mod == "SAM" or hyp.norm_bias.strength > 0 or hyp.only_linear_layers_weight_decay
+                                         or (hyp.grad_clip is not None and float(hyp.grad_clip_norm) == float("inf")))
+        if replicated:
+            from .parallel import replicated_reduce
+            local_closure = closure
+
+            def closure():                       # noqa: F811  (the closure of the replicated path includes the exchange)
+                self._running0 = torch.stack([eng.running_mean, eng.running_var]).clone()
+                return replicated_reduce(self, *local_closure())
+
         loss_k, correct_k, sq_k = closure()
-        if self.world > 1:
+        if self.world > 1 and not replicated:
             from .parallel import sharded_update
             loss_k, correct_k, sq_k = sharded_update(self, loss_k, correct_k, sq_k, lr,
                                                     weight_decay=0.0 if mod in ("LARS", "LARC") else None)

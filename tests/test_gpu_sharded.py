@@ -18,6 +18,10 @@ OVERRIDES = ["hyp=fbclip", "hyp.steps=3", "hyp.warmup=1", "data.batch_size=32", 
 N, PIXELS, SEED = 7 * 32, 16, 11       # 7 chunks: ranks own 4 and 3
 
 
+OPTIONS = ["hyp/optim_modification=SAM", "hyp.grad_clip_norm=inf", "hyp.grad_clip=0.02", "hyp.only_linear_layers_weight_decay=True",
+           "hyp.norm_bias.strength=1e-3", "hyp.norm_bias.norm_type=2", "hyp.norm_bias.bias=50"]
+
+
 def _run(rank, world, port, out_dir, grad_reg):
     import sys
     sys.path.insert(0, REPO)
@@ -27,7 +31,7 @@ def _run(rank, world, port, out_dir, grad_reg):
     from tests.helpers import make_data
 
     torch.cuda.set_device(0)
-    over = list(OVERRIDES) + (["hyp.grad_reg.block_strength=0.5"] if grad_reg else [])
+    over = list(OVERRIDES) + (["hyp.grad_reg.block_strength=0.5"] if grad_reg is True else (OPTIONS if grad_reg == "options" else []))
     if world > 1:
         torch.distributed.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
         over.append("impl/setup=distributed")
@@ -50,8 +54,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("grad_reg", [False, True])
+@pytest.mark.parametrize("grad_reg", [False, True, "options"])
 def test_two_rank_run_equals_single_process(tmp_path, grad_reg):
+    """plain step and regulariser: sharded update (reduce-scatter / all-gather); "options": SAM + L-infinity clip + norm bias +
+    per-tensor weight decay, which all-reduce the gradient and replicate the 1-process update."""
     out = str(tmp_path)
     mp.spawn(_run, args=(1, 0, out, grad_reg), nprocs=1, join=True)
     mp.spawn(_run, args=(2, _free_port(), out, grad_reg), nprocs=2, join=True)
@@ -59,11 +65,11 @@ def test_two_rank_run_equals_single_process(tmp_path, grad_reg):
     for r in range(2):
         got = torch.load(os.path.join(out, f"w2_r{r}.pt"))
         for key in ("train_loss", "train_acc", "param_norm", "grad_norm", "full_loss", "preclip_gradnorm", "clipped_step"):
-            assert np.allclose(got["stats"][key], ref["stats"][key], rtol=2e-4 if not grad_reg else 5e-3, atol=1e-6), (key, got["stats"][key], ref["stats"][key])
+            assert np.allclose(got["stats"][key], ref["stats"][key], rtol=2e-4 if grad_reg is False else 5e-3, atol=1e-6), (key, got["stats"][key], ref["stats"][key])
         for k in range(7):
             # steps 1-2 agree to the bit; from step 3 on the parameters differ in the last bits (the ranks sum the full-batch
             # gradient in a different order) and a chunk gradient amplifies that to ~1e-4 (fp32 noise floor, cf. test_gpu_training)
-            assert np.allclose(got["stats"][f"grad_norm_train_{k}"], ref["stats"][f"grad_norm_train_{k}"], rtol=1e-3 if not grad_reg else 5e-3), (
+            assert np.allclose(got["stats"][f"grad_norm_train_{k}"], ref["stats"][f"grad_norm_train_{k}"], rtol=1e-3 if grad_reg is False else 5e-3), (
                 k, got["stats"][f"grad_norm_train_{k}"], ref["stats"][f"grad_norm_train_{k}"])
         for name, t in ref["state"].items():
             if t.is_floating_point():
@@ -71,6 +77,6 @@ def test_two_rank_run_equals_single_process(tmp_path, grad_reg):
                 # BN shifts / running means are ~1e-3 after three steps and sit on the fp32 noise floor of the cancelling
                 # chunk-gradient sums (cf. test_gpu_training): judge them on the scale of a typical parameter (2e-2)
                 scale = max(float(t.abs().max()), 2e-2)
-                assert float((got["state"][name] - t).abs().max()) < (1e-3 if not grad_reg else 1e-2) * scale + 1e-6, name   # fp32 chunk-gradient noise (order of sums differs)
+                assert float((got["state"][name] - t).abs().max()) < (1e-3 if grad_reg is False else 1e-2) * scale + 1e-6, name   # fp32 chunk-gradient noise (order of sums differs)
             else:
                 assert torch.equal(got["state"][name], t), name
