@@ -607,11 +607,13 @@ class Engine:
 
     # --------------------------------------------------------------------------------------- full-batch gradient + step --
     def full_gradient(self, patches, labels, lr, block_strength=0.0, eps=1e-2, implementation="forward-differences",
-                      chunk_ids=None, counter0=0, acc_strength=0.0):
+                      chunk_ids=None, counter0=0, acc_strength=0.0, after_pre_pass=None):
         """Accumulate the regularised gradient over chunks (reference training.py:144-174) into ``self.avg``.
 
         ``patches``/``labels`` hold the whole resident dataset; chunk k = rows [k*chunk, (k+1)*chunk).  ``chunk_ids``
         must be a contiguous range (this rank's shard).  Returns device tensors (loss_k, correct_k, n_k) for the chunks.
+        ``after_pre_pass``: called once ``self.pre`` (the local mean of the ``acc_strength`` pre-pass) is complete -- the multi-GPU
+        path turns it into the global mean there.
         """
         chunk, P, G = self.chunk, self.plan.P, self.G
         n_chunks = patches.shape[0] // chunk if chunk_ids is None else len(chunk_ids)
@@ -647,6 +649,8 @@ class Engine:
                      self.var_tab.data_ptr(), 1, self.G * self.plan.ch_total, self.unbias.data_ptr(), g_n, self.plan.ch_total, BN_MOMENTUM)
                 self.num_batches_tracked += g_n
                 done += g_n
+            if after_pre_pass is not None:
+                after_pre_pass()
         done = 0
         while done < n_chunks:
             g_n = min(G, n_chunks - done)

@@ -117,6 +117,28 @@ def combine_running_stats(r0, r_local, plan, updates_per_chunk, momentum=0.1, gr
     return out
 
 
+def bn_updates_per_chunk(hyp):
+    """BN running-statistic updates per chunk in the main loop: the base pass plus the finite-difference passes (which run when
+    either regulariser strength is non-zero: reference modules.py:150-152)."""
+    fd = hyp.grad_reg.block_strength != 0 or hyp.grad_reg.acc_strength != 0
+    return 1 + (0 if not fd else (2 if hyp.grad_reg.implementation == "central-differences" else 1))
+
+
+def reduce_pre_pass(trainer):
+    """``grad_reg.acc_strength`` with several ranks: the pre-pass mean over the local chunks (``engine.pre``) becomes the global mean
+    (x K_r/K, one all-reduce) before the first chunk is regularised; its BN updates (one per chunk, all before the main loop's)
+    are recombined on their own, and the main loop's recombination starts from the result."""
+    from .lib import call
+    eng, plan = trainer.engine, trainer.shard
+    call("fb_mt_scale", eng.pre.data_ptr(), eng.pre.numel(), float(plan.count / plan.n_chunks))
+    dist.all_reduce(eng.pre)
+    combined = combine_running_stats(trainer._running0, torch.stack([eng.running_mean, eng.running_var]), plan, 1)
+    eng.running_mean.copy_(combined[0])
+    eng.running_var.copy_(combined[1])
+    eng.num_batches_tracked += plan.n_chunks - plan.count
+    trainer._running0 = combined.clone()
+
+
 def replicated_reduce(trainer, loss_k, correct_k, sq_k):
     """The exchange for the options that need the WHOLE averaged gradient on every rank (SAM's ascent step, the norm bias, the
     L-infinity clip, per-tensor weight decay): local running mean x K_r/K -> ONE all-reduce(SUM) = the exact global mean, replicated;
@@ -126,7 +148,7 @@ def replicated_reduce(trainer, loss_k, correct_k, sq_k):
     eng, hyp, plan = trainer.engine, trainer.cfg.hyp, trainer.shard
     call("fb_mt_scale", eng.avg.data_ptr(), eng.avg.numel(), float(plan.count / plan.n_chunks))
     dist.all_reduce(eng.avg)
-    passes = 1 + (0 if hyp.grad_reg.block_strength == 0 else (2 if hyp.grad_reg.implementation == "central-differences" else 1))
+    passes = bn_updates_per_chunk(hyp)
     r_local = torch.stack([eng.running_mean, eng.running_var])
     combined = combine_running_stats(trainer._running0, r_local, plan, passes)
     eng.running_mean.copy_(combined[0])
@@ -162,7 +184,7 @@ def sharded_update(trainer, loss_k, correct_k, sq_k, lr, weight_decay=None):
     eng.norms2[0] = gnorm2
     eng.norms2[1] = pnorm2
     # BN running statistics: recombine the rank-local EMAs
-    passes = 1 + (0 if hyp.grad_reg.block_strength == 0 else (2 if hyp.grad_reg.implementation == "central-differences" else 1))
+    passes = bn_updates_per_chunk(hyp)
     r_local = torch.stack([eng.running_mean, eng.running_var])
     combined = combine_running_stats(trainer._running0, r_local, plan, passes)
     eng.running_mean.copy_(combined[0])

@@ -258,8 +258,6 @@ def _check_scope(cfg):
         if max(cfg.data.batch_size // hyp.sub_batch, 1) != 1:
             raise NotImplementedError("grad_reg.acc_strength with sub_batch < batch_size: the reference's pre-pass runs whole blocks "
                                       "(other BN batches than the main loop)")
-        if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            raise NotImplementedError("grad_reg.acc_strength in the sharded path")
     if hyp.batch_clip is not None:
         raise NotImplementedError("hyp.batch_clip: the reference's own full-batch loop fails on it (NameError in _record_stats)")
     if hyp.grad_noise["additive"] is not None or hyp.grad_noise["multiplicative"] is not None:
@@ -378,7 +376,12 @@ class FullBatchTrainer:
 
         def closure():
             """``gradient_evaluation`` (reference training.py:217-225) up to the clip, which is fused into the consumer of ``eng.avg``."""
-            out = eng.full_gradient(self.patches, self.labels, lr, gr.block_strength, gr.eps, gr.implementation, acc_strength=gr.acc_strength)
+            hook = None
+            if self.world > 1 and gr.acc_strength != 0:
+                from .parallel import reduce_pre_pass
+                hook = lambda: reduce_pre_pass(self)          # noqa: E731
+            out = eng.full_gradient(self.patches, self.labels, lr, gr.block_strength, gr.eps, gr.implementation, acc_strength=gr.acc_strength,
+                                    after_pre_pass=hook)
             self._pre_sqnorm = None
             if gr.acc_strength != 0:             # |pre_grads|^2 for full_loss (reference training.py:98-101)
                 lib.call("fb_mt_norms2", eng.pre.data_ptr(), None, eng.plan.P, eng.norms2.data_ptr(), eng.mt_ws.data_ptr())
