@@ -359,3 +359,41 @@ extern "C" int fb_mt_ema(float* ema, const float* src, int64_t n, float momentum
     FB_CHECK_LAUNCH("fb_mt_ema");
     return FB_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Gradient noise of the closure (reference training.py:212-215) acts on the CLIPPED gradient, so the clip that fb_mt_clip_sgd
+// otherwise fuses is applied in place first (fb_mt_clip_scale), then fb_mt_grad_noise with noise drawn by the host framework's
+// generator (the reference draws torch.randn_like per parameter):
+//   mode 0: grad += strength * noise          (p.grad.add_(a * randn))       two roundings, like the tensor expression
+//   mode 1: grad *= 1 + strength * noise      (p.grad.mul_(1 + m * randn))
+__global__ void mt_clip_scale_kernel(float* __restrict__ grad, long long n, const float* __restrict__ gnorm2, float grad_clip) {
+    const float norm = sqrtf(gnorm2[0]);
+    if (!(norm > grad_clip)) return;
+    const float coef = grad_clip / (norm + 1e-6f);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) grad[i] *= coef;
+}
+extern "C" int fb_mt_clip_scale(float* grad, int64_t n, const float* gnorm2, float grad_clip, void* stream) {
+    if (!grad || !gnorm2) FB_FAIL(FB_ERR_ARG, "fb_mt_clip_scale: null pointer");
+    const int64_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(mt_clip_scale_kernel, dim3((unsigned)(nb < 4096 ? (nb < 1 ? 1 : nb) : 4096)), dim3(256), 0, (hipStream_t)stream, grad, (long long)n,
+                       gnorm2, grad_clip);
+    FB_CHECK_LAUNCH("fb_mt_clip_scale");
+    return FB_OK;
+}
+__global__ void mt_grad_noise_kernel(float* __restrict__ grad, const float* __restrict__ noise, long long n, float strength, int mode) {
+#pragma clang fp contract(off)
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float t = strength * noise[i];
+        if (mode == 0) grad[i] = grad[i] + t;
+        else { const float u = 1.f + t; grad[i] = grad[i] * u; }
+    }
+}
+extern "C" int fb_mt_grad_noise(float* grad, const float* noise, int64_t n, float strength, int32_t mode, void* stream) {
+    if (!grad || !noise) FB_FAIL(FB_ERR_ARG, "fb_mt_grad_noise: null pointer");
+    if (mode != 0 && mode != 1) FB_FAIL(FB_ERR_ARG, "fb_mt_grad_noise: mode %d", mode);
+    const int64_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(mt_grad_noise_kernel, dim3((unsigned)(nb < 4096 ? (nb < 1 ? 1 : nb) : 4096)), dim3(256), 0, (hipStream_t)stream, grad, noise,
+                       (long long)n, strength, mode);
+    FB_CHECK_LAUNCH("fb_mt_grad_noise");
+    return FB_OK;
+}

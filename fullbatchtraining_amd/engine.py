@@ -716,6 +716,17 @@ class Engine:
             self.first_step = first
             self.sgd_step(lr, wd, momentum, dampening, nesterov, grad_clip, lo=self.plan.offsets[name], n=math.prod(self.plan.param_shapes[name]))
 
+    def apply_clip(self, grad_clip):
+        """The clip of ``sgd_step`` applied to ``self.avg`` in place (needed when something acts on the clipped gradient before the
+        update: gradient noise, reference training.py:205-215); uses the norm in ``self.norms2[0]``."""
+        call("fb_mt_clip_scale", self.avg.data_ptr(), self.plan.P, self.norms2.data_ptr(), float(grad_clip))
+
+    def grad_noise(self, noise_tensors, strength, multiplicative):
+        """``p.grad.add_(a * noise)`` / ``p.grad.mul_(1 + m * noise)`` (reference training.py:212-215) on the averaged gradient;
+        ``noise_tensors``: one tensor per parameter in ``model.parameters()`` layout (the caller draws them), or the flat arena vector."""
+        flat = noise_tensors if torch.is_tensor(noise_tensors) else self.flatten([t.detach() for t in noise_tensors])
+        call("fb_mt_grad_noise", self.avg.data_ptr(), flat.data_ptr(), self.plan.P, float(strength), 1 if multiplicative else 0)
+
     def clip_norm_inf(self):
         """``hyp.grad_clip_norm=inf`` (reference training.py:199-200): put (max|avg|)^2 into the clip-norm slot ``self.norms2[0]``."""
         call("fb_mt_absmax2", self.avg.data_ptr(), self.plan.P, self.norms2.data_ptr(), self.mt_ws.data_ptr())

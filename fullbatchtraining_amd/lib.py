@@ -65,6 +65,8 @@ _SIGS = {
     "fb_mt_absmax2": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p],
     "fb_mt_norm_bias": [c_void_p, c_void_p, c_i64, c_void_p, c_float, c_float, c_int, c_void_p],
     "fb_mt_ema": [c_void_p, c_void_p, c_i64, c_float, c_float, c_void_p],
+    "fb_mt_clip_scale": [c_void_p, c_i64, c_void_p, c_float, c_void_p],
+    "fb_mt_grad_noise": [c_void_p, c_void_p, c_i64, c_float, c_int, c_void_p],
 }
 EXPORTS = tuple(_SIGS) + ("fb_last_error_string", "fb_abi_version", "fb_profile_enable", "fb_profile_read", "fb_ws_conv_stat_floats",
                           "fb_ws_wgrad_slab_floats", "fb_ws_bn_partial_floats", "fb_ws_mt_floats", "fb_bn_bwd_reduce_rows", "fb_conv_masked_addend_supported")

@@ -5,7 +5,7 @@ Mirrors, for ``hyp.train_stochastic=False``:
   gradient_evaluation        :226-234   (closure: accumulate, stats, clip)          -> Engine.full_gradient / sgd_step
   _accumulate_full_gradient  :121-185
   _record_stats              :85-119    (same keys, same formulas)
-  _modify_gradient_params    :187-215   (norm bias, global L2 / L-infinity clip; gradient noise -> NotImplementedError)
+  _modify_gradient_params    :187-215   (norm bias, global L2 / L-infinity clip, gradient noise)
   evaluate                   :343-388
   get_loss_fn                :391-413   (cross entropy, label smoothing, incorrect-xent: fused into the head kernel)
   optim_interface            fullbatch/training/optimizers.py:10-93 (Gradient Descent / line_search none; cosine-*, warm-up)
@@ -260,8 +260,6 @@ def _check_scope(cfg):
                                       "(other BN batches than the main loop)")
     if hyp.batch_clip is not None:
         raise NotImplementedError("hyp.batch_clip: the reference's own full-batch loop fails on it (NameError in _record_stats)")
-    if hyp.grad_noise["additive"] is not None or hyp.grad_noise["multiplicative"] is not None:
-        raise NotImplementedError("grad_noise draws from the reference's per-tensor RNG stream; not reproducible on the arena")
     if hyp.grad_clip is not None and float(hyp.grad_clip_norm) not in (2.0, float("inf")):
         raise NotImplementedError("grad_clip_norm: the global L2 and L-infinity clips are implemented")
     if hyp.shuffle:
@@ -390,7 +388,8 @@ class FullBatchTrainer:
 
         # more than one rank: the plain step shards the update (reduce-scatter, shard-local clip + SGD, all-gather); the options that
         # need the whole averaged gradient on every rank all-reduce it instead and then run the 1-process code below, replicated
-        replicated = self.world > 1 and (mod == "SAM" or hyp.norm_bias.strength > 0 or hyp.only_linear_layers_weight_decay
+        noisy = hyp.grad_noise["additive"] is not None or hyp.grad_noise["multiplicative"] is not None
+        replicated = self.world > 1 and (mod == "SAM" or hyp.norm_bias.strength > 0 or hyp.only_linear_layers_weight_decay or noisy
                                          or (hyp.grad_clip is not None and float(hyp.grad_clip_norm) == float("inf")))
         if replicated:
             from .parallel import replicated_reduce
@@ -417,32 +416,52 @@ class FullBatchTrainer:
                     eng.grad_and_param_sqnorm()
                 if hyp.grad_clip is not None and float(hyp.grad_clip_norm) == float("inf"):
                     eng.clip_norm_inf()
+                if not noisy:
+                    return eng.norms2
+                # gradient noise acts on the clipped gradient (reference training.py:205-215): clip in place, then one randn_like per
+                # parameter and kind, in the reference's order; the statistics keep the pre-clip norm
+                norms = eng.norms2.clone()
+                if hyp.grad_clip is not None:
+                    eng.apply_clip(hyp.grad_clip)
+                for kind in ("additive", "multiplicative"):
+                    if hyp.grad_noise[kind] is not None:
+                        flat = eng.flatten([torch.randn_like(p) for p in self.model.parameters()])
+                        if self.world > 1:       # every rank must add the same noise: rank 0's draw
+                            torch.distributed.broadcast(flat, src=0)
+                        eng.grad_noise(flat, hyp.grad_noise[kind], kind == "multiplicative")
+                return norms
 
-            modify()
+            clip = None if noisy else hyp.grad_clip          # (already applied in place where noise follows it)
+            norms = modify()
             if mod == "SAM":                     # sam.py:84-92: closure, first_step, closure, second_step; stats are recorded twice
-                self._record_stats(loss_k, correct_k, sq_k, eng.norms2, lr, train_time)
-                eng.sam_ascent(self.optimizer.rho, hyp.grad_clip)
+                self._record_stats(loss_k, correct_k, sq_k, norms, lr, train_time)
+                if noisy:
+                    eng.grad_and_param_sqnorm()  # the ascent step is normalised by the norm of the final (clipped, noisy) gradient
+                eng.sam_ascent(self.optimizer.rho, clip)
                 loss_k, correct_k, sq_k = closure()
-                modify()                         # param_norm of the second record is taken at theta + e_w, like the reference's
-                self._record_stats(loss_k, correct_k, sq_k, eng.norms2, lr, train_time)
+                norms = modify()                 # param_norm of the second record is taken at theta + e_w, like the reference's
+                self._record_stats(loss_k, correct_k, sq_k, norms, lr, train_time)
                 eng.sam_restore()
-                self._update(lr)
+                self._update(lr, grad_clip=clip)
                 self.scheduler.step()
                 return
             # LARS / LARC: the wrapper zeroes the weight decay around SGD.step(closure) and nothing else survives the closure (see LARS)
-            self._update(lr, zero_wd=mod in ("LARS", "LARC"))
+            self._update(lr, zero_wd=mod in ("LARS", "LARC"), grad_clip=clip)
+            self._record_stats(loss_k, correct_k, sq_k, norms, lr, train_time)
+            self.scheduler.step()
+            return
         self._record_stats(loss_k, correct_k, sq_k, eng.norms2, lr, train_time)
         self.scheduler.step()
 
-    def _update(self, lr, zero_wd=False):
+    def _update(self, lr, zero_wd=False, grad_clip=None):
         """Clip + Nesterov SGD on the arena; per-tensor weight decay when the optimizer has one param group per tensor
         (``hyp.only_linear_layers_weight_decay``, reference optimizers.py:14-21)."""
         eng, hyp, o = self.engine, self.cfg.hyp, self.cfg.hyp.optim
         if hyp.only_linear_layers_weight_decay and not zero_wd:
             wds = [g["weight_decay"] for g in self.optimizer.param_groups]
-            eng.sgd_step_per_tensor(lr, wds, o.momentum, o.dampening, o.nesterov, hyp.grad_clip)
+            eng.sgd_step_per_tensor(lr, wds, o.momentum, o.dampening, o.nesterov, grad_clip)
         else:
-            eng.sgd_step(lr, 0.0 if zero_wd else o.weight_decay, o.momentum, o.dampening, o.nesterov, hyp.grad_clip)
+            eng.sgd_step(lr, 0.0 if zero_wd else o.weight_decay, o.momentum, o.dampening, o.nesterov, grad_clip)
 
     def _regather_augmented(self):
         """A fresh RandomCrop offset / flip per image and step (the reference draws them in its DataLoader workers once per epoch =

@@ -205,6 +205,11 @@ int fb_mt_sam_restore(float* theta, const float* e_w, int64_t n, void* stream);
 int fb_mt_absmax2(const float* a, int64_t n, float* out, float* ws, void* stream);
 int fb_mt_norm_bias(float* grad, const float* theta, int64_t n, const float* pnorm2, float strength, float bias, int32_t norm_type, void* stream);
 int fb_mt_ema(float* ema, const float* src, int64_t n, float momentum, float one_minus, void* stream);
+/* gradient noise of the closure (training.py:212-215; it acts on the clipped gradient, so the clip is applied in place first):
+ *   fb_mt_clip_scale : grad *= grad_clip / (|grad| + 1e-6) if |grad| > grad_clip   (the in-place form of fb_mt_clip_sgd's clip)
+ *   fb_mt_grad_noise : mode 0: grad += strength * noise ; mode 1: grad *= 1 + strength * noise   (noise drawn by the caller) */
+int fb_mt_clip_scale(float* grad, int64_t n, const float* gnorm2, float grad_clip, void* stream);
+int fb_mt_grad_noise(float* grad, const float* noise, int64_t n, float strength, int32_t mode, void* stream);
 
 #ifdef __cplusplus
 }

@@ -574,6 +574,13 @@ def _gradient_evaluation(spec, params, buffers, X, Y, hyp, lr, stats, chunk, q=i
             stats["clipped_step"].append(1)
         else:
             stats["clipped_step"].append(0)
+    gn = hyp.get("grad_noise") or {}
+    if gn.get("additive") is not None:  # training.py:212-213, Langevin-type noise; one randn_like per parameter, in parameter order
+        for g in avg:
+            g.add_(gn["additive"] * torch.randn_like(g))
+    if gn.get("multiplicative") is not None:  # training.py:214-215
+        for g in avg:
+            g.mul_(1 + gn["multiplicative"] * torch.randn_like(g))
     return avg
 
 

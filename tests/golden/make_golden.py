@@ -25,6 +25,7 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, REPO)
 
 SAMPLE_STRIDE = 997  # every 997th element of each flat tensor is kept verbatim
+NOISE_SEED = 4242
 
 
 def import_reference():
@@ -65,8 +66,11 @@ def loaders(x, y, batch):
     ds = torch.utils.data.TensorDataset(x, y)
     sampler = torch.utils.data.SequentialSampler(ds)
     sampler.set_epoch = lambda *a, **k: None
-    train = torch.utils.data.DataLoader(ds, batch_size=min(batch, len(ds)), sampler=sampler, drop_last=True)
-    valid = torch.utils.data.DataLoader(ds, batch_size=min(batch, len(ds)), shuffle=False, drop_last=False)
+    # the loaders get a generator of their own: a DataLoader iterator draws its base seed at the start of every pass, and with the
+    # default generator that draw would sit between the seeding and the gradient-noise draws of the fb_noise scenario
+    own = torch.Generator().manual_seed(0)
+    train = torch.utils.data.DataLoader(ds, batch_size=min(batch, len(ds)), sampler=sampler, drop_last=True, generator=own)
+    valid = torch.utils.data.DataLoader(ds, batch_size=min(batch, len(ds)), shuffle=False, drop_last=False, generator=own)
     return train, valid
 
 
@@ -124,6 +128,10 @@ SCENARIOS_A9 = {
                             "data.batch_size=64", "hyp.sub_batch=64"], 31),
     "fb_incorrect": (128, 16, ["hyp=fbclip", "hyp.label_smoothing=0.05", "hyp.loss_modification=incorrect-xent", "hyp.steps=3", "hyp.warmup=0",
                                "data.batch_size=64", "hyp.sub_batch=64"], 33),
+    # gradient noise (training.py:212-215) draws torch.randn_like per parameter from the default generator: the generator is seeded
+    # right before train() for scenarios with "noise" in their name (NOISE_SEED), and the consumers of these vectors do the same
+    "fb_noise": (128, 16, ["hyp=fbclip", "hyp.grad_noise.additive=0.01", "hyp.grad_noise.multiplicative=0.1", "hyp.steps=3", "hyp.warmup=0",
+                           "data.batch_size=64", "hyp.sub_batch=64"], 35),
     "fb_tta": (128, 16, ["hyp=fb1", "hyp.test_time_flips=True", "hyp.steps=2", "hyp.warmup=0", "data.batch_size=64", "hyp.sub_batch=64"], 27),
     "fb_ema": (128, 16, ["hyp=fb1", "hyp.evaluate_ema=True", "hyp.eval_ema_momentum=0.6", "hyp.steps=3", "hyp.warmup=0", "data.batch_size=64",
                          "hyp.sub_batch=64"], 25),
@@ -180,6 +188,8 @@ def run_scenario(fullbatch, compose, scen, out, dtype=torch.float):
     per, samp = summarise([v.to(dtype) for v in probe.state_dict().values()])
     out[f"{name}/probe_state_per"], out[f"{name}/probe_state_sample"] = per, samp
 
+    if "noise" in scen:
+        torch.manual_seed(NOISE_SEED)
     stats = fullbatch.training.train(model, trainloader, validloader, setup, cfg)
     keys = sorted(k for k in stats if k != "train_time")
     out[f"{name}/stat_keys"] = np.array(keys)

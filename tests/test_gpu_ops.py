@@ -558,3 +558,26 @@ def test_head_loss_variants(smoothing, only_incorrect):
         assert abs(float(loss[g]) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
         assert rel(dlogits[g * ipg:(g + 1) * ipg].cpu(), z.grad) < 1e-5
         assert float(correct[g]) == float((z.argmax(dim=1) == y).sum())
+
+
+def test_clip_scale_and_grad_noise_kernels():
+    """fb_mt_clip_scale / fb_mt_grad_noise vs the reference's in-place tensor expressions (training.py:205-215), bit for bit."""
+    lib = _lib()
+    torch.manual_seed(17)
+    n = 200_003
+    g, noise = torch.randn(n) * 0.01, torch.randn(n)
+    gd, nd = g.cuda(), noise.cuda()
+    norms2, ws = torch.zeros(2, device="cuda"), torch.zeros(lib.load().fb_ws_mt_floats(1), device="cuda")
+    lib.call("fb_mt_norms2", gd.data_ptr(), None, n, norms2.data_ptr(), ws.data_ptr())
+    lib.call("fb_mt_clip_scale", gd.data_ptr(), n, norms2.data_ptr(), 0.25)
+    norm = norms2[0].sqrt().cpu()
+    ref = g * (0.25 / (norm + 1e-6)) if norm > 0.25 else g.clone()
+    assert torch.equal(gd.cpu(), ref)
+    lib.call("fb_mt_clip_scale", gd.data_ptr(), n, norms2.data_ptr(), 1e6)       # no clip: untouched
+    assert torch.equal(gd.cpu(), ref)
+    lib.call("fb_mt_grad_noise", gd.data_ptr(), nd.data_ptr(), n, 0.01, 0)
+    ref.add_(0.01 * noise)
+    assert torch.equal(gd.cpu(), ref)
+    lib.call("fb_mt_grad_noise", gd.data_ptr(), nd.data_ptr(), n, 0.1, 1)
+    ref.mul_(1 + 0.1 * noise)
+    assert torch.equal(gd.cpu(), ref)

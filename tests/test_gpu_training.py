@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import make_data, rel_err, summarise
+from tests.helpers import NOISE_SEED, make_data, rel_err, summarise
 
 pytestmark = pytest.mark.gpu
 
@@ -29,6 +29,8 @@ def _run(meta, name, extra=(), tmp_path=None, valid_full=False):
     model = construct_model(cfg.model, 3, 10)
     x, y = make_data(sc["n"], sc["pixels"])
     setup = dict(device=torch.device("cuda:0"), dtype=torch.float, memory_format=torch.contiguous_format)
+    if "noise" in name:
+        torch.manual_seed(NOISE_SEED)          # the generator state the reference run drew its gradient noise from
     stats = train(model, (x, y), (x, y) if valid_full else (x[:64], y[:64]), setup, cfg)
     return cfg, model, stats
 
@@ -109,6 +111,25 @@ def test_train_ema_evaluation_matches_reference(golden, tmp_path):
     # the live model (not the EMA) is what train() leaves in the container
     err = rel_err(summarise([v.double() for v in model.state_dict().values()])[1], data[f"{name}@f64/final_sample"])
     assert err < max(10 * rel_err(data[f"{name}/final_sample"], data[f"{name}@f64/final_sample"]), 1e-5)
+
+
+def test_train_gradient_noise_matches_reference(golden, tmp_path):
+    """hyp.grad_noise (reference training.py:212-215): additive + multiplicative noise on the clipped gradient, one randn_like per
+    parameter from the default generator.  The fp32 reference run is the yardstick here (its float64 twin draws float64 noise, a
+    different stream); the float64 pin of the same scenario is in tests/test_oracle_golden.py."""
+    data, meta = golden
+    name = "fb_noise"
+    cfg, model, stats = _run(meta, name, ["impl.engine.chunk_group=2"], tmp_path)
+    for key in ("train_loss", "param_norm", "grad_norm", "full_loss", "preclip_gradnorm", "clipped_step"):
+        r32 = data[f"{name}/stat/{key}"]
+        print(f"{name} {key}: engine {np.array(stats[key])} ref32 {r32}")
+        assert np.allclose(stats[key], r32, rtol=2e-3, atol=1e-6), (key, stats[key], r32)
+    err = rel_err(summarise([v.double() for v in model.state_dict().values()])[1], data[f"{name}/final_sample"])
+    print(f"{name}: final state engine-vs-ref32 {err:.2e}")
+    assert err < 1e-3
+    # the noise is live: the noise-free run of the same configuration ends somewhere else
+    quiet = [o for o in meta["scenarios"][name]["overrides"] if "grad_noise" not in o]
+    assert abs(data[f"{name}/stat/train_loss"][-1] - data["fb_clip_warm/stat/train_loss"][-1]) > 0 and len(quiet) < len(meta["scenarios"][name]["overrides"])
 
 
 def test_train_test_time_flips_matches_reference(golden, tmp_path):

@@ -15,7 +15,7 @@ import torch
 from fullbatchtraining_amd.cfg import compose
 from fullbatchtraining_amd.models import construct_model
 from oracle import fb_oracle as orc
-from tests.helpers import hyp_from_cfg, make_data, rel_err, summarise
+from tests.helpers import NOISE_SEED, hyp_from_cfg, make_data, rel_err, summarise
 
 F64 = torch.float64
 
@@ -112,7 +112,8 @@ TRAIN_CASES = ["fb_plain", "fb_gradreg", "fb_clip_warm", "fb_gradreg_c32", "fb_c
                "fb_acc", "fb_acc_central",      # acc_strength pre-pass (scenarios_extra.npz)
                "fb_sam", "fb_sam_gradreg", "fb_lars", "fb_larc",     # optimizer wrappers around the closure (scenarios_n4.npz)
                "fb_clip_inf", "fb_normbias1", "fb_normbias2", "fb_ema", "fb_tta", "fb_linwd",
-               "fb_smooth", "fb_incorrect"]     # label smoothing / incorrect-xent loss (a12); L-inf clip, norm bias, EMA / mirrored evaluation (scenarios_a9.npz)
+               "fb_smooth", "fb_incorrect",     # label smoothing / incorrect-xent loss (a12)
+               "fb_noise"]                      # additive + multiplicative gradient noise from the seeded default generator; L-inf clip, norm bias, EMA / mirrored evaluation (scenarios_a9.npz)
 
 
 @pytest.mark.parametrize("name", TRAIN_CASES)
@@ -122,6 +123,8 @@ def test_training_float64_pin(golden, name):
     cfg, model, state, x, y = _setup(meta, name, F64)
     spec = orc.Spec(cfg.model.depth)
     chunk = min(cfg.data.batch_size, cfg.hyp.sub_batch)
+    if "noise" in name:
+        torch.manual_seed(NOISE_SEED)
     stats = orc.train(spec, state, x, y, hyp_from_cfg(cfg), cfg.hyp.steps, chunk, cfg.hyp.scheduler, cfg.hyp.warmup, Xv=x, Yv=y,
                       validate_every=1000)       # the generator validates on the training tensors after step 1 and after the last step
     key = f"{name}@f64"
