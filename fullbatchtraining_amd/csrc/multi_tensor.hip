@@ -397,3 +397,38 @@ extern "C" int fb_mt_grad_noise(float* grad, const float* noise, int64_t n, floa
     FB_CHECK_LAUNCH("fb_mt_grad_noise");
     return FB_OK;
 }
+
+// general p-norm clip (reference training.py:201-204: the p-norm of the per-tensor p-norms = (sum |g_i|^p)^(1/p)):
+// out[0] = norm^2, in the slot of the squared L2 norm like fb_mt_absmax2.  Partial sums in float, second stage in double.
+__global__ __launch_bounds__(256) void mt_pnorm_kernel(const float* __restrict__ a, long long n, float p, float* __restrict__ ws) {
+    __shared__ float sm[16];
+    float acc[1] = {0.f};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float x = fabsf(a[i]);
+        acc[0] += p == 1.f ? x : (x > 0.f ? powf(x, p) : 0.f);
+    }
+    block_reduce_sum<1>(acc, sm);
+    if (threadIdx.x == 0) ws[blockIdx.x] = acc[0];
+}
+__global__ void mt_pnorm_finalize_kernel(const float* __restrict__ ws, int nb, double inv_p, float* __restrict__ out) {
+    __shared__ double sm[64];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 64) s += (double)ws[i];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 64; ++i) s += sm[i];
+        const double norm = pow(s, inv_p);
+        out[0] = (float)(norm * norm);
+    }
+}
+extern "C" int fb_mt_pnorm2(const float* a, int64_t n, float p, float* out, float* ws, void* stream) {
+    if (!a || !out || !ws) FB_FAIL(FB_ERR_ARG, "fb_mt_pnorm2: null pointer");
+    if (!(p >= 1.f)) FB_FAIL(FB_ERR_ARG, "fb_mt_pnorm2: p=%g (p >= 1; infinity is fb_mt_absmax2)", (double)p);
+    const int64_t want = (n + 255) / 256;
+    const int nb = (int)(want < 1 ? 1 : (want > FB_MT_BLOCKS ? FB_MT_BLOCKS : want));
+    hipLaunchKernelGGL(mt_pnorm_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, (long long)n, p, ws);
+    hipLaunchKernelGGL(mt_pnorm_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ws, nb, 1.0 / (double)p, out);
+    FB_CHECK_LAUNCH("fb_mt_pnorm2");
+    return FB_OK;
+}

@@ -731,6 +731,10 @@ class Engine:
         """``hyp.grad_clip_norm=inf`` (reference training.py:199-200): put (max|avg|)^2 into the clip-norm slot ``self.norms2[0]``."""
         call("fb_mt_absmax2", self.avg.data_ptr(), self.plan.P, self.norms2.data_ptr(), self.mt_ws.data_ptr())
 
+    def clip_norm_p(self, p):
+        """``hyp.grad_clip_norm=p`` (reference training.py:201-204): (sum |avg_i|^p)^(2/p) into the clip-norm slot."""
+        call("fb_mt_pnorm2", self.avg.data_ptr(), self.plan.P, float(p), self.norms2.data_ptr(), self.mt_ws.data_ptr())
+
     def norm_bias(self, strength, norm_type, bias):
         """External norm bias on the averaged gradient (reference training.py:188-196); ``self.norms2[1]`` must hold |theta|^2.
         One launch per parameter tensor: the constant of norm_type 1 must not land in the arena's alignment padding."""

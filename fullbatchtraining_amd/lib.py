@@ -63,6 +63,7 @@ _SIGS = {
     "fb_mt_sam_ascent": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_float, c_float, c_void_p],
     "fb_mt_sam_restore": [c_void_p, c_void_p, c_i64, c_void_p],
     "fb_mt_absmax2": [c_void_p, c_i64, c_void_p, c_void_p, c_void_p],
+    "fb_mt_pnorm2": [c_void_p, c_i64, c_float, c_void_p, c_void_p, c_void_p],
     "fb_mt_norm_bias": [c_void_p, c_void_p, c_i64, c_void_p, c_float, c_float, c_int, c_void_p],
     "fb_mt_ema": [c_void_p, c_void_p, c_i64, c_float, c_float, c_void_p],
     "fb_mt_clip_scale": [c_void_p, c_i64, c_void_p, c_float, c_void_p],

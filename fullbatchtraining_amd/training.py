@@ -260,8 +260,8 @@ def _check_scope(cfg):
                                       "(other BN batches than the main loop)")
     if hyp.batch_clip is not None:
         raise NotImplementedError("hyp.batch_clip: the reference's own full-batch loop fails on it (NameError in _record_stats)")
-    if hyp.grad_clip is not None and float(hyp.grad_clip_norm) not in (2.0, float("inf")):
-        raise NotImplementedError("grad_clip_norm: the global L2 and L-infinity clips are implemented")
+    if hyp.grad_clip is not None and not float(hyp.grad_clip_norm) >= 1.0:
+        raise NotImplementedError("grad_clip_norm must be a p-norm with p >= 1 (or inf)")
     if hyp.shuffle:
         raise NotImplementedError("hyp.shuffle=True changes chunk composition every step; resident data is sequential")
 
@@ -390,7 +390,7 @@ class FullBatchTrainer:
         # need the whole averaged gradient on every rank all-reduce it instead and then run the 1-process code below, replicated
         noisy = hyp.grad_noise["additive"] is not None or hyp.grad_noise["multiplicative"] is not None
         replicated = self.world > 1 and (mod == "SAM" or hyp.norm_bias.strength > 0 or hyp.only_linear_layers_weight_decay or noisy
-                                         or (hyp.grad_clip is not None and float(hyp.grad_clip_norm) == float("inf")))
+                                         or (hyp.grad_clip is not None and float(hyp.grad_clip_norm) != 2.0))
         if replicated:
             from .parallel import replicated_reduce
             local_closure = closure
@@ -416,6 +416,8 @@ class FullBatchTrainer:
                     eng.grad_and_param_sqnorm()
                 if hyp.grad_clip is not None and float(hyp.grad_clip_norm) == float("inf"):
                     eng.clip_norm_inf()
+                elif hyp.grad_clip is not None and float(hyp.grad_clip_norm) != 2.0:
+                    eng.clip_norm_p(float(hyp.grad_clip_norm))
                 if not noisy:
                     return eng.norms2
                 # gradient noise acts on the clipped gradient (reference training.py:205-215): clip in place, then one randn_like per

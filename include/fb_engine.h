@@ -203,6 +203,8 @@ int fb_mt_sam_restore(float* theta, const float* e_w, int64_t n, void* stream);
  *   fb_mt_norm_bias: external norm bias on ONE parameter tensor (training.py:188-196); pnorm2 = device |theta|^2 of all parameters
  * and the model EMA used for evaluation (training/utils.py:22-29): ema = momentum*ema + one_minus*src. */
 int fb_mt_absmax2(const float* a, int64_t n, float* out, float* ws, void* stream);
+/* out[0] = ((sum |a_i|^p)^(1/p))^2 -- the clip norm for grad_clip_norm = p other than 2 / inf (training.py:201-204) */
+int fb_mt_pnorm2(const float* a, int64_t n, float p, float* out, float* ws, void* stream);
 int fb_mt_norm_bias(float* grad, const float* theta, int64_t n, const float* pnorm2, float strength, float bias, int32_t norm_type, void* stream);
 int fb_mt_ema(float* ema, const float* src, int64_t n, float momentum, float one_minus, void* stream);
 /* gradient noise of the closure (training.py:212-215; it acts on the clipped gradient, so the clip is applied in place first):

@@ -565,8 +565,9 @@ def _gradient_evaluation(spec, params, buffers, X, Y, hyp, lr, stats, chunk, q=i
     if hyp.get("grad_clip") is not None:
         if float(hyp.get("grad_clip_norm", 2)) == float("inf"):  # training.py:199-200
             grad_norm = max(g.abs().max() for g in avg)
-        else:
-            grad_norm = torch.norm(torch.stack([torch.norm(g, 2) for g in avg]), 2)
+        else:  # training.py:201-204: the p-norm of the per-tensor p-norms
+            pn = float(hyp.get("grad_clip_norm", 2))
+            grad_norm = torch.norm(torch.stack([torch.norm(g, pn) for g in avg]), pn)
         stats["preclip_gradnorm"].append(float(grad_norm))
         if grad_norm > hyp["grad_clip"]:
             for g in avg:

@@ -132,6 +132,8 @@ SCENARIOS_A9 = {
     # right before train() for scenarios with "noise" in their name (NOISE_SEED), and the consumers of these vectors do the same
     "fb_noise": (128, 16, ["hyp=fbclip", "hyp.grad_noise.additive=0.01", "hyp.grad_noise.multiplicative=0.1", "hyp.steps=3", "hyp.warmup=0",
                            "data.batch_size=64", "hyp.sub_batch=64"], 35),
+    "fb_clip_l1": (128, 16, ["hyp=fbclip", "hyp.grad_clip=50.0", "hyp.grad_clip_norm=1", "hyp.steps=3", "hyp.warmup=0", "data.batch_size=64",
+                             "hyp.sub_batch=64"], 37),
     "fb_tta": (128, 16, ["hyp=fb1", "hyp.test_time_flips=True", "hyp.steps=2", "hyp.warmup=0", "data.batch_size=64", "hyp.sub_batch=64"], 27),
     "fb_ema": (128, 16, ["hyp=fb1", "hyp.evaluate_ema=True", "hyp.eval_ema_momentum=0.6", "hyp.steps=3", "hyp.warmup=0", "data.batch_size=64",
                          "hyp.sub_batch=64"], 25),

@@ -107,8 +107,8 @@ def test_out_of_scope_options_raise():
     with pytest.raises(NotImplementedError):
         _check_scope(compose(["hyp=fb1", "hyp.batch_clip=1.0"]))                              # broken in the reference itself
     with pytest.raises(NotImplementedError):
-        _check_scope(compose(["hyp=fbclip", "hyp.grad_clip_norm=1"]))                         # L2 and L-infinity clips only
-    for ok in (["hyp=fbclip", "hyp.grad_clip_norm=inf"], ["hyp=fb1", "hyp.norm_bias.strength=0.1"], ["hyp=fb1", "hyp.evaluate_ema=True"],
+        _check_scope(compose(["hyp=fbclip", "hyp.grad_clip_norm=0.5"]))                       # p-norms with p >= 1 (or inf)
+    for ok in (["hyp=fbclip", "hyp.grad_clip_norm=inf"], ["hyp=fbclip", "hyp.grad_clip_norm=1"], ["hyp=fb1", "hyp.norm_bias.strength=0.1"], ["hyp=fb1", "hyp.evaluate_ema=True"],
                ["hyp=fb1", "hyp/optim_modification=SAM"], ["hyp=fb1", "hyp/optim_modification=LARC"], ["hyp=fb1", "hyp.grad_noise.additive=0.1"]):
         _check_scope(compose(ok))
     cfg = compose(["hyp=fb1"])

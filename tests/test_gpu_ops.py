@@ -459,6 +459,9 @@ def test_absmax_norm_bias_and_ema_kernels():
     out, ws = torch.zeros(2, device="cuda"), torch.zeros(lib.load().fb_ws_mt_floats(1), device="cuda")
     lib.call("fb_mt_absmax2", gd.data_ptr(), n, out.data_ptr(), ws.data_ptr())
     assert float(out[0]) == 0.75 * 0.75
+    for pnorm in (1.0, 3.0):
+        lib.call("fb_mt_pnorm2", gd.data_ptr(), n, pnorm, out.data_ptr(), ws.data_ptr())
+        assert abs(float(out[0].sqrt()) - float(torch.norm(g.double(), pnorm))) < 1e-5 * float(torch.norm(g.double(), pnorm))
     pn2 = torch.tensor([float(theta.pow(2).sum())], device="cuda")
     for norm_type, bias in ((1, 10.0), (1, 1e4), (2, 70.0)):
         gd = g.cuda()

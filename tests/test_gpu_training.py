@@ -49,7 +49,8 @@ def _run(meta, name, extra=(), tmp_path=None, valid_full=False):
                                             # test_engine_per_tensor_weight_decay_matches_torch_sgd and in the float64 oracle pin)
                                             ("fb_linwd", 3e-3, 2),
                                             # loss functions of get_loss_fn (a12): label smoothing (with the regulariser), incorrect-xent
-                                            ("fb_smooth", 8e-3, 2), ("fb_incorrect", 1e-2, 1)])
+                                            ("fb_smooth", 8e-3, 2), ("fb_incorrect", 1e-2, 1),
+                                            ("fb_clip_l1", 2e-4, 2)])                                # p-norm clip, p = 1
 def test_train_matches_reference_run_f32(golden, name, tol, group, tmp_path):
     data, meta = golden
     cfg, model, stats = _run(meta, name, [f"impl.engine.chunk_group={group}"], tmp_path)
