@@ -19,7 +19,7 @@ N, PIXELS, SEED = 7 * 32, 16, 11       # 7 chunks: ranks own 4 and 3
 
 
 OPTIONS = ["hyp/optim_modification=SAM", "hyp.grad_clip_norm=inf", "hyp.grad_clip=0.02", "hyp.only_linear_layers_weight_decay=True",
-           "hyp.norm_bias.strength=1e-3", "hyp.norm_bias.norm_type=2", "hyp.norm_bias.bias=50"]
+           "hyp.norm_bias.strength=1e-3", "hyp.norm_bias.norm_type=2", "hyp.norm_bias.bias=50", "hyp.grad_noise.additive=1e-3"]
 
 
 def _run(rank, world, port, out_dir, grad_reg):
@@ -59,7 +59,7 @@ def _free_port():
 @pytest.mark.parametrize("grad_reg", [False, True, "options", "acc"])
 def test_two_rank_run_equals_single_process(tmp_path, grad_reg):
     """plain step and regulariser: sharded update (reduce-scatter / all-gather); "options": SAM + L-infinity clip + norm bias +
-    per-tensor weight decay, which all-reduce the gradient and replicate the 1-process update; "acc": the acc_strength pre-pass
+    per-tensor weight decay + gradient noise (rank 0's draw, broadcast), which all-reduce the gradient and replicate the 1-process update; "acc": the acc_strength pre-pass
     (its own all-reduce and BN recombination inside the closure)."""
     out = str(tmp_path)
     mp.spawn(_run, args=(1, 0, out, grad_reg), nprocs=1, join=True)
