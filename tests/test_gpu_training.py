@@ -166,6 +166,34 @@ def test_train_bf16_tracks_fp32_statistics(golden, tmp_path):
     assert abs(stats["train_acc"][0] - data["fb_plain@f64/stat/train_acc"][0]) < 0.02
 
 
+@pytest.mark.parametrize("mixed", [False, True])
+def test_full_batch_descent_fits_a_learnable_dataset(mixed, tmp_path):
+    """End-to-end sanity beyond the 2-3 steps of the parity scenarios: 25 full-batch steps (clip + warm-up + Nesterov momentum, the
+    fbclip recipe at a small scale) on a dataset whose labels are a function of the inputs.  f32 and bf16 both fit it, and the bf16
+    trajectory stays near the f32 one."""
+    from fullbatchtraining_amd.cfg import compose
+    from fullbatchtraining_amd.models import construct_model
+    from fullbatchtraining_amd.training import train
+
+    gen = torch.Generator().manual_seed(7)
+    n, pixels = 512, 16
+    protos = torch.randn(10, 3, pixels, pixels, generator=gen)
+    y = torch.randint(0, 10, (n,), generator=gen)
+    x = protos[y] + 0.5 * torch.randn(n, 3, pixels, pixels, generator=gen)      # class prototype + noise
+    cfg = compose(["hyp=fbclip", "hyp.steps=25", "hyp.warmup=5", "hyp.optim.lr=0.1", "hyp.grad_clip=1.0", "data.batch_size=128", "hyp.sub_batch=128",
+                   f"data.pixels={pixels}", "impl.validate_every_nth_step=1000", f"impl.mixed_precision={mixed}", "impl.engine.chunk_group=4"],
+                  original_cwd=str(tmp_path), name="fit")
+    torch.manual_seed(0)
+    model = construct_model(cfg.model, 3, 10)
+    setup = dict(device=torch.device("cuda:0"), dtype=torch.float, memory_format=torch.contiguous_format)
+    stats = train(model, (x, y), (x, y), setup, cfg)
+    loss, acc = np.array(stats["train_loss"]), np.array(stats["train_acc"])
+    print(f"mixed={mixed}: loss {loss[[0, 5, 10, 15, 20, 24]]}, acc {acc[[0, 5, 10, 15, 20, 24]]}, valid_acc {stats['valid_acc']}")
+    assert np.all(np.isfinite(loss)) and loss[-1] < 0.25 * loss[0] and acc[-1] > 0.95
+    assert stats["valid_acc"][-1] > 0.9          # BN running statistics are usable in eval mode
+    assert len(loss) == 25 and len(stats["grad_norm_train_3"]) == 25
+
+
 def test_checkpoint_roundtrip_and_reference_layout(golden, tmp_path):
     """5-list checkpoint (reference training/utils.py:43-51): same structure as the reference's file, resume continues."""
     data, meta = golden
