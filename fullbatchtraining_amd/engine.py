@@ -651,16 +651,30 @@ class Engine:
                 done += g_n
             if after_pre_pass is not None:
                 after_pre_pass()
-        done = 0
+        # With several groups per step the running-mean pass of group k (HBM-bound, 2 x G x 45 MB) runs on the weight-gradient stream
+        # beside the forward convolutions of group k+1; the per-chunk gradients then alternate between two arenas (the main stream
+        # writes dgamma / dbeta / fc gradients of group k+1 while group k is still being folded in).
+        overlap = (not fd) and self.wstream is not None and n_chunks > G and os.environ.get("FB_ACC_OVERLAP", "1") != "0"
+        if overlap and getattr(self, "g_alt", None) is None:
+            self.g_alt, self.acc_ws = torch.zeros_like(self.g), torch.zeros_like(self.mt_ws)
+        done, group_idx = 0, 0
         while done < n_chunks:
             g_n = min(G, n_chunks - done)
             lo = (k_first + done) * chunk
             xb, yb = patches[lo:lo + g_n * chunk], labels[lo:lo + g_n * chunk]
-            self.group_gradient(xb, yb, g_n, self.g, 1, self.theta, 0)
+            gbuf = self.g_alt if (overlap and group_idx & 1) else self.g
+            group_idx += 1
+            self.group_gradient(xb, yb, g_n, gbuf, 1, self.theta, 0)
             loss_all[done:done + g_n].copy_(self.loss[:g_n])
             correct_all[done:done + g_n].copy_(self.correct[:g_n])
             n_passes = 1
-            if not fd:
+            if overlap:
+                ready = torch.cuda.current_stream().record_event()
+                with torch.cuda.stream(self.wstream):
+                    self.wstream.wait_event(ready)
+                    call("fb_mt_accumulate", self.avg.data_ptr(), gbuf.data_ptr(), P, g_n, P, counter0 + done, sq_all.data_ptr() + 4 * done,
+                         self.acc_ws.data_ptr())
+            elif not fd:
                 call("fb_mt_accumulate", self.avg.data_ptr(), self.g.data_ptr(), P, g_n, P, counter0 + done, self.sq.data_ptr(),
                      self.mt_ws.data_ptr())
             else:
@@ -688,12 +702,15 @@ class Engine:
                 else:
                     call("fb_mt_fd_combine_accumulate", self.avg.data_ptr(), self.g.data_ptr(), self.g_fd[0].data_ptr(),
                          self.g.data_ptr(), P, g_n, P, self.eps_n.data_ptr(), cf, counter0 + done)
-            sq_all[done:done + g_n].copy_(self.sq[:g_n])
+            if not overlap:
+                sq_all[done:done + g_n].copy_(self.sq[:g_n])
             call("fb_bn_running_update", self.running_mean.data_ptr(), self.running_var.data_ptr(), self.mean_tab.data_ptr(),
                  self.var_tab.data_ptr(), n_passes, self.G * self.plan.ch_total, self.unbias.data_ptr(), g_n, self.plan.ch_total,
                  BN_MOMENTUM)
             self.num_batches_tracked += g_n * n_passes
             done += g_n
+        if overlap:
+            torch.cuda.current_stream().wait_stream(self.wstream)
         return loss_all, correct_all, sq_all
 
     def grad_and_param_sqnorm(self):
