@@ -239,6 +239,26 @@ def get_loss_fn(cfg_hyp, batch_size):
     raise ValueError(f"Invalid loss modification {cfg_hyp.loss_modification}.")
 
 
+def _is_shuffling(loader):
+    """A DataLoader whose sampler is not sequential (the reference's loaders for hyp.shuffle=True): every pass has a new order."""
+    return isinstance(loader, torch.utils.data.DataLoader) and not isinstance(loader.sampler, torch.utils.data.SequentialSampler)
+
+
+def _stage_dataset(loader, device):
+    """The DATASET behind a loader, in dataset order, on the device -- read through a private sequential loader so that the
+    generator of the caller's loader is not advanced."""
+    probe = torch.utils.data.DataLoader(loader.dataset, batch_size=1024, shuffle=False, drop_last=False, generator=torch.Generator())
+    xs, ys = zip(*[(x, y) for x, y in probe])
+    return torch.cat(xs).to(device), torch.cat(ys).to(device=device, dtype=torch.long)
+
+
+def _pass_indices(loader):
+    """Sample indices of one pass over ``loader`` in its order; advances its generator (or the default one) exactly like the
+    reference's ``for ... in trainloader`` does: the DataLoader iterator draws a base seed, then the sampler its permutation."""
+    torch.empty((), dtype=torch.int64).random_(generator=loader.generator)
+    return torch.tensor([i for batch in loader.batch_sampler for i in batch], dtype=torch.long)
+
+
 def _stage(loader, device):
     """Materialise a (static, unaugmented) loader as device-resident tensors in loader order (drop_last honoured)."""
     if isinstance(loader, (tuple, list)) and torch.is_tensor(loader[0]):
@@ -262,8 +282,6 @@ def _check_scope(cfg):
         raise NotImplementedError("hyp.batch_clip: the reference's own full-batch loop fails on it (NameError in _record_stats)")
     if hyp.grad_clip is not None and not float(hyp.grad_clip_norm) >= 1.0:
         raise NotImplementedError("grad_clip_norm must be a p-norm with p >= 1 (or inf)")
-    if hyp.shuffle:
-        raise NotImplementedError("hyp.shuffle=True changes chunk composition every step; resident data is sequential")
 
 
 def _device_augmentation(cfg, trainloader):
@@ -323,7 +341,15 @@ class FullBatchTrainer:
         self.loss_fn = get_loss_fn(cfg.hyp, cfg.data.batch_size)
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
         self.rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
-        X, Y = _stage(trainloader, self.device)
+        # a shuffling train loader: the dataset stays resident in dataset order and every step regathers it in the order of a new
+        # pass over the loader's batch sampler (reference: `for block, (inputs, labels) in enumerate(trainloader)` every step)
+        self.shuffler = trainloader if _is_shuffling(trainloader) else None
+        if self.shuffler is not None:
+            Xall, Yall = _stage_dataset(trainloader, self.device)
+            per_pass = len(trainloader.batch_sampler) * (trainloader.batch_size or 1) if trainloader.drop_last else len(trainloader.sampler)
+            X, Y = Xall[:per_pass], Yall[:per_pass]                   # shapes only; the first step gathers the first permutation
+        else:
+            X, Y = _stage(trainloader, self.device)
         block = min(cfg.data.batch_size, X.shape[0])
         chunks_in_block = max(block // cfg.hyp.sub_batch, 1)
         if block % chunks_in_block != 0:
@@ -351,12 +377,22 @@ class FullBatchTrainer:
         lo, hi = self.shard.first * self.chunk, (self.shard.first + self.shard.count) * self.chunk
         self.patches = torch.empty(hi - lo, stem.hout, stem.wout, stem.cin_pad, device=self.device, dtype=self.dtype) if hi > lo else None
         self.augment = _device_augmentation(cfg, trainloader)
+        if self.shuffler is not None:
+            if self.augment is not None:
+                raise NotImplementedError("a shuffling train loader together with impl.engine.device_augment")
+            self._all_images, self._all_labels = Xall.float().contiguous(), Yall
         self.images = X[lo:hi].float().contiguous() if (self.augment is not None and hi > lo) else None   # base images stay resident
         self._aug_step, self._n_total, self._lo = 0, X.shape[0], lo
-        if hi > lo and self.augment is None:
+        if hi > lo and self.augment is None and self.shuffler is None:
             stem_patches(X[lo:hi], stem, self.dtype, out=self.patches)
         self.labels = Y[lo:hi].contiguous()
-        self.valid = _stage(validloader, self.device) if validloader is not None else None
+        # a validation DataLoader is read once through a private loader (its generator untouched); every validation pass then advances
+        # that generator by the one base-seed draw the reference's pass over it makes (keeps shared generators aligned)
+        self._valid_loader = validloader if isinstance(validloader, torch.utils.data.DataLoader) else None
+        if self._valid_loader is not None and isinstance(validloader.sampler, torch.utils.data.SequentialSampler):
+            self.valid = _stage_dataset(validloader, self.device)
+        else:
+            self.valid = _stage(validloader, self.device) if validloader is not None else None
         self.stats = defaultdict(list)
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -366,6 +402,8 @@ class FullBatchTrainer:
         train_time = time.time()
         if self.augment is not None and self.images is not None:
             self._regather_augmented()
+        if self.shuffler is not None:
+            self._regather_shuffled()
         lr = self.optimizer.param_groups[0]["lr"]
         gr = hyp.grad_reg
         if self.world > 1:
@@ -465,6 +503,18 @@ class FullBatchTrainer:
         else:
             eng.sgd_step(lr, 0.0 if zero_wd else o.weight_decay, o.momentum, o.dampening, o.nesterov, grad_clip)
 
+    def _regather_shuffled(self):
+        """A new pass over the shuffling train loader: its batch sampler gives this step's sample order (rank 0's draw on several
+        ranks); this rank's slice of it is gathered from the resident dataset and turned into stem patches again."""
+        idx = _pass_indices(self.shuffler).to(self.device)
+        if self.world > 1:
+            torch.distributed.broadcast(idx, src=0)
+        lo, hi = self._lo, self._lo + self.shard.count * self.chunk
+        mine = idx[lo:hi]
+        if hi > lo:
+            stem_patches(self._all_images.index_select(0, mine), self.engine.plan.stem, self.dtype, out=self.patches)
+            self.labels = self._all_labels.index_select(0, mine).contiguous()
+
     def _regather_augmented(self):
         """A fresh RandomCrop offset / flip per image and step (the reference draws them in its DataLoader workers once per epoch =
         step); drawn for the WHOLE dataset from one seeded CPU generator so that a rank's images get the same augmentation however
@@ -519,6 +569,8 @@ class FullBatchTrainer:
         if self.valid is None:
             return stats
         X, Y = self.valid
+        if getattr(self, "_valid_loader", None) is not None:     # the reference's pass over the validation loader draws one base seed
+            torch.empty((), dtype=torch.int64).random_(generator=self._valid_loader.generator)
         eng = self.engine
         cap = eng.G * eng.chunk
         loss_sum, correct, n = 0.0, 0.0, 0

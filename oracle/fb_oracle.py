@@ -619,8 +619,12 @@ def evaluate(spec, params, buffers, X, Y, batch=128, q=identity, test_time_flips
 
 
 def train(spec, state, X, Y, hyp, steps, chunk, scheduler="cosine-decay", warmup=0, q=identity, Xv=None, Yv=None,
-          validate_every=100):
-    """Small driver mirroring reference training.py:217-239 + 296-298; mutates ``state`` in place; returns stats."""
+          validate_every=100, order_fn=None, before_eval=None):
+    """Small driver mirroring reference training.py:217-239 + 296-298; mutates ``state`` in place; returns stats.
+
+    ``order_fn(step)``: sample indices of this step's pass over the data in loader order (a shuffling train loader: the reference
+    iterates its DataLoader anew every step, training.py:145-147); ``before_eval()``: called before every validation pass (lets a
+    test advance a generator the way the reference's validation loader does)."""
     params, buffers = split_state(state)
     momentum = [None] * len(params)
     # get_loss_fn (reference training.py:391-413): the training loss; evaluate() always uses plain cross entropy (training.py:345)
@@ -633,7 +637,11 @@ def train(spec, state, X, Y, hyp, steps, chunk, scheduler="cosine-decay", warmup
         ema_params = {k: v.clone() for k, v in params.items()}
         ema_buffers = {k: v.clone() for k, v in buffers.items()}
     for step in range(steps):
-        full_batch_step(spec, params, buffers, momentum, X, Y, hyp, sched.lr, stats, chunk, q)
+        Xs, Ys = X, Y
+        if order_fn is not None:
+            idx = order_fn(step)
+            Xs, Ys = X[idx], Y[idx]
+        full_batch_step(spec, params, buffers, momentum, Xs, Ys, hyp, sched.lr, stats, chunk, q)
         stats["lr"].append(sched.lr)
         sched.step()
         eval_params, eval_buffers = params, buffers
@@ -644,6 +652,8 @@ def train(spec, state, X, Y, hyp, steps, chunk, scheduler="cosine-decay", warmup
                     dst[k].copy_(m * dst[k] + (1 - m) * src[k])
             eval_params, eval_buffers = ema_params, ema_buffers
         if Xv is not None and (step % validate_every == 0 or step + 1 >= steps):
+            if before_eval is not None:
+                before_eval()
             vl, va = evaluate(spec, eval_params, eval_buffers, Xv, Yv, q=q, test_time_flips=hyp.get("test_time_flips", False))
             stats["valid_loss"].append(vl)
             stats["valid_acc"].append(va)

@@ -62,8 +62,14 @@ def make_data(n, pixels=32, classes=10, seed=1234):
     return x, y
 
 
-def loaders(x, y, batch):
+def loaders(x, y, batch, shuffle=False):
     ds = torch.utils.data.TensorDataset(x, y)
+    if shuffle:            # what the reference's data preparation builds for hyp.shuffle=True: a RandomSampler, a new permutation per pass
+        own = torch.Generator().manual_seed(0)
+        train = torch.utils.data.DataLoader(ds, batch_size=min(batch, len(ds)), shuffle=True, drop_last=True, generator=own)
+        valid = torch.utils.data.DataLoader(ds, batch_size=min(batch, len(ds)), shuffle=False, drop_last=False, generator=own)
+        train.sampler.set_epoch = lambda *a, **k: None
+        return train, valid
     sampler = torch.utils.data.SequentialSampler(ds)
     sampler.set_epoch = lambda *a, **k: None
     # the loaders get a generator of their own: a DataLoader iterator draws its base seed at the start of every pass, and with the
@@ -134,6 +140,8 @@ SCENARIOS_A9 = {
                            "data.batch_size=64", "hyp.sub_batch=64"], 35),
     "fb_clip_l1": (128, 16, ["hyp=fbclip", "hyp.grad_clip=50.0", "hyp.grad_clip_norm=1", "hyp.steps=3", "hyp.warmup=0", "data.batch_size=64",
                              "hyp.sub_batch=64"], 37),
+    # a shuffling train loader (hyp.shuffle=True in the reference's data preparation): chunk composition changes every step
+    "fb_shuffle": (192, 16, ["hyp=fb1", "hyp.steps=3", "hyp.warmup=0", "data.batch_size=64", "hyp.sub_batch=64"], 39),
     "fb_tta": (128, 16, ["hyp=fb1", "hyp.test_time_flips=True", "hyp.steps=2", "hyp.warmup=0", "data.batch_size=64", "hyp.sub_batch=64"], 27),
     "fb_ema": (128, 16, ["hyp=fb1", "hyp.evaluate_ema=True", "hyp.eval_ema_momentum=0.6", "hyp.steps=3", "hyp.warmup=0", "data.batch_size=64",
                          "hyp.sub_batch=64"], 25),
@@ -149,7 +157,7 @@ def run_scenario(fullbatch, compose, scen, out, dtype=torch.float):
     cfg = compose(overrides + extra + ["impl.validate_every_nth_step=1000", f"data.pixels={pixels}"], original_cwd=tmp,
                   name=name, seed=mseed)
     x, y = make_data(n, pixels)
-    trainloader, validloader = loaders(x, y, cfg.data.batch_size)
+    trainloader, validloader = loaders(x, y, cfg.data.batch_size, shuffle="shuffle" in scen)
     setup = dict(device=torch.device("cpu"), dtype=dtype, memory_format=torch.contiguous_format)
     x = x.to(dtype)
     torch.manual_seed(mseed)

@@ -35,3 +35,20 @@ def hyp_from_cfg(cfg):
 def rel_err(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def shuffling_loaders(x, y, batch):
+    """The loaders tests/golden/make_golden.py hands to the reference in the "shuffle" scenarios: RandomSampler train loader and a
+    validation loader that share one generator seeded with 0."""
+    ds = torch.utils.data.TensorDataset(x, y)
+    own = torch.Generator().manual_seed(0)
+    train = torch.utils.data.DataLoader(ds, batch_size=min(batch, len(ds)), shuffle=True, drop_last=True, generator=own)
+    valid = torch.utils.data.DataLoader(ds, batch_size=min(batch, len(ds)), shuffle=False, drop_last=False, generator=own)
+    return train, valid
+
+
+def loader_pass_indices(loader):
+    """Sample indices of one pass over ``loader`` in its order, consuming its generator exactly like ``for batch in loader`` does
+    (torch DataLoader: the iterator draws a base seed first, then the sampler draws its permutation)."""
+    torch.empty((), dtype=torch.int64).random_(generator=loader.generator)
+    return torch.tensor([i for batch in loader.batch_sampler for i in batch], dtype=torch.long)

@@ -109,7 +109,7 @@ def test_out_of_scope_options_raise():
     with pytest.raises(NotImplementedError):
         _check_scope(compose(["hyp=fbclip", "hyp.grad_clip_norm=0.5"]))                       # p-norms with p >= 1 (or inf)
     for ok in (["hyp=fbclip", "hyp.grad_clip_norm=inf"], ["hyp=fbclip", "hyp.grad_clip_norm=1"], ["hyp=fb1", "hyp.norm_bias.strength=0.1"], ["hyp=fb1", "hyp.evaluate_ema=True"],
-               ["hyp=fb1", "hyp/optim_modification=SAM"], ["hyp=fb1", "hyp/optim_modification=LARC"], ["hyp=fb1", "hyp.grad_noise.additive=0.1"]):
+               ["hyp=fb1", "hyp/optim_modification=SAM"], ["hyp=fb1", "hyp/optim_modification=LARC"], ["hyp=fb1", "hyp.grad_noise.additive=0.1"], ["hyp=fb1", "hyp.shuffle=True"]):
         _check_scope(compose(ok))
     cfg = compose(["hyp=fb1"])
     cfg.hyp.optim.name = "L-BFGS"

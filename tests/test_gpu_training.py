@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import NOISE_SEED, make_data, rel_err, summarise
+from tests.helpers import NOISE_SEED, make_data, rel_err, shuffling_loaders, summarise
 
 pytestmark = pytest.mark.gpu
 
@@ -31,6 +31,9 @@ def _run(meta, name, extra=(), tmp_path=None, valid_full=False):
     setup = dict(device=torch.device("cuda:0"), dtype=torch.float, memory_format=torch.contiguous_format)
     if "noise" in name:
         torch.manual_seed(NOISE_SEED)          # the generator state the reference run drew its gradient noise from
+    if "shuffle" in name:                      # the loaders the reference run was given (RandomSampler, shared generator)
+        tl, vl = shuffling_loaders(x, y, cfg.data.batch_size)
+        return cfg, model, train(model, tl, vl, setup, cfg)
     stats = train(model, (x, y), (x, y) if valid_full else (x[:64], y[:64]), setup, cfg)
     return cfg, model, stats
 
@@ -50,7 +53,9 @@ def _run(meta, name, extra=(), tmp_path=None, valid_full=False):
                                             ("fb_linwd", 3e-3, 2),
                                             # loss functions of get_loss_fn (a12): label smoothing (with the regulariser), incorrect-xent
                                             ("fb_smooth", 8e-3, 2), ("fb_incorrect", 1e-2, 1),
-                                            ("fb_clip_l1", 2e-4, 2)])                                # p-norm clip, p = 1
+                                            ("fb_clip_l1", 2e-4, 2),                                 # p-norm clip, p = 1
+                                            # shuffling train loader (lr 0.4 without warm-up: the loss climbs 2.4 -> 3.9 -> 7.0 and fp32 noise with it; steps 1-2 agree to 3e-4)
+                                            ("fb_shuffle", 1e-2, 2)])
 def test_train_matches_reference_run_f32(golden, name, tol, group, tmp_path):
     data, meta = golden
     cfg, model, stats = _run(meta, name, [f"impl.engine.chunk_group={group}"], tmp_path)

@@ -15,7 +15,7 @@ import torch
 from fullbatchtraining_amd.cfg import compose
 from fullbatchtraining_amd.models import construct_model
 from oracle import fb_oracle as orc
-from tests.helpers import NOISE_SEED, hyp_from_cfg, make_data, rel_err, summarise
+from tests.helpers import NOISE_SEED, hyp_from_cfg, loader_pass_indices, make_data, rel_err, shuffling_loaders, summarise
 
 F64 = torch.float64
 
@@ -114,6 +114,7 @@ TRAIN_CASES = ["fb_plain", "fb_gradreg", "fb_clip_warm", "fb_gradreg_c32", "fb_c
                "fb_clip_inf", "fb_normbias1", "fb_normbias2", "fb_ema", "fb_tta", "fb_linwd",
                "fb_smooth", "fb_incorrect",     # label smoothing / incorrect-xent loss (a12)
                "fb_clip_l1",                    # p-norm clip, p = 1
+               "fb_shuffle",                    # shuffling train loader: a new permutation (chunk composition) every step
                "fb_noise"]                      # additive + multiplicative gradient noise from the seeded default generator; L-inf clip, norm bias, EMA / mirrored evaluation (scenarios_a9.npz)
 
 
@@ -126,8 +127,13 @@ def test_training_float64_pin(golden, name):
     chunk = min(cfg.data.batch_size, cfg.hyp.sub_batch)
     if "noise" in name:
         torch.manual_seed(NOISE_SEED)
+    order_fn = before_eval = None
+    if "shuffle" in name:              # the same loaders the reference ran on; their generator advances as in a DataLoader pass
+        tl, vl = shuffling_loaders(x, y, cfg.data.batch_size)
+        order_fn = lambda step: loader_pass_indices(tl)                                           # noqa: E731
+        before_eval = lambda: torch.empty((), dtype=torch.int64).random_(generator=vl.generator)  # noqa: E731
     stats = orc.train(spec, state, x, y, hyp_from_cfg(cfg), cfg.hyp.steps, chunk, cfg.hyp.scheduler, cfg.hyp.warmup, Xv=x, Yv=y,
-                      validate_every=1000)       # the generator validates on the training tensors after step 1 and after the last step
+                      validate_every=1000, order_fn=order_fn, before_eval=before_eval)       # the generator validates on the training tensors after step 1 and after the last step
     key = f"{name}@f64"
     tol = 1e-7 if "legacy" not in name else 1e-6
     for stat in ("train_loss", "train_acc", "param_norm", "grad_norm", "full_loss", "preclip_gradnorm", "clipped_step", "valid_loss", "valid_acc"):
