@@ -2,8 +2,8 @@
 
 The reference reads one OmegaConf tree ``cfg.{data,model,impl,hyp,analysis,seed,name,dryrun}`` built by Hydra
 from ``config/cfg.yaml`` + group files (reference ``config/cfg.yaml:9-37``, ``train_with_gradient_descent.py:19``).
-This module composes the same tree from the YAML files under ``fullbatchtraining_amd/config`` and accepts the
-same command-line override grammar for the keys the hot path consumes:
+This module composes the same tree from ``fullbatchtraining_amd/config/presets.yaml`` (one document: group -> choice ->
+values) and accepts the same command-line override grammar for the keys the hot path consumes:
 
     compose(["hyp=gradreg", "data.batch_size=32", "hyp.grad_reg.block_strength=0.5"])
 
@@ -16,6 +16,16 @@ import os
 import yaml
 
 CONFIG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config")
+_PRESETS = None
+
+
+def _presets():
+    """group path ("root", "hyp", "hyp/optim", ...) -> choice -> values."""
+    global _PRESETS
+    if _PRESETS is None:
+        with open(os.path.join(CONFIG_DIR, "presets.yaml")) as handle:
+            _PRESETS = yaml.safe_load(handle)["groups"]
+    return _PRESETS
 
 
 class AttrDict(dict):
@@ -77,12 +87,11 @@ def _merge(base, new):
 
 
 def _load_group(rel_dir, name, selections, prefix):
-    """Load ``<rel_dir>/<name>.yaml`` resolving its own ``defaults`` list relative to its directory."""
-    path = os.path.join(CONFIG_DIR, rel_dir, f"{name}.yaml")
-    if not os.path.isfile(path):
-        raise ValueError(f"Unknown config option {os.path.join(rel_dir, name)!r} (no {path}).")
-    with open(path) as handle:
-        raw = _fix_floats(yaml.safe_load(handle) or {})
+    """Load choice ``name`` of group ``rel_dir`` resolving its own ``defaults`` list relative to that group."""
+    group = _presets().get(rel_dir.replace(os.sep, "/") or "root", {})
+    if name not in group:
+        raise ValueError(f"Unknown config option {os.path.join(rel_dir, name)!r}.")
+    raw = _fix_floats(copy.deepcopy(group[name]) or {})
     defaults = raw.pop("defaults", [])
     out = {}
     for entry in defaults:
@@ -105,9 +114,11 @@ def compose(overrides=(), **extra):
     for item in overrides:
         key, _, value = item.partition("=")
         key = key.lstrip("+").replace("/", ".")
-        group_dir = os.path.join(CONFIG_DIR, key.replace(".", os.sep))
-        if os.path.isdir(group_dir) and os.path.isfile(os.path.join(group_dir, f"{value}.yaml")):
+        group = _presets().get(key.replace(".", "/"))
+        if group is not None and value in group:
             selections[key] = value
+        elif group is not None and key.replace(".", "/") != "root":
+            raise ValueError(f"Unknown choice {value!r} for config group {key!r} (have: {sorted(group)}).")
         else:
             assignments.append((key, _parse_scalar(value)))
     tree = _load_group("", "cfg", selections, "")
