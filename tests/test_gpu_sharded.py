@@ -31,7 +31,7 @@ def _run(rank, world, port, out_dir, grad_reg):
     from tests.helpers import make_data
 
     torch.cuda.set_device(0)
-    extra = {False: [], True: ["hyp.grad_reg.block_strength=0.5"], "options": OPTIONS,
+    extra = {False: [], True: ["hyp.grad_reg.block_strength=0.5"], "options": OPTIONS, "shuffle": [],
              "acc": ["hyp.grad_reg.block_strength=0.0", "hyp.grad_reg.acc_strength=0.5", "hyp.grad_reg.implementation=central-differences"]}
     over = list(OVERRIDES) + extra[grad_reg]
     if world > 1:
@@ -42,7 +42,11 @@ def _run(rank, world, port, out_dir, grad_reg):
     model = construct_model(cfg.model, 3, 10)
     x, y = make_data(N, PIXELS)
     setup = dict(device=torch.device("cuda:0"), dtype=torch.float, memory_format=torch.contiguous_format)
-    stats = train(model, (x, y), None, setup, cfg)
+    feed = (x, y)
+    if grad_reg == "shuffle":          # a shuffling train loader: every rank follows rank 0's permutation of each step
+        from tests.helpers import shuffling_loaders
+        feed = shuffling_loaders(x, y, 32)[0]
+    stats = train(model, feed, None, setup, cfg)
     keep = {k: v for k, v in stats.items() if k != "train_time"}
     torch.save(dict(stats=keep, state={k: v.cpu() for k, v in model.state_dict().items()}),
                os.path.join(out_dir, f"w{world}_r{rank}.pt"))
@@ -56,7 +60,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("grad_reg", [False, True, "options", "acc"])
+@pytest.mark.parametrize("grad_reg", [False, True, "options", "acc", "shuffle"])
 def test_two_rank_run_equals_single_process(tmp_path, grad_reg):
     """plain step and regulariser: sharded update (reduce-scatter / all-gather); "options": SAM + L-infinity clip + norm bias +
     per-tensor weight decay + gradient noise (rank 0's draw, broadcast), which all-reduce the gradient and replicate the 1-process update; "acc": the acc_strength pre-pass
@@ -87,7 +91,7 @@ def test_two_rank_run_equals_single_process(tmp_path, grad_reg):
                 # fp32 chunk-gradient noise (order of sums differs); the central-difference acc term divides the difference of two such
                 # gradients by 2 eps_n: a last-bit difference in the all-reduced pre-pass mean moves a weight by up to 4 % after the
                 # first real update (steps 1-2, taken at identical parameters, agree to the bit -- asserted below)
-                tol = {False: 1e-3, True: 1e-2, "options": 1e-2, "acc": 6e-2}[grad_reg]
+                tol = {False: 1e-3, True: 1e-2, "options": 1e-2, "acc": 6e-2, "shuffle": 1e-2}[grad_reg]
                 assert float((got["state"][name] - t).abs().max()) < tol * scale + 1e-6, name
             else:
                 assert torch.equal(got["state"][name], t), name
