@@ -607,13 +607,14 @@ class Engine:
 
     # --------------------------------------------------------------------------------------- full-batch gradient + step --
     def full_gradient(self, patches, labels, lr, block_strength=0.0, eps=1e-2, implementation="forward-differences",
-                      chunk_ids=None, counter0=0, acc_strength=0.0, after_pre_pass=None):
+                      chunk_ids=None, counter0=0, acc_strength=0.0, after_pre_pass=None, pre_block=None):
         """Accumulate the regularised gradient over chunks (reference training.py:144-174) into ``self.avg``.
 
         ``patches``/``labels`` hold the whole resident dataset; chunk k = rows [k*chunk, (k+1)*chunk).  ``chunk_ids``
         must be a contiguous range (this rank's shard).  Returns device tensors (loss_k, correct_k, n_k) for the chunks.
         ``after_pre_pass``: called once ``self.pre`` (the local mean of the ``acc_strength`` pre-pass) is complete -- the multi-GPU
-        path turns it into the global mean there.
+        path turns it into the global mean there.  ``pre_block``: images per BN batch of the pre-pass when it differs from the
+        chunk size (the reference's pre-pass runs whole loader blocks, its main loop ``sub_batch`` chunks; a multiple of ``chunk``).
         """
         chunk, P, G = self.chunk, self.plan.P, self.G
         n_chunks = patches.shape[0] // chunk if chunk_ids is None else len(chunk_ids)
@@ -639,16 +640,25 @@ class Engine:
                 self.pre = torch.zeros(P, **f32)
             pre = self.pre
             pre.zero_()
-            done = 0
-            while done < n_chunks:
-                g_n = min(G, n_chunks - done)
-                lo = (k_first + done) * chunk
-                self.group_gradient(patches[lo:lo + g_n * chunk], labels[lo:lo + g_n * chunk], g_n, self.g, 1, self.theta, 0)
-                call("fb_mt_accumulate", pre.data_ptr(), self.g.data_ptr(), P, g_n, P, done, None, self.mt_ws.data_ptr())
-                call("fb_bn_running_update", self.running_mean.data_ptr(), self.running_var.data_ptr(), self.mean_tab.data_ptr(),
-                     self.var_tab.data_ptr(), 1, self.G * self.plan.ch_total, self.unbias.data_ptr(), g_n, self.plan.ch_total, BN_MOMENTUM)
-                self.num_batches_tracked += g_n
-                done += g_n
+            bsz = chunk if pre_block is None else int(pre_block)          # images per BN batch of the pre-pass
+            per = bsz // chunk
+            if bsz % chunk != 0 or n_chunks % per != 0 or per > G:
+                raise lib.EngineError(f"pre-pass blocks of {bsz} images do not tile {n_chunks} chunks of {chunk} (group {G})")
+            n_batches, g_cap = n_chunks // per, G // per
+            self.chunk = bsz                                             # (as evaluate_batch does: all per-batch sizes follow self.chunk)
+            try:
+                done = 0
+                while done < n_batches:
+                    g_n = min(g_cap, n_batches - done)
+                    lo = k_first * chunk + done * bsz
+                    self.group_gradient(patches[lo:lo + g_n * bsz], labels[lo:lo + g_n * bsz], g_n, self.g, 1, self.theta, 0)
+                    call("fb_mt_accumulate", pre.data_ptr(), self.g.data_ptr(), P, g_n, P, done, None, self.mt_ws.data_ptr())
+                    call("fb_bn_running_update", self.running_mean.data_ptr(), self.running_var.data_ptr(), self.mean_tab.data_ptr(),
+                         self.var_tab.data_ptr(), 1, self.G * self.plan.ch_total, self.unbias.data_ptr(), g_n, self.plan.ch_total, BN_MOMENTUM)
+                    self.num_batches_tracked += g_n
+                    done += g_n
+            finally:
+                self.chunk = chunk
             if after_pre_pass is not None:
                 after_pre_pass()
         # With several groups per step the running-mean pass of group k (HBM-bound, 2 x G x 45 MB) runs on the weight-gradient stream

@@ -274,10 +274,10 @@ def _check_scope(cfg):
     hyp = cfg.hyp
     if hyp.train_stochastic or hyp.train_switch_stochastic is not None:
         raise NotImplementedError("the engine implements the full-batch branch (hyp.train_stochastic=False) only")
-    if hyp.grad_reg.acc_strength != 0:
-        if max(cfg.data.batch_size // hyp.sub_batch, 1) != 1:
-            raise NotImplementedError("grad_reg.acc_strength with sub_batch < batch_size: the reference's pre-pass runs whole blocks "
-                                      "(other BN batches than the main loop)")
+    if hyp.grad_reg.acc_strength != 0 and max(cfg.data.batch_size // hyp.sub_batch, 1) != 1 \
+            and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        raise NotImplementedError("grad_reg.acc_strength with sub_batch < batch_size on several ranks (the pre-pass runs whole blocks; "
+                                  "chunk ranges of the ranks would have to be cut at block boundaries)")
     if hyp.batch_clip is not None:
         raise NotImplementedError("hyp.batch_clip: the reference's own full-batch loop fails on it (NameError in _record_stats)")
     if hyp.grad_clip is not None and not float(hyp.grad_clip_norm) >= 1.0:
@@ -354,7 +354,7 @@ class FullBatchTrainer:
         chunks_in_block = max(block // cfg.hyp.sub_batch, 1)
         if block % chunks_in_block != 0:
             raise NotImplementedError("data.batch_size must be divisible into equal sub_batch chunks")
-        self.chunk = block // chunks_in_block
+        self.chunk, self.block = block // chunks_in_block, block
         self.num_blocks = X.shape[0] // block               # drop_last=True
         self.n_chunks = self.num_blocks * chunks_in_block
         self.datapoints = self.n_chunks * self.chunk
@@ -417,7 +417,7 @@ class FullBatchTrainer:
                 from .parallel import reduce_pre_pass
                 hook = lambda: reduce_pre_pass(self)          # noqa: E731
             out = eng.full_gradient(self.patches, self.labels, lr, gr.block_strength, gr.eps, gr.implementation, acc_strength=gr.acc_strength,
-                                    after_pre_pass=hook)
+                                    after_pre_pass=hook, pre_block=self.block)
             self._pre_sqnorm = None
             if gr.acc_strength != 0:             # |pre_grads|^2 for full_loss (reference training.py:98-101)
                 lib.call("fb_mt_norms2", eng.pre.data_ptr(), None, eng.plan.P, eng.norms2.data_ptr(), eng.mt_ws.data_ptr())

@@ -512,10 +512,14 @@ def _gradient_evaluation(spec, params, buffers, X, Y, hyp, lr, stats, chunk, q=i
     n_chunks = X.shape[0] // chunk  # drop_last=True, reference data_preparation.py:68
     acc = hyp.get("acc_strength", 0.0)
     pre = None
-    if acc != 0:  # pre-pass, training.py:128-142: plain full gradient (running mean over blocks); a train-mode pass of its own
+    if acc != 0:  # pre-pass, training.py:128-142: plain full gradient (running mean over WHOLE blocks of data.batch_size images --
+        # BN batches of their own when the main loop cuts blocks into sub_batch chunks); a train-mode pass of its own
         pre = [torch.zeros_like(p) for p in params.values()]
-        for counter, k in enumerate(range(n_chunks) if chunk_range is None else chunk_range):
-            g0, _, _ = chunk_gradient(spec, params, buffers, X[k * chunk:(k + 1) * chunk], Y[k * chunk:(k + 1) * chunk], q)
+        block = hyp.get("block", chunk)
+        n_blocks = X.shape[0] // block
+        block_ids = range(n_blocks) if chunk_range is None else sorted({k * chunk // block for k in chunk_range})
+        for counter, b in enumerate(block_ids):
+            g0, _, _ = chunk_gradient(spec, params, buffers, X[b * block:(b + 1) * block], Y[b * block:(b + 1) * block], q)
             for a, g in zip(pre, g0):
                 g.sub_(a)
                 a.add_(g, alpha=1 / (counter + 1))

@@ -142,6 +142,9 @@ SCENARIOS_A9 = {
                              "hyp.sub_batch=64"], 37),
     # a shuffling train loader (hyp.shuffle=True in the reference's data preparation): chunk composition changes every step
     "fb_shuffle": (192, 16, ["hyp=fb1", "hyp.steps=3", "hyp.warmup=0", "data.batch_size=64", "hyp.sub_batch=64"], 39),
+    # acc_strength with sub-chunked blocks: the pre-pass runs WHOLE blocks (BN batch = data.batch_size), the main loop sub_batch chunks
+    "fb_acc_sub": (128, 16, ["hyp=fb1", "hyp.steps=2", "hyp.warmup=0", "hyp.grad_reg.block_strength=0.5", "hyp.grad_reg.acc_strength=0.25",
+                             "data.batch_size=64", "hyp.sub_batch=32"], 41),
     "fb_tta": (128, 16, ["hyp=fb1", "hyp.test_time_flips=True", "hyp.steps=2", "hyp.warmup=0", "data.batch_size=64", "hyp.sub_batch=64"], 27),
     "fb_ema": (128, 16, ["hyp=fb1", "hyp.evaluate_ema=True", "hyp.eval_ema_momentum=0.6", "hyp.steps=3", "hyp.warmup=0", "data.batch_size=64",
                          "hyp.sub_batch=64"], 25),

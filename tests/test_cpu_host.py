@@ -102,8 +102,7 @@ def test_out_of_scope_options_raise():
     with pytest.raises(NotImplementedError):
         _check_scope(compose(["hyp=base_sgd"]))                    # stochastic branch
     _check_scope(compose(["hyp=fb1", "hyp.grad_reg.acc_strength=0.1"]))                       # supported: pre-pass over whole blocks
-    with pytest.raises(NotImplementedError):                                                  # ... but not with sub-chunked blocks
-        _check_scope(compose(["hyp=fb1", "hyp.grad_reg.acc_strength=0.1", "data.batch_size=128", "hyp.sub_batch=32"]))
+    _check_scope(compose(["hyp=fb1", "hyp.grad_reg.acc_strength=0.1", "data.batch_size=128", "hyp.sub_batch=32"]))   # ... also sub-chunked
     with pytest.raises(NotImplementedError):
         _check_scope(compose(["hyp=fb1", "hyp.batch_clip=1.0"]))                              # broken in the reference itself
     with pytest.raises(NotImplementedError):

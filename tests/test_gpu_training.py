@@ -41,6 +41,7 @@ def _run(meta, name, extra=(), tmp_path=None, valid_full=False):
 @pytest.mark.parametrize("name,tol,group", [("fb_plain", 2e-4, 3), ("fb_clip_warm", 2e-4, 13), ("fb_gradreg", 3e-3, 2),
                                             ("fb_gradreg_c32", 8e-3, 4), ("fb_central", 3e-3, 2), ("fb_legacy", 8e-3, 1),
                                             ("fb_acc", 8e-3, 3), ("fb_acc_central", 3e-3, 2),        # acc_strength pre-pass
+                                            ("fb_acc_sub", 8e-3, 4),                                 # ... over whole blocks of 2 sub-chunks
                                             # optimizer wrappers around the closure: SAM records two closures per step
                                             ("fb_sam", 1e-3, 3), ("fb_sam_gradreg", 8e-3, 2), ("fb_lars", 2e-4, 1), ("fb_larc", 2e-4, 2),
                                             # off-by-default options of the gradient modification: L-inf clip, norm bias

@@ -114,6 +114,7 @@ TRAIN_CASES = ["fb_plain", "fb_gradreg", "fb_clip_warm", "fb_gradreg_c32", "fb_c
                "fb_clip_inf", "fb_normbias1", "fb_normbias2", "fb_ema", "fb_tta", "fb_linwd",
                "fb_smooth", "fb_incorrect",     # label smoothing / incorrect-xent loss (a12)
                "fb_clip_l1",                    # p-norm clip, p = 1
+               "fb_acc_sub",                    # acc_strength pre-pass over whole blocks, main loop over sub-chunks
                "fb_shuffle",                    # shuffling train loader: a new permutation (chunk composition) every step
                "fb_noise"]                      # additive + multiplicative gradient noise from the seeded default generator; L-inf clip, norm bias, EMA / mirrored evaluation (scenarios_a9.npz)
 
