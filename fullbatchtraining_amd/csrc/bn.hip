@@ -95,12 +95,12 @@ __global__ void bn_apply_kernel(const uint4* __restrict__ x, uint4* __restrict__
 // "Span" variants of the elementwise kernels (used whenever the channel vectors of a pixel divide 256): a workgroup owns a run of
 // consecutive 16-byte vectors of ONE statistics group, so a thread keeps its channel vector for the whole run and its
 // coefficients stay in registers -- the grid-stride form above re-reads 16-48 coefficient dwords per 16-byte vector through
-// the same texture path as the data (1.5-3x its bytes).  Four vectors per thread are in flight per loop trip.
+// the same texture path as the data (1.5-3x its bytes).  BN_SPAN_U vectors per thread are in flight per loop trip.
 template <int V> __device__ __forceinline__ void load_coef(const float* __restrict__ p, float* o) {
 #pragma unroll
     for (int k = 0; k < V; k += 4) { const float4 v = *(const float4*)(p + k); o[k] = v.x; o[k + 1] = v.y; o[k + 2] = v.z; o[k + 3] = v.w; }
 }
-constexpr int BN_SPAN_U = 4;
+constexpr int BN_SPAN_U = 2;        // vectors in flight per thread and loop trip
 // streaming accesses of the span kernels: every tensor is far larger than L2 + Infinity Cache and is touched once per kernel
 typedef __attribute__((ext_vector_type(4))) unsigned bn_u32x4_t;
 __device__ __forceinline__ uint4 ld_stream(const uint4* p) {
@@ -156,8 +156,10 @@ __global__ __launch_bounds__(256) void bn_apply_span_kernel(const uint4* __restr
     for (; i < hi; i += 256) { uint4 rr = make_uint4(0, 0, 0, 0); if (RES) rr = res[i]; one(x[i], rr, i); }
 }
 
-// run length of a span kernel: 4096 vectors (64 KiB per tensor) when that still gives >= 2048 workgroups, else 1024
-static inline int bn_span(long long n_vec) { return n_vec / 4096 >= 2048 ? 4096 : 1024; }
+// run length of a span kernel: 512 vectors (one trip of two vectors per thread).  Alone on the device longer runs are a little faster
+// (4096 vectors, four in flight: 5.7-6.5 TB/s), inside the step short ones win: 245.5 vs 249.6 ms/step (same-box A/B of 512 / 1024 /
+// 2048 / 4096 / 8192-vector runs with 1, 2, 4, 8 vectors in flight; profiles/r1_pmc_notes.md)
+static inline int bn_span(long long) { return 512; }
 
 template <typename T>
 static void launch_bn_apply(const void* x, void* y, const float* scale, const float* shift, const void* res, const float* rscale,
