@@ -63,6 +63,32 @@ def cpu_baseline(n_chunks=8):
                       f"one full step = 390 chunks ~ {390 * dt / n_chunks:.0f} s"}
 
 
+def self_launch(n_gpus):
+    """Run this script as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>` in a child
+    process and pass its output through.  Nothing in the calling process may have initialised the GPU."""
+    import socket
+    import subprocess
+
+    share = os.environ.get("FB_BENCH_SHARE_DEVICE") == "1"
+    visible = torch.cuda.device_count()                 # counting devices does not initialise HIP
+    if visible < n_gpus and not share:
+        print(f"bench.py --gpus {n_gpus}: only {visible} GPU(s) visible on this node", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL between the ranks (see the pool's driver notes)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n_gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,12 +109,16 @@ def main():
                          "timed region (the protocol the rocprofv3 summaries under profiles/ are generated with)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N`: this process has not touched the GPU yet; it starts N fresh ranks (one per GPU) as children of
+        # torch.distributed.run, relays rank 0's JSON line and exits with the launcher's code (reference fullbatch/utils.py:33-45 is
+        # the self-spawning launcher this replaces)
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.exit(f"bench.py --gpus {args.gpus} inside a torch.distributed.run job of WORLD_SIZE={world}: the two must agree")
     # FB_BENCH_SHARE_DEVICE=1 (development only): all ranks on cuda:0 over gloo -- exercises the multi-rank orchestration on
     # a 1-GPU box (RCCL refuses two ranks on one device); the number it prints is not a scaling result
     share = os.environ.get("FB_BENCH_SHARE_DEVICE") == "1"

@@ -68,11 +68,16 @@ template <typename T, int RES>   // RES: 0 none, 1 plain residual, 2 residual wi
 __global__ void bn_apply_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, const float* __restrict__ scale,
                                 const float* __restrict__ shift, const uint4* __restrict__ res, const float* __restrict__ rscale,
                                 const float* __restrict__ rshift, long long n_vec, int cvec, long long vec_per_group, int C, int relu,
-                                unsigned char* __restrict__ mask_out) {
+                                unsigned char* __restrict__ mask_out, long long valid_vec) {
     constexpr int V = ET<T>::VEC;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (long long)gridDim.x * blockDim.x) {
         const int c0 = (int)(i % cvec) * V;
         const long long g = i / vec_per_group;
+        if (i - g * vec_per_group >= valid_vec) {           // padding pixels of a ragged statistics group: exact zeros, mask clear
+            y[i] = make_uint4(0, 0, 0, 0);
+            if (mask_out) mask_out[i] = 0;
+            continue;
+        }
         float xv[V], o[V];
         unsigned m = 0;
         ET<T>::unpack(x[i], xv);
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(256) void bn_apply_span_kernel(const uint4* __restr
                                                             const float* __restrict__ shift, const uint4* __restrict__ res,
                                                             const float* __restrict__ rscale, const float* __restrict__ rshift, long long n_vec,
                                                             int cvec, long long vec_per_group, int C, int relu, unsigned char* __restrict__ mask_out,
-                                                            int span) {
+                                                            int span, long long valid_vec) {
     constexpr int V = ET<T>::VEC;
     const long long g = blockIdx.y, base = g * vec_per_group;
     const long long lim = n_vec - base < vec_per_group ? n_vec - base : vec_per_group;
@@ -142,7 +147,9 @@ __global__ __launch_bounds__(256) void bn_apply_span_kernel(const uint4* __restr
             o[k] = relu ? fmaxf(v, 0.f) : v;
             m |= (v > 0.f ? 1u : 0u) << k;
         }
-        st_stream(y + i, ET<T>::pack(o));
+        uint4 packed = ET<T>::pack(o);
+        if (i >= valid_vec) { packed = make_uint4(0, 0, 0, 0); m = 0; }      // padding pixels of a ragged statistics group
+        st_stream(y + i, packed);
         if (mask_out) mask_out[i] = (unsigned char)m;
     };
     long long i = lo + threadIdx.x;
@@ -163,30 +170,31 @@ static inline int bn_span(long long) { return 512; }
 
 template <typename T>
 static void launch_bn_apply(const void* x, void* y, const float* scale, const float* shift, const void* res, const float* rscale,
-                            const float* rshift, int64_t n_pixels, int C, int64_t ppg, int relu, unsigned char* mask_out, hipStream_t st) {
+                            const float* rshift, int64_t n_pixels, int C, int64_t ppg, int64_t valid_ppg, int relu, unsigned char* mask_out, hipStream_t st) {
     const int cvec = C / ET<T>::VEC;
     const long long n_vec = n_pixels * cvec, vpg = ppg * cvec;
+    const long long valid_vec = (valid_ppg > 0 && valid_ppg < ppg ? valid_ppg : ppg) * cvec;
     if (256 % cvec == 0 && vpg > 0) {
         const int span = bn_span(n_vec);
         const dim3 grid((unsigned)((vpg + span - 1) / span), (unsigned)((n_vec + vpg - 1) / vpg));
-        if (!res) hipLaunchKernelGGL((bn_apply_span_kernel<T, 0>), grid, dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, nullptr, nullptr, nullptr, n_vec, cvec, vpg, C, relu, mask_out, span);
-        else if (!rscale) hipLaunchKernelGGL((bn_apply_span_kernel<T, 1>), grid, dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, nullptr, nullptr, n_vec, cvec, vpg, C, relu, mask_out, span);
-        else hipLaunchKernelGGL((bn_apply_span_kernel<T, 2>), grid, dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, rscale, rshift, n_vec, cvec, vpg, C, relu, mask_out, span);
+        if (!res) hipLaunchKernelGGL((bn_apply_span_kernel<T, 0>), grid, dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, nullptr, nullptr, nullptr, n_vec, cvec, vpg, C, relu, mask_out, span, valid_vec);
+        else if (!rscale) hipLaunchKernelGGL((bn_apply_span_kernel<T, 1>), grid, dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, nullptr, nullptr, n_vec, cvec, vpg, C, relu, mask_out, span, valid_vec);
+        else hipLaunchKernelGGL((bn_apply_span_kernel<T, 2>), grid, dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, rscale, rshift, n_vec, cvec, vpg, C, relu, mask_out, span, valid_vec);
         return;
     }
     const int blocks = (int)((n_vec + 255) / 256 < 8192 ? (n_vec + 255) / 256 : 8192);
-    if (!res) hipLaunchKernelGGL((bn_apply_kernel<T, 0>), dim3(blocks), dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, nullptr, nullptr, nullptr, n_vec, cvec, vpg, C, relu, mask_out);
-    else if (!rscale) hipLaunchKernelGGL((bn_apply_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, nullptr, nullptr, n_vec, cvec, vpg, C, relu, mask_out);
-    else hipLaunchKernelGGL((bn_apply_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, rscale, rshift, n_vec, cvec, vpg, C, relu, mask_out);
+    if (!res) hipLaunchKernelGGL((bn_apply_kernel<T, 0>), dim3(blocks), dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, nullptr, nullptr, nullptr, n_vec, cvec, vpg, C, relu, mask_out, valid_vec);
+    else if (!rscale) hipLaunchKernelGGL((bn_apply_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, nullptr, nullptr, n_vec, cvec, vpg, C, relu, mask_out, valid_vec);
+    else hipLaunchKernelGGL((bn_apply_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, rscale, rshift, n_vec, cvec, vpg, C, relu, mask_out, valid_vec);
 }
 
 extern "C" int fb_bn_apply(const void* x, void* y, const float* scale, const float* shift, const void* res, const float* rscale,
-                           const float* rshift, int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t relu, void* mask_out,
-                           int32_t dtype, void* stream) {
+                           const float* rshift, int64_t n_pixels, int32_t C, int64_t pixels_per_group, int64_t valid_pixels_per_group,
+                           int32_t relu, void* mask_out, int32_t dtype, void* stream) {
     if (!x || !y || !scale || !shift) FB_FAIL(FB_ERR_ARG, "fb_bn_apply: null pointer");
     if (C % 8 != 0) FB_FAIL(FB_ERR_SHAPE, "fb_bn_apply: C=%d must be a multiple of 8", C);
-    if (dtype == FB_F32) launch_bn_apply<float>(x, y, scale, shift, res, rscale, rshift, n_pixels, C, pixels_per_group, relu, (unsigned char*)mask_out, (hipStream_t)stream);
-    else launch_bn_apply<bf16_tag>(x, y, scale, shift, res, rscale, rshift, n_pixels, C, pixels_per_group, relu, (unsigned char*)mask_out, (hipStream_t)stream);
+    if (dtype == FB_F32) launch_bn_apply<float>(x, y, scale, shift, res, rscale, rshift, n_pixels, C, pixels_per_group, valid_pixels_per_group, relu, (unsigned char*)mask_out, (hipStream_t)stream);
+    else launch_bn_apply<bf16_tag>(x, y, scale, shift, res, rscale, rshift, n_pixels, C, pixels_per_group, valid_pixels_per_group, relu, (unsigned char*)mask_out, (hipStream_t)stream);
     FB_CHECK_LAUNCH("fb_bn_apply");
     return FB_OK;
 }

@@ -179,16 +179,23 @@ __global__ void head_loss_kernel(const float* __restrict__ logits, const long lo
                                  int only_incorrect) {
     extern __shared__ float sm[];   // [ipg] losses, [ipg] corrects
     const int g = blockIdx.x;
+    int valid = 0;                  // rows with a negative label are padding of a ragged chunk
+    for (int n = 0; n < ipg; ++n) valid += labels[(long long)g * ipg + n] >= 0 ? 1 : 0;
     for (int n = threadIdx.x; n < ipg; n += blockDim.x) {
         const float* z = logits + ((long long)g * ipg + n) * classes;
         float* dz = dlogits + ((long long)g * ipg + n) * classes;
         const int label = (int)labels[(long long)g * ipg + n];
+        if (label < 0) {
+            for (int j = 0; j < classes; ++j) dz[j] = 0.f;
+            sm[n] = 0.f; sm[ipg + n] = 0.f;
+            continue;
+        }
         float m = z[0]; int am = 0;
         for (int j = 1; j < classes; ++j) if (z[j] > m) { m = z[j]; am = j; }   // first maximum, as torch.argmax
         float se = 0.f;
         for (int j = 0; j < classes; ++j) se += expf(z[j] - m);
         const float lse = logf(se);
-        const float inv_n = 1.f / (float)ipg;
+        const float inv_n = 1.f / (float)valid;
         const float keep = (only_incorrect && am == label) ? 0.f : 1.f;
         const float w_t = 1.f - smoothing, w_o = smoothing / ((float)classes - 1.f);
         float li = 0.f;
@@ -204,7 +211,7 @@ __global__ void head_loss_kernel(const float* __restrict__ logits, const long lo
     if (threadIdx.x == 0) {
         float l = 0.f, c = 0.f;
         for (int n = 0; n < ipg; ++n) { l += sm[n]; c += sm[ipg + n]; }
-        loss[g] = l / (float)ipg; correct[g] = c;
+        loss[g] = l / (float)valid; correct[g] = c;
     }
 }
 
@@ -218,6 +225,69 @@ extern "C" int fb_head_loss(const float* feat, const float* fc_w, const float* f
     hipLaunchKernelGGL(head_loss_kernel, dim3(n_groups), dim3(128), (size_t)2 * imgs_per_group * sizeof(float), (hipStream_t)stream, logits,
                        (const long long*)labels, dlogits, loss, correct, imgs_per_group, classes, label_smoothing, only_incorrect);
     FB_CHECK_LAUNCH("fb_head_loss");
+    return FB_OK;
+}
+
+// ---- evaluation helpers ------------------------------------------------------------------------------------------------
+__global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
+                                      const float* __restrict__ rv, float eps, float* __restrict__ scale, float* __restrict__ shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] * (1.f / sqrtf(rv[c] + eps));
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+extern "C" int fb_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                                 float* scale, float* shift, int32_t C, void* stream) {
+    if (!gamma || !beta || !running_mean || !running_var || !scale || !shift) FB_FAIL(FB_ERR_ARG, "fb_bn_eval_coeffs: null pointer");
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean, running_var, eps,
+                       scale, shift, C);
+    FB_CHECK_LAUNCH("fb_bn_eval_coeffs");
+    return FB_OK;
+}
+
+// one workgroup: thread per image, then a fixed-order sum (thread 0)
+__global__ void head_tta_kernel(const float* __restrict__ za, const float* __restrict__ zb, const long long* __restrict__ labels, int n_img,
+                                int classes, float* __restrict__ ws) {
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < n_img; n += gridDim.x * blockDim.x) {
+        const float* a = za + (long long)n * classes; const float* b = zb + (long long)n * classes;
+        float ma = a[0], mb = b[0];
+        for (int j = 1; j < classes; ++j) { ma = fmaxf(ma, a[j]); mb = fmaxf(mb, b[j]); }
+        float sa = 0.f, sb = 0.f;
+        for (int j = 0; j < classes; ++j) { sa += expf(a[j] - ma); sb += expf(b[j] - mb); }
+        // outputs_j = softmax(a)_j + softmax(b)_j in (0, 2]; CE(outputs) = logsumexp(outputs) - outputs_label
+        const int label = (int)labels[n];
+        float best = -1.f, se = 0.f, ol = 0.f; int am = 0;
+        for (int j = 0; j < classes; ++j) {
+            const float o = expf(a[j] - ma) / sa + expf(b[j] - mb) / sb;
+            if (o > best) { best = o; am = j; }
+            se += expf(o);
+            if (j == label) ol = o;
+        }
+        ws[n] = logf(se) - ol;
+        ws[n_img + n] = am == label ? 1.f : 0.f;
+    }
+}
+__global__ void head_tta_sum_kernel(const float* __restrict__ ws, int n_img, float* __restrict__ loss_sum, float* __restrict__ correct) {
+    __shared__ double sl[256], sc[256];
+    double l = 0.0, c = 0.0;
+    for (int n = threadIdx.x; n < n_img; n += 256) { l += (double)ws[n]; c += (double)ws[n_img + n]; }
+    sl[threadIdx.x] = l; sc[threadIdx.x] = c;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) { sl[threadIdx.x] += sl[threadIdx.x + h]; sc[threadIdx.x] += sc[threadIdx.x + h]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { loss_sum[0] = (float)sl[0]; correct[0] = (float)sc[0]; }
+}
+// ws: 2*n floats of caller-provided scratch (per-image loss terms and hits).
+extern "C" int fb_head_tta(const float* logits_a, const float* logits_b, const int64_t* labels, int32_t n, int32_t classes, float* ws,
+                           float* loss_sum, float* correct, void* stream) {
+    if (!logits_a || !logits_b || !labels || !ws || !loss_sum || !correct) FB_FAIL(FB_ERR_ARG, "fb_head_tta: null pointer");
+    hipLaunchKernelGGL(head_tta_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits_a, logits_b, (const long long*)labels, n,
+                       classes, ws);
+    hipLaunchKernelGGL(head_tta_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, n, loss_sum, correct);
+    FB_CHECK_LAUNCH("fb_head_tta");
     return FB_OK;
 }
 

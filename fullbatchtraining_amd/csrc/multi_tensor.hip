@@ -181,6 +181,48 @@ extern "C" int fb_mt_fd_combine_accumulate(float* avg, const float* g, const flo
     return FB_OK;
 }
 
+// ---- the same in two steps, for per-chunk clipping of the regularised gradient (hyp.batch_clip) ------------------------------
+__global__ __launch_bounds__(256) void mt_fd_combine_inplace_kernel(float* g, const float* ga, const float* gb,      // (gb may alias g)
+                                                                    long long gstride, long long n, const float* __restrict__ eps_n, float cf) {
+    const int j = blockIdx.y;
+    const float e = eps_n[j];
+    float* gj = g + (long long)j * gstride; const float* a = ga + (long long)j * gstride; const float* b = gb + (long long)j * gstride;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float vhp = (a[i] - b[i]) / e;            // same expression (and rounding) as mt_fd_combine_kernel
+        gj[i] = gj[i] + cf * vhp;
+    }
+}
+extern "C" int fb_mt_fd_combine(float* g, const float* ga, const float* gb, int64_t group_stride, int32_t n_groups, int64_t n, const float* eps_n,
+                                float cf, void* stream) {
+    if (!g || !ga || !gb || !eps_n) FB_FAIL(FB_ERR_ARG, "fb_mt_fd_combine: null pointer");
+    const int64_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(mt_fd_combine_inplace_kernel, dim3((unsigned)(nb < 1024 ? nb : 1024), n_groups), dim3(256), 0, (hipStream_t)stream, g, ga, gb,
+                       (long long)group_stride, (long long)n, eps_n, cf);
+    FB_CHECK_LAUNCH("fb_mt_fd_combine");
+    return FB_OK;
+}
+__global__ __launch_bounds__(256) void mt_chunk_clip_kernel(float* __restrict__ g, long long gstride, long long n, const float* __restrict__ sq,
+                                                            float clip, float* __restrict__ clipped) {
+    const int j = blockIdx.y;
+    const float norm = sqrtf(sq[j]);
+    const bool hit = norm > clip;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && clipped) clipped[j] = hit ? 1.f : 0.f;
+    if (!hit) return;
+    const float coef = clip / (norm + 1e-6f);
+    float* gj = g + (long long)j * gstride;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) gj[i] *= coef;
+}
+extern "C" int fb_mt_chunk_clip(float* g, int64_t group_stride, int32_t n_groups, int64_t n, const float* sq, float clip, float* clipped,
+                                void* stream) {
+    if (!g || !sq) FB_FAIL(FB_ERR_ARG, "fb_mt_chunk_clip: null pointer");
+    if (!(clip >= 0.f)) FB_FAIL(FB_ERR_ARG, "fb_mt_chunk_clip: clip=%g must be non-negative", (double)clip);
+    const int64_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(mt_chunk_clip_kernel, dim3((unsigned)(nb < 1024 ? nb : 1024), n_groups), dim3(256), 0, (hipStream_t)stream, g,
+                       (long long)group_stride, (long long)n, sq, clip, clipped);
+    FB_CHECK_LAUNCH("fb_mt_chunk_clip");
+    return FB_OK;
+}
+
 // ---- |a|^2 and |b|^2 ----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mt_norms2_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, float* __restrict__ ws) {
     __shared__ float sm[16];

@@ -66,10 +66,22 @@ def max_group(plan, chunk, dtype):
     return max(1, ((1 << 31) - 1) // (chunk * per_image * torch.empty((), dtype=dtype).element_size()))
 
 
+def padded_chunk(plan, chunk):
+    """Images per chunk AS STORED: the smallest size >= ``chunk`` whose pixels fill whole 128-pixel statistics blocks on every feature
+    map of the plan (the conv epilogues and the BN kernels reduce statistics in 128-pixel blocks that must not straddle two chunks).
+    128 stays 128; data.batch_size=125 (the all-50 000-images variant, 400 chunks) is stored as 128 images with 3 zero images."""
+    mult = 1
+    for L in plan.layers:
+        mult = math.lcm(mult, 128 // math.gcd(128, L.hout * L.wout))
+    return _round_up(chunk, mult)
+
+
 class Plan:
     """Static layer plan + arena offsets derived from the parameter container (``fullbatchtraining_amd.models.ResNet``)."""
 
-    def __init__(self, model, pixels):
+    def __init__(self, model, pixels, arena_align=64):
+        """``arena_align``: the arena length is padded to a multiple of it (lcm(64, world size) so that every rank's shard of the
+        reduce-scatter has the same length for any number of GPUs)."""
         self.kind, self.stem_kind, self.classes, self.channels = model.kind, model.stem_kind, model.classes, model.channels
         self.pixels = pixels
         named = dict(model.named_parameters())
@@ -80,7 +92,7 @@ class Plan:
         for name in self.param_names:
             self.offsets[name] = off
             off = _round_up(off + named[name].numel(), 4)
-        self.P = _round_up(off, 64)
+        self.P = _round_up(off, math.lcm(64, int(arena_align)))
         self.n_params = sum(v.numel() for v in named.values())
         # layers
         if self.stem_kind == "CIFAR":
@@ -174,22 +186,29 @@ class _Pool:
 
 
 class Engine:
-    def __init__(self, model, pixels, chunk, max_groups, compute_dtype=torch.bfloat16, device="cuda", fd_sets=0):
-        """``fd_sets``: extra per-chunk gradient/parameter sets for finite differences (0 none, 1 forward, 2 central)."""
+    def __init__(self, model, pixels, chunk, max_groups, compute_dtype=torch.bfloat16, device="cuda", fd_sets=0, arena_align=64,
+                 chunk_valid=None):
+        """``fd_sets``: extra per-chunk gradient/parameter sets for finite differences (0 none, 1 forward, 2 central).
+        ``chunk``: images per statistics group AS STORED; ``chunk_valid`` (default ``chunk``): the real images of a chunk.  A chunk size
+        whose pixels do not fill whole 128-pixel statistics blocks on every feature map (e.g. data.batch_size=125) is stored padded
+        to ``padded_chunk(...)`` images: the padding images are zeros with label -1, ``fb_bn_apply`` keeps them exactly zero after every
+        BatchNorm (so they add nothing to any statistic, weight gradient or loss) and all counts use ``chunk_valid``."""
         lib.load()
         if not torch.cuda.is_available():
             raise lib.EngineError("Engine needs an MI355X: no HIP device visible (there is no CPU path).")
         self.device = torch.device(device)
         self.dt = compute_dtype
         self.dtc = lib.dtype_code(compute_dtype)
-        self.plan = Plan(model, pixels)
+        self.plan = Plan(model, pixels, arena_align)
         self.chunk, self.G = chunk, max_groups
+        self.valid = chunk if chunk_valid is None else int(chunk_valid)
+        if not 0 < self.valid <= chunk:
+            raise lib.EngineError(f"chunk_valid={chunk_valid} outside (0, {chunk}]")
         for L in self.plan.layers:
             if (chunk * L.hout * L.wout) % 128 != 0:
-                raise lib.EngineError(f"chunk size {chunk} x {L.hout}x{L.wout} feature map of {L.conv_name}: pixels per chunk must be a "
-                                      "multiple of 128 (BN statistics are reduced in 128-pixel blocks that must not straddle chunks); "
-                                      "use a chunk size (data.batch_size / hyp.sub_batch) that is a multiple of "
-                                      f"{128 // math.gcd(128, L.hout * L.wout)}")
+                raise lib.EngineError(f"stored chunk size {chunk} x {L.hout}x{L.wout} feature map of {L.conv_name}: pixels per chunk must be "
+                                      "a multiple of 128 (BN statistics are reduced in 128-pixel blocks that must not straddle chunks); "
+                                      "pass chunk=padded_chunk(plan, n) and chunk_valid=n for other chunk sizes")
         P = self.plan.P
         f32 = dict(device=self.device, dtype=torch.float32)
         self.theta = torch.zeros(P, **f32)
@@ -212,11 +231,8 @@ class Engine:
         self.n_passes = 1 + fd_sets
         self.mean_tab = torch.zeros(self.n_passes, self.G, self.plan.ch_total, **f32)
         self.var_tab = torch.zeros(self.n_passes, self.G, self.plan.ch_total, **f32)
-        unbias = torch.ones(self.plan.ch_total)
-        for L in self.plan.layers:
-            m = chunk * L.hout * L.wout
-            unbias[L.ch_off:L.ch_off + L.cout] = m / (m - 1)
-        self.unbias = unbias.to(self.device)
+        self._unbias_tabs = {}
+        self.unbias = self._unbias_for(self.valid)
         self._alloc_activations()
         self.mt_ws = torch.zeros(lib.load().fb_ws_mt_floats(self.G), **f32)
         self.sq = torch.zeros(self.G, **f32)
@@ -231,6 +247,17 @@ class Engine:
         self._wgrad_event = None
         self.label_smoothing, self.only_incorrect = 0.0, False      # loss function of the head kernel (reference get_loss_fn)
         self.load_from_model(model)
+
+    def _unbias_for(self, batch):
+        """Bessel factors m/(m-1) per BN channel for BN batches of ``batch`` images (the running variance is the unbiased one)."""
+        tab = self._unbias_tabs.get(batch)
+        if tab is None:
+            unbias = torch.ones(self.plan.ch_total)
+            for L in self.plan.layers:
+                m = batch * L.hout * L.wout
+                unbias[L.ch_off:L.ch_off + L.cout] = m / (m - 1)
+            tab = self._unbias_tabs[batch] = unbias.to(self.device)
+        return tab
 
     # ------------------------------------------------------------------------------------------------------ buffers --
     def _alloc_activations(self):
@@ -402,7 +429,7 @@ class Engine:
         px = n * L.hout * L.wout
         n_mblocks = (px + 127) // 128
         pstride = self.plan.P if wsets > 1 else 0
-        call("fb_bn_fwd_finalize", self.stat_ws.data_ptr(), n_mblocks, G, L.cout, float(self.chunk * L.hout * L.wout),
+        call("fb_bn_fwd_finalize", self.stat_ws.data_ptr(), n_mblocks, G, L.cout, float(self.valid * L.hout * L.wout),
              theta.data_ptr() + 4 * L.g_off, theta.data_ptr() + 4 * L.b_off, pstride, BN_EPS,
              self.mean_tab[pidx].data_ptr(), self.var_tab[pidx].data_ptr(), self.plan.ch_total, L.ch_off,
              L.scale.data_ptr(), L.shift.data_ptr(), L.invstd.data_ptr())
@@ -411,7 +438,8 @@ class Engine:
         px = G * self.chunk * L.hout * L.wout
         call("fb_bn_apply", L.x.data_ptr(), out.data_ptr(), L.scale.data_ptr(), L.shift.data_ptr(), _ptr(res),
              resL.scale.data_ptr() if resL is not None else None, resL.shift.data_ptr() if resL is not None else None,
-             px, L.cout, self.chunk * L.hout * L.wout, 1 if relu else 0, _ptr(self._mask_of(out)) if relu else None, self.dtc)
+             px, L.cout, self.chunk * L.hout * L.wout, self.valid * L.hout * L.wout if self.valid < self.chunk else 0, 1 if relu else 0,
+             _ptr(self._mask_of(out)) if relu else None, self.dtc)
 
     def _mask_of(self, act):
         """ReLU bitmask buffer (1 byte per 16-byte vector) paired with a post-ReLU activation tensor, created on first use."""
@@ -477,7 +505,7 @@ class Engine:
         y = None if bits is not None else mask
         call("fb_bn_bwd_reduce", dout.data_ptr(), _ptr(y), _ptr(bits), L.x.data_ptr(), self.mean_tab[pidx].data_ptr(), L.invstd.data_ptr(),
              self.plan.ch_total, L.ch_off, self.stat_ws.data_ptr(), px, L.cout, ppg, self.dtc)
-        call("fb_bn_bwd_finalize", self.stat_ws.data_ptr(), n_mblocks, G, L.cout, float(ppg), L.scale.data_ptr(),
+        call("fb_bn_bwd_finalize", self.stat_ws.data_ptr(), n_mblocks, G, L.cout, float(self.valid * L.hout * L.wout), L.scale.data_ptr(),
              self.mean_tab[pidx].data_ptr(), L.invstd.data_ptr(), self.plan.ch_total, L.ch_off,
              gout.data_ptr() + 4 * L.g_off, gout.data_ptr() + 4 * L.b_off, self.plan.P, L.coef.data_ptr())
         dx = self.pool.get((n, L.hout, L.wout, L.cout))
@@ -607,7 +635,7 @@ class Engine:
 
     # --------------------------------------------------------------------------------------- full-batch gradient + step --
     def full_gradient(self, patches, labels, lr, block_strength=0.0, eps=1e-2, implementation="forward-differences",
-                      chunk_ids=None, counter0=0, acc_strength=0.0, after_pre_pass=None, pre_block=None):
+                      chunk_ids=None, counter0=0, acc_strength=0.0, after_pre_pass=None, pre_block=None, batch_clip=None):
         """Accumulate the regularised gradient over chunks (reference training.py:144-174) into ``self.avg``.
 
         ``patches``/``labels`` hold the whole resident dataset; chunk k = rows [k*chunk, (k+1)*chunk).  ``chunk_ids``
@@ -615,12 +643,18 @@ class Engine:
         ``after_pre_pass``: called once ``self.pre`` (the local mean of the ``acc_strength`` pre-pass) is complete -- the multi-GPU
         path turns it into the global mean there.  ``pre_block``: images per BN batch of the pre-pass when it differs from the
         chunk size (the reference's pre-pass runs whole loader blocks, its main loop ``sub_batch`` chunks; a multiple of ``chunk``).
+        ``batch_clip``: ``hyp.batch_clip`` -- every (regularised) chunk gradient is clipped to this L2 norm before it enters the running
+        mean (reference training.py:166-167, _clip_gradient_list training/utils.py:4-19; also the pre-pass blocks, :138-139);
+        ``self.clipped_all`` then holds the per-chunk 0/1 flags of the main loop.
         """
         chunk, P, G = self.chunk, self.plan.P, self.G
         n_chunks = patches.shape[0] // chunk if chunk_ids is None else len(chunk_ids)
         k_first = 0 if chunk_ids is None else chunk_ids[0]
         f32 = dict(device=self.device, dtype=torch.float32)
         loss_all, correct_all, sq_all = torch.empty(n_chunks, **f32), torch.empty(n_chunks, **f32), torch.empty(n_chunks, **f32)
+        self.clipped_all = torch.zeros(n_chunks, **f32) if batch_clip is not None else None
+        if batch_clip is not None and getattr(self, "clipped", None) is None:
+            self.clipped = torch.zeros(self.G, **f32)
         fd = block_strength != 0 or acc_strength != 0          # GradRegularizer.__init__, modules.py:150-152
         if fd:
             if implementation not in ("forward-differences", "forward-differences-legacy", "central-differences"):
@@ -641,30 +675,38 @@ class Engine:
             pre = self.pre
             pre.zero_()
             bsz = chunk if pre_block is None else int(pre_block)          # images per BN batch of the pre-pass
+            if bsz != chunk and self.valid != chunk:
+                raise NotImplementedError("acc_strength pre-pass over blocks of several sub_batch chunks with a padded (ragged) chunk size")
             per = bsz // chunk
             if bsz % chunk != 0 or n_chunks % per != 0 or per > G:
                 raise lib.EngineError(f"pre-pass blocks of {bsz} images do not tile {n_chunks} chunks of {chunk} (group {G})")
             n_batches, g_cap = n_chunks // per, G // per
+            saved_valid = self.valid
             self.chunk = bsz                                             # (as evaluate_batch does: all per-batch sizes follow self.chunk)
+            self.valid = bsz if bsz != chunk else saved_valid
             try:
                 done = 0
                 while done < n_batches:
                     g_n = min(g_cap, n_batches - done)
                     lo = k_first * chunk + done * bsz
                     self.group_gradient(patches[lo:lo + g_n * bsz], labels[lo:lo + g_n * bsz], g_n, self.g, 1, self.theta, 0)
+                    if batch_clip is not None:
+                        call("fb_mt_sqnorm", self.g.data_ptr(), P, g_n, P, 1.0, None, 0.0, self.sq.data_ptr(), self.mt_ws.data_ptr())
+                        call("fb_mt_chunk_clip", self.g.data_ptr(), P, g_n, P, self.sq.data_ptr(), float(batch_clip), None)
                     call("fb_mt_accumulate", pre.data_ptr(), self.g.data_ptr(), P, g_n, P, done, None, self.mt_ws.data_ptr())
                     call("fb_bn_running_update", self.running_mean.data_ptr(), self.running_var.data_ptr(), self.mean_tab.data_ptr(),
-                         self.var_tab.data_ptr(), 1, self.G * self.plan.ch_total, self.unbias.data_ptr(), g_n, self.plan.ch_total, BN_MOMENTUM)
+                         self.var_tab.data_ptr(), 1, self.G * self.plan.ch_total, self._unbias_for(self.valid).data_ptr(), g_n,
+                         self.plan.ch_total, BN_MOMENTUM)
                     self.num_batches_tracked += g_n
                     done += g_n
             finally:
-                self.chunk = chunk
+                self.chunk, self.valid = chunk, saved_valid
             if after_pre_pass is not None:
                 after_pre_pass()
         # With several groups per step the running-mean pass of group k (HBM-bound, 2 x G x 45 MB) runs on the weight-gradient stream
         # beside the forward convolutions of group k+1; the per-chunk gradients then alternate between two arenas (the main stream
         # writes dgamma / dbeta / fc gradients of group k+1 while group k is still being folded in).
-        overlap = (not fd) and self.wstream is not None and n_chunks > G and os.environ.get("FB_ACC_OVERLAP", "1") != "0"
+        overlap = (not fd) and batch_clip is None and self.wstream is not None and n_chunks > G and os.environ.get("FB_ACC_OVERLAP", "1") != "0"
         if overlap and getattr(self, "g_alt", None) is None:
             self.g_alt, self.acc_ws = torch.zeros_like(self.g), torch.zeros_like(self.mt_ws)
         done, group_idx = 0, 0
@@ -684,6 +726,10 @@ class Engine:
                     self.wstream.wait_event(ready)
                     call("fb_mt_accumulate", self.avg.data_ptr(), gbuf.data_ptr(), P, g_n, P, counter0 + done, sq_all.data_ptr() + 4 * done,
                          self.acc_ws.data_ptr())
+            elif not fd and batch_clip is not None:
+                call("fb_mt_sqnorm", self.g.data_ptr(), P, g_n, P, 1.0, None, 0.0, self.sq.data_ptr(), self.mt_ws.data_ptr())
+                call("fb_mt_chunk_clip", self.g.data_ptr(), P, g_n, P, self.sq.data_ptr(), float(batch_clip), self.clipped.data_ptr())
+                call("fb_mt_accumulate", self.avg.data_ptr(), self.g.data_ptr(), P, g_n, P, counter0 + done, None, self.mt_ws.data_ptr())
             elif not fd:
                 call("fb_mt_accumulate", self.avg.data_ptr(), self.g.data_ptr(), P, g_n, P, counter0 + done, self.sq.data_ptr(),
                      self.mt_ws.data_ptr())
@@ -707,13 +753,19 @@ class Engine:
                     self.prep_weights(self.theta_k, g_n, per_chunk=True)
                     self.group_gradient(xb, yb, g_n, self.g_fd[1], 2, self.theta_k, 2)
                     n_passes = 3
-                    call("fb_mt_fd_combine_accumulate", self.avg.data_ptr(), self.g.data_ptr(), self.g_fd[0].data_ptr(),
-                         self.g_fd[1].data_ptr(), P, g_n, P, self.eps_n.data_ptr(), cf, counter0 + done)
-                else:
-                    call("fb_mt_fd_combine_accumulate", self.avg.data_ptr(), self.g.data_ptr(), self.g_fd[0].data_ptr(),
-                         self.g.data_ptr(), P, g_n, P, self.eps_n.data_ptr(), cf, counter0 + done)
+                gb = self.g_fd[1] if central else self.g                 # vhp = (g(theta+) - g(theta-)) / eps_n  or  (g(theta+) - g) / eps_n
+                if batch_clip is None:
+                    call("fb_mt_fd_combine_accumulate", self.avg.data_ptr(), self.g.data_ptr(), self.g_fd[0].data_ptr(), gb.data_ptr(), P, g_n, P,
+                         self.eps_n.data_ptr(), cf, counter0 + done)
+                else:      # the regularised chunk gradients are materialised, clipped one by one, then averaged
+                    call("fb_mt_fd_combine", self.g.data_ptr(), self.g_fd[0].data_ptr(), gb.data_ptr(), P, g_n, P, self.eps_n.data_ptr(), cf)
+                    call("fb_mt_sqnorm", self.g.data_ptr(), P, g_n, P, 1.0, None, 0.0, self.vnorm2.data_ptr(), self.mt_ws.data_ptr())
+                    call("fb_mt_chunk_clip", self.g.data_ptr(), P, g_n, P, self.vnorm2.data_ptr(), float(batch_clip), self.clipped.data_ptr())
+                    call("fb_mt_accumulate", self.avg.data_ptr(), self.g.data_ptr(), P, g_n, P, counter0 + done, None, self.mt_ws.data_ptr())
             if not overlap:
                 sq_all[done:done + g_n].copy_(self.sq[:g_n])
+            if batch_clip is not None:
+                self.clipped_all[done:done + g_n].copy_(self.clipped[:g_n])
             call("fb_bn_running_update", self.running_mean.data_ptr(), self.running_var.data_ptr(), self.mean_tab.data_ptr(),
                  self.var_tab.data_ptr(), n_passes, self.G * self.plan.ch_total, self.unbias.data_ptr(), g_n, self.plan.ch_total,
                  BN_MOMENTUM)
@@ -808,14 +860,13 @@ class Engine:
             raise lib.EngineError("evaluate_batch: batch larger than the engine's activation buffers")
         self.prep_weights(self.theta, 1)
         for L in self.plan.layers:
-            gamma, beta = self.theta[L.g_off:L.g_off + L.cout], self.theta[L.b_off:L.b_off + L.cout]
-            rm, rv = self.running_mean[L.ch_off:L.ch_off + L.cout], self.running_var[L.ch_off:L.ch_off + L.cout]
-            sc = gamma * torch.rsqrt(rv + BN_EPS)
-            L.scale[0].copy_(sc)
-            L.shift[0].copy_(beta - rm * sc)
-        chunk, self.chunk, self._eval = self.chunk, n, True
+            call("fb_bn_eval_coeffs", self.theta.data_ptr() + 4 * L.g_off, self.theta.data_ptr() + 4 * L.b_off,
+                 self.running_mean.data_ptr() + 4 * L.ch_off, self.running_var.data_ptr() + 4 * L.ch_off, BN_EPS, L.scale.data_ptr(),
+                 L.shift.data_ptr(), L.cout)
+        saved = (self.chunk, self.valid)
+        self.chunk, self.valid, self._eval = n, n, True
         try:
             self.forward(patches, labels, 1, 1, self.theta, 0)
         finally:
-            self.chunk, self._eval = chunk, False
+            (self.chunk, self.valid), self._eval = saved, False
         return float(self.loss[0]), float(self.correct[0])

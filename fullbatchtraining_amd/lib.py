@@ -9,6 +9,7 @@ import os
 import torch
 
 FB_F32, FB_BF16 = 0, 1
+EXPECTED_ABI = 7          # fb_abi_version() the ctypes structs / signatures below were written for
 MT_BLOCKS = 1024
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libfbengine.so")
 
@@ -36,7 +37,7 @@ _SIGS = {
     "fb_weight_prep": [c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "fb_bn_fwd_finalize": [c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_i64, c_float, c_void_p, c_void_p, c_int,
                            c_int, c_void_p, c_void_p, c_void_p, c_void_p],
-    "fb_bn_apply": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_void_p, c_int, c_void_p],
+    "fb_bn_apply": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_i64, c_int, c_void_p, c_int, c_void_p],
     "fb_bn_running_update": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_void_p, c_int, c_int, c_float, c_void_p],
     "fb_bn_bwd_reduce": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_i64, c_int, c_i64, c_int, c_void_p],
     "fb_bn_bwd_finalize": [c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
@@ -57,6 +58,10 @@ _SIGS = {
     "fb_mt_fd_perturb": [c_void_p, c_void_p, c_i64, c_int, c_i64, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
                          c_void_p],
     "fb_mt_fd_combine_accumulate": [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_void_p, c_float, c_int, c_void_p],
+    "fb_mt_fd_combine": [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_void_p, c_float, c_void_p],
+    "fb_mt_chunk_clip": [c_void_p, c_i64, c_int, c_i64, c_void_p, c_float, c_void_p, c_void_p],
+    "fb_bn_eval_coeffs": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p],
+    "fb_head_tta": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "fb_mt_norms2": [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p],
     "fb_mt_clip_sgd": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_float, c_float, c_float, c_float, c_float, c_int, c_int, c_void_p],
     "fb_mt_scale": [c_void_p, c_i64, c_float, c_void_p],
@@ -110,6 +115,9 @@ def load():
             fn.argtypes, fn.restype = sig, c_int
         lib.fb_last_error_string.restype = C.c_char_p
         lib.fb_abi_version.restype = c_int
+        if lib.fb_abi_version() != EXPECTED_ABI:           # a stale in-tree .so would read the argument structs with another layout
+            raise EngineError(f"{_LIB_PATH} has ABI version {lib.fb_abi_version()}, this package expects {EXPECTED_ABI}: rebuild it with "
+                              "`python -m fullbatchtraining_amd.build --force`")
         lib.fb_ws_conv_stat_floats.argtypes, lib.fb_ws_conv_stat_floats.restype = [C.POINTER(ConvArgs)], c_i64
         lib.fb_ws_wgrad_slab_floats.argtypes, lib.fb_ws_wgrad_slab_floats.restype = [C.POINTER(WgradArgs)], c_i64
         lib.fb_ws_bn_partial_floats.argtypes, lib.fb_ws_bn_partial_floats.restype = [c_i64, c_int], c_i64

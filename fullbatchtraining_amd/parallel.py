@@ -192,3 +192,14 @@ def sharded_update(trainer, loss_k, correct_k, sq_k, lr, weight_decay=None):
     eng.num_batches_tracked += (plan.n_chunks - plan.count) * passes
     gathered = all_gather_chunk_stats(torch.stack([loss_k, correct_k, sq_k]), plan)        # one collective for the three statistics
     return gathered[0], gathered[1], gathered[2]
+
+
+def gather_sharded_state(trainer, group=None):
+    """After ``sharded_update`` a rank holds only ITS shard of the momentum and of the clipped averaged gradient.  Before a
+    checkpoint is written (rank 0 saves the whole ``momentum_buffer`` list, reference training/utils.py:43-49) or ``p.grad`` is
+    exposed (closure contract), the shards are all-gathered into the full arenas.  Collective: every rank calls it."""
+    eng, plan = trainer.engine, trainer.shard
+    n = eng.plan.P // plan.world
+    lo = plan.rank * n
+    for arena in (eng.mom, eng.avg):
+        dist.all_gather_into_tensor(arena, arena[lo:lo + n].clone(), group=group)

@@ -125,7 +125,16 @@ class _OptimizerWrapper:
 
     def __init__(self, optimizer):
         self.optim = optimizer
-        self.param_groups = optimizer.param_groups
+
+    @property
+    def param_groups(self):
+        """Always the wrapped optimizer's CURRENT list: ``Optimizer.load_state_dict`` replaces it, and the scheduler (which drives the
+        wrapped SGD) writes the lr there -- a reference held from construction would freeze the lr of a resumed SAM / LARS run."""
+        return self.optim.param_groups
+
+    @param_groups.setter
+    def param_groups(self, value):
+        self.optim.param_groups = value
 
     def __getstate__(self):
         return self.optim.__getstate__()
@@ -260,14 +269,19 @@ def _pass_indices(loader):
 
 
 def _stage(loader, device):
-    """Materialise a (static, unaugmented) loader as device-resident tensors in loader order (drop_last honoured)."""
+    """Materialise a (static, unaugmented) loader as tensors in loader order (drop_last honoured), on ``device`` -- or, with
+    ``device=None``, wherever they are (the trainer then moves only its own rank's slice into HBM)."""
     if isinstance(loader, (tuple, list)) and torch.is_tensor(loader[0]):
-        return loader[0].to(device), loader[1].to(device=device, dtype=torch.long)
-    xs, ys = [], []
-    for x, y in loader:
-        xs.append(x)
-        ys.append(y)
-    return torch.cat(xs).to(device), torch.cat(ys).to(device=device, dtype=torch.long)
+        X, Y = loader[0], loader[1]
+    else:
+        xs, ys = [], []
+        for x, y in loader:
+            xs.append(x)
+            ys.append(y)
+        X, Y = torch.cat(xs), torch.cat(ys)
+    if device is None:
+        return X, Y.to(dtype=torch.long)
+    return X.to(device), Y.to(device=device, dtype=torch.long)
 
 
 def _check_scope(cfg):
@@ -278,8 +292,8 @@ def _check_scope(cfg):
             and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
         raise NotImplementedError("grad_reg.acc_strength with sub_batch < batch_size on several ranks (the pre-pass runs whole blocks; "
                                   "chunk ranges of the ranks would have to be cut at block boundaries)")
-    if hyp.batch_clip is not None:
-        raise NotImplementedError("hyp.batch_clip: the reference's own full-batch loop fails on it (NameError in _record_stats)")
+    if hyp.batch_clip is not None and float(hyp.grad_clip_norm) != 2.0:
+        raise NotImplementedError("hyp.batch_clip with grad_clip_norm != 2 (the per-chunk clip kernel implements the L2 norm)")
     if hyp.grad_clip is not None and not float(hyp.grad_clip_norm) >= 1.0:
         raise NotImplementedError("grad_clip_norm must be a p-norm with p >= 1 (or inf)")
 
@@ -316,18 +330,20 @@ def _device_augmentation(cfg, trainloader):
 def _evaluate_batch(eng, xb, yb, test_time_flips):
     """Loss sum and #correct of one validation batch (reference training.py:365-380).  ``test_time_flips``: the reference feeds the SUM
     of the softmax outputs of the image and of its horizontal mirror to the loss function and the argmax (training.py:370-373); the
-    two forward passes run through the engine (the mirror is taken by the patch-gather kernel), the 10-way epilogue is host-side glue."""
+    two forward passes run through the engine (the mirror is taken by the patch-gather kernel), the epilogue is ``fb_head_tta``."""
     if not test_time_flips:
         l, c = eng.evaluate_batch(stem_patches(xb, eng.plan.stem, eng.dt), yb)
         return l * yb.shape[0], c
     n = xb.shape[0]
     eng.evaluate_batch(stem_patches(xb, eng.plan.stem, eng.dt), yb)
-    left = eng.logits[:n].softmax(dim=1)
+    left = eng.logits[:n].clone()
     mirror = torch.ones(n, dtype=torch.int8, device=xb.device)
     eng.evaluate_batch(stem_patches(xb.float().contiguous(), eng.plan.stem, eng.dt, aug=(None, None, mirror, 0, None)), yb)
-    outputs = left + eng.logits[:n].softmax(dim=1)
-    loss = torch.nn.functional.cross_entropy(outputs, yb)
-    return float(loss) * n, float((outputs.argmax(dim=-1) == yb).float().sum())
+    ws = torch.empty(2 * n + 2, device=xb.device, dtype=torch.float32)
+    lib.call("fb_head_tta", left.data_ptr(), eng.logits.data_ptr(), yb.data_ptr(), n, eng.plan.classes, ws.data_ptr(), ws.data_ptr() + 8 * n,
+             ws.data_ptr() + 8 * n + 4)
+    loss_sum, correct = ws[2 * n:].tolist()
+    return loss_sum, correct
 
 
 class FullBatchTrainer:
@@ -341,6 +357,9 @@ class FullBatchTrainer:
         self.loss_fn = get_loss_fn(cfg.hyp, cfg.data.batch_size)
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
         self.rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+        # the multi-process code path (collectives, sharded update); FB_FORCE_DIST=1 takes it with an initialised process group of ONE
+        # rank as well, which runs the real RCCL reduce-scatter / all-gather calls on a 1-GPU box (tests/test_gpu_sharded.py)
+        self.multi = self.world > 1 or (torch.distributed.is_initialized() and os.environ.get("FB_FORCE_DIST") == "1")
         # a shuffling train loader: the dataset stays resident in dataset order and every step regathers it in the order of a new
         # pass over the loader's batch sampler (reference: `for block, (inputs, labels) in enumerate(trainloader)` every step)
         self.shuffler = trainloader if _is_shuffling(trainloader) else None
@@ -349,7 +368,7 @@ class FullBatchTrainer:
             per_pass = len(trainloader.batch_sampler) * (trainloader.batch_size or 1) if trainloader.drop_last else len(trainloader.sampler)
             X, Y = Xall[:per_pass], Yall[:per_pass]                   # shapes only; the first step gathers the first permutation
         else:
-            X, Y = _stage(trainloader, self.device)
+            X, Y = _stage(trainloader, None)                         # only this rank's chunk range is copied to the device below
         block = min(cfg.data.batch_size, X.shape[0])
         chunks_in_block = max(block // cfg.hyp.sub_batch, 1)
         if block % chunks_in_block != 0:
@@ -367,25 +386,32 @@ class FullBatchTrainer:
             log.warning("grad_reg finite differences need matching fp32 passes (perturbation ~1e-6 per weight): running fp32.")
         from .parallel import ShardPlan, group_size
         self.shard = ShardPlan(self.n_chunks, self.world, self.rank)
-        from .engine import Plan, max_group
-        G = group_size(self.shard.count, int(cfg.impl.get("engine", {}).get("chunk_group", 98)),
-                       cap=max_group(Plan(model, X.shape[-1]), self.chunk, self.dtype))
-        self.engine = Engine(model, X.shape[-1], self.chunk, G, compute_dtype=self.dtype, device=self.device, fd_sets=fd_sets)
+        from .engine import Plan, max_group, padded_chunk
+        plan = Plan(model, X.shape[-1])
+        # chunk sizes that do not fill whole 128-pixel statistics blocks (data.batch_size=125: all 50 000 images in 400 chunks,
+        # reference data_preparation.py:64-72) are stored padded with zero images (label -1)
+        self.chunk_pad = padded_chunk(plan, self.chunk)
+        G = group_size(self.shard.count, int(cfg.impl.get("engine", {}).get("chunk_group", 98)), cap=max_group(plan, self.chunk_pad, self.dtype))
+        self.engine = Engine(model, X.shape[-1], self.chunk_pad, G, compute_dtype=self.dtype, device=self.device, fd_sets=fd_sets,
+                             arena_align=64 * self.world, chunk_valid=self.chunk)
         self.engine.label_smoothing = getattr(self.loss_fn, "smoothing", 0.0)
         self.engine.only_incorrect = getattr(self.loss_fn, "only_incorrect", False)
         stem = self.engine.plan.stem
         lo, hi = self.shard.first * self.chunk, (self.shard.first + self.shard.count) * self.chunk
-        self.patches = torch.empty(hi - lo, stem.hout, stem.wout, stem.cin_pad, device=self.device, dtype=self.dtype) if hi > lo else None
+        self.patches = torch.zeros(self.shard.count * self.chunk_pad, stem.hout, stem.wout, stem.cin_pad, device=self.device,
+                                   dtype=self.dtype) if hi > lo else None
         self.augment = _device_augmentation(cfg, trainloader)
         if self.shuffler is not None:
             if self.augment is not None:
                 raise NotImplementedError("a shuffling train loader together with impl.engine.device_augment")
             self._all_images, self._all_labels = Xall.float().contiguous(), Yall
-        self.images = X[lo:hi].float().contiguous() if (self.augment is not None and hi > lo) else None   # base images stay resident
+        mine = X[lo:hi].to(self.device) if (hi > lo and self.shuffler is None) else None
+        self.images = mine.float().contiguous() if (self.augment is not None and mine is not None) else None   # base images stay resident
         self._aug_step, self._n_total, self._lo = 0, X.shape[0], lo
-        if hi > lo and self.augment is None and self.shuffler is None:
-            stem_patches(X[lo:hi], stem, self.dtype, out=self.patches)
-        self.labels = Y[lo:hi].contiguous()
+        if mine is not None and self.augment is None:
+            self._gather_patches(mine)
+        del mine
+        self.labels = self._pad_labels(Y[lo:hi].to(self.device))
         # a validation DataLoader is read once through a private loader (its generator untouched); every validation pass then advances
         # that generator by the one base-seed draw the reference's pass over it makes (keeps shared generators aligned)
         self._valid_loader = validloader if isinstance(validloader, torch.utils.data.DataLoader) else None
@@ -406,18 +432,18 @@ class FullBatchTrainer:
             self._regather_shuffled()
         lr = self.optimizer.param_groups[0]["lr"]
         gr = hyp.grad_reg
-        if self.world > 1:
+        if self.multi:
             self._running0 = torch.stack([eng.running_mean, eng.running_var]).clone()
         mod = hyp.optim_modification.name
 
         def closure():
             """``gradient_evaluation`` (reference training.py:217-225) up to the clip, which is fused into the consumer of ``eng.avg``."""
             hook = None
-            if self.world > 1 and gr.acc_strength != 0:
+            if self.multi and gr.acc_strength != 0:
                 from .parallel import reduce_pre_pass
                 hook = lambda: reduce_pre_pass(self)          # noqa: E731
             out = eng.full_gradient(self.patches, self.labels, lr, gr.block_strength, gr.eps, gr.implementation, acc_strength=gr.acc_strength,
-                                    after_pre_pass=hook, pre_block=self.block)
+                                    after_pre_pass=hook, pre_block=self.block // self.chunk * self.chunk_pad, batch_clip=hyp.batch_clip)
             self._pre_sqnorm = None
             if gr.acc_strength != 0:             # |pre_grads|^2 for full_loss (reference training.py:98-101)
                 lib.call("fb_mt_norms2", eng.pre.data_ptr(), None, eng.plan.P, eng.norms2.data_ptr(), eng.mt_ws.data_ptr())
@@ -427,7 +453,7 @@ class FullBatchTrainer:
         # more than one rank: the plain step shards the update (reduce-scatter, shard-local clip + SGD, all-gather); the options that
         # need the whole averaged gradient on every rank all-reduce it instead and then run the 1-process code below, replicated
         noisy = hyp.grad_noise["additive"] is not None or hyp.grad_noise["multiplicative"] is not None
-        replicated = self.world > 1 and (mod == "SAM" or hyp.norm_bias.strength > 0 or hyp.only_linear_layers_weight_decay or noisy
+        replicated = self.multi and (mod == "SAM" or hyp.norm_bias.strength > 0 or hyp.only_linear_layers_weight_decay or noisy
                                          or (hyp.grad_clip is not None and float(hyp.grad_clip_norm) != 2.0))
         if replicated:
             from .parallel import replicated_reduce
@@ -438,10 +464,11 @@ class FullBatchTrainer:
                 return replicated_reduce(self, *local_closure())
 
         loss_k, correct_k, sq_k = closure()
-        if self.world > 1 and not replicated:
+        if self.multi and not replicated:
             from .parallel import sharded_update
             loss_k, correct_k, sq_k = sharded_update(self, loss_k, correct_k, sq_k, lr,
                                                     weight_decay=0.0 if mod in ("LARS", "LARC") else None)
+            self._state_is_sharded = True        # momentum / clipped gradient complete only on each rank's shard until gather_state()
         else:
             o = hyp.optim
 
@@ -466,7 +493,7 @@ class FullBatchTrainer:
                 for kind in ("additive", "multiplicative"):
                     if hyp.grad_noise[kind] is not None:
                         flat = eng.flatten([torch.randn_like(p) for p in self.model.parameters()])
-                        if self.world > 1:       # every rank must add the same noise: rank 0's draw
+                        if self.multi:       # every rank must add the same noise: rank 0's draw
                             torch.distributed.broadcast(flat, src=0)
                         eng.grad_noise(flat, hyp.grad_noise[kind], kind == "multiplicative")
                 return norms
@@ -493,6 +520,33 @@ class FullBatchTrainer:
         self._record_stats(loss_k, correct_k, sq_k, eng.norms2, lr, train_time)
         self.scheduler.step()
 
+    def _gather_patches(self, images, aug=None):
+        """Stem patches of this rank's images (chunk order) into ``self.patches``; with a padded chunk size every chunk's images go to
+        the head of its ``chunk_pad`` rows and the padding rows are (re)zeroed."""
+        stem = self.engine.plan.stem
+        if self.chunk_pad == self.chunk:
+            stem_patches(images, stem, self.dtype, aug=aug, out=self.patches)
+            return
+        dense = stem_patches(images, stem, self.dtype, aug=aug)
+        rows = self.patches.view(self.shard.count, self.chunk_pad, *self.patches.shape[1:])
+        rows[:, :self.chunk].copy_(dense.view(self.shard.count, self.chunk, *dense.shape[1:]))
+        rows[:, self.chunk:].zero_()
+
+    def _pad_labels(self, labels):
+        if self.chunk_pad == self.chunk:
+            return labels.contiguous()
+        out = torch.full((self.shard.count, self.chunk_pad), -1, dtype=torch.long, device=labels.device)
+        out[:, :self.chunk] = labels.view(self.shard.count, self.chunk)
+        return out.reshape(-1)
+
+    def gather_state(self):
+        """Make the momentum and the averaged-gradient arenas whole on every rank again after sharded updates (a collective; no-op
+        for one process or after a replicated update)."""
+        if getattr(self, "_state_is_sharded", False):
+            from .parallel import gather_sharded_state
+            gather_sharded_state(self)
+            self._state_is_sharded = False
+
     def _update(self, lr, zero_wd=False, grad_clip=None):
         """Clip + Nesterov SGD on the arena; per-tensor weight decay when the optimizer has one param group per tensor
         (``hyp.only_linear_layers_weight_decay``, reference optimizers.py:14-21)."""
@@ -507,13 +561,13 @@ class FullBatchTrainer:
         """A new pass over the shuffling train loader: its batch sampler gives this step's sample order (rank 0's draw on several
         ranks); this rank's slice of it is gathered from the resident dataset and turned into stem patches again."""
         idx = _pass_indices(self.shuffler).to(self.device)
-        if self.world > 1:
+        if self.multi:
             torch.distributed.broadcast(idx, src=0)
         lo, hi = self._lo, self._lo + self.shard.count * self.chunk
         mine = idx[lo:hi]
         if hi > lo:
-            stem_patches(self._all_images.index_select(0, mine), self.engine.plan.stem, self.dtype, out=self.patches)
-            self.labels = self._all_labels.index_select(0, mine).contiguous()
+            self._gather_patches(self._all_images.index_select(0, mine))
+            self.labels = self._pad_labels(self._all_labels.index_select(0, mine))
 
     def _regather_augmented(self):
         """A fresh RandomCrop offset / flip per image and step (the reference draws them in its DataLoader workers once per epoch =
@@ -530,7 +584,7 @@ class FullBatchTrainer:
             oy, ox = (off[i, lo:lo + n].to(self.device) for i in range(2))
         if a["flip_p"] > 0:
             fl = (torch.rand(self._n_total, generator=gen) < a["flip_p"]).to(torch.int8)[lo:lo + n].to(self.device)
-        stem_patches(self.images, self.engine.plan.stem, self.dtype, aug=(oy, ox, fl, a["crop_pad"], a["pad_value"]), out=self.patches)
+        self._gather_patches(self.images, aug=(oy, ox, fl, a["crop_pad"], a["pad_value"]))
 
     def _record_stats(self, loss_k, correct_k, sq_k, norms2, lr, train_time):
         """Same keys/formulas as reference training.py:85-119 and :205-211 (one host sync per step, after the update is queued)."""
@@ -558,6 +612,11 @@ class FullBatchTrainer:
         stats["param_norm"] += [param_norm.item()]
         stats["grad_norm"] += [full_grad_norm.sqrt().item()]
         stats["full_loss"] += [full_loss.item()]
+        if hyp.batch_clip is not None:           # the count the reference means to log (its own line, training.py:118, dies with a NameError)
+            clipped = self.engine.clipped_all.sum()
+            if self.multi:
+                torch.distributed.all_reduce(clipped)
+            stats["clipped_batches"] += [int(clipped.item())]
         if hyp.grad_clip is not None:
             grad_norm = gn2.sqrt().item()
             stats["preclip_gradnorm"] += [grad_norm]
@@ -706,13 +765,16 @@ def train(model, trainloader, validloader, setup, cfg):
                 log.info("Terminating training after fitting all datapoints.")
                 trainer.evaluate()
                 break
-        if trainer.rank == 0 and cfg.impl.checkpoint.name is not None:
+        if cfg.impl.checkpoint.name is not None:
             if (Counter.step - 1) % cfg.impl.checkpoint.save_every_nth_step == 0 or Counter.step >= cfg.hyp.steps:
-                file = os.path.join(cfg.original_cwd, "checkpoints", cfg.impl.checkpoint.name)
-                os.makedirs(os.path.dirname(file), exist_ok=True)
-                _save_to_checkpoint(model, optimizer, scheduler, None, Counter, file=file, engine=eng)
+                trainer.gather_state()           # every rank: the saved momentum buffers must be whole (sharded update)
+                if trainer.rank == 0:
+                    file = os.path.join(cfg.original_cwd, "checkpoints", cfg.impl.checkpoint.name)
+                    os.makedirs(os.path.dirname(file), exist_ok=True)
+                    _save_to_checkpoint(model, optimizer, scheduler, None, Counter, file=file, engine=eng)
         if cfg.dryrun:
             break
+    trainer.gather_state()
     eng.store_to_model(model, with_grad=True)    # closure contract: p.grad holds the last (clipped) full gradient
     _sync_optimizer_state(eng, model, optimizer)
     return stats

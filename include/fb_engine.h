@@ -111,8 +111,11 @@ int fb_bn_fwd_finalize(const float* stat_partial, int32_t n_mblocks, int32_t n_g
 /* y = relu?(x*scale[g][c] + shift[g][c] + residual)  residual: none | res | res*rscale[g][c]+rshift[g][c]
  * (BatchNorm2d + ReLU(inplace) + `out += identity`, resnets.py:217-228) */
 int fb_bn_apply(const void* x, void* y, const float* scale, const float* shift, const void* res, const float* rscale,
-                const float* rshift, int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t relu, void* mask_out,
-                int32_t dtype, void* stream);
+                const float* rshift, int64_t n_pixels, int32_t C, int64_t pixels_per_group, int64_t valid_pixels_per_group,
+                int32_t relu, void* mask_out, int32_t dtype, void* stream);
+/* valid_pixels_per_group (0 = all): chunk sizes that do not fill whole 128-pixel statistics blocks (data.batch_size=125, reference
+ * data_preparation.py:64-72) are stored padded with zero images; the pixels [valid, pixels_per_group) of every group are written as
+ * exact zeros with a clear mask, so they stay out of every later sum (statistics are divided by the REAL count). */
 /* mask_out (optional): ReLU mask, one byte per 16-byte vector of y (bit k = element k > 0).  The backward kernels accept it
  * in place of y (1/16 of the bytes).  When both `mask` and `y` are NULL no mask is applied (BN without ReLU). */
 /* sequential running-stat EMA for every BN channel of the network in one launch (momentum 0.1, unbiased var,
@@ -157,9 +160,18 @@ int fb_head_pool(const void* a, float* feat, int32_t n_img, int32_t HW, int32_t 
 /* fc + log_softmax + nll (mean over the chunk) + argmax-correct (training.py:78-80): logits, dlogits [n][classes],
  * loss[g], correct[g].  The loss functions of get_loss_fn (training.py:391-413): label_smoothing s -> LabelSmoothCrossEntropyLoss
  * (modules.py:86-101; s = 0 is CrossEntropyLoss), only_incorrect -> IncorrectCrossEntropyLoss (modules.py:104-119). */
+/* Rows with a NEGATIVE label are padding: no loss, no gradient, not counted in the mean or in `correct`. */
 int fb_head_loss(const float* feat, const float* fc_w, const float* fc_b, int64_t param_group_stride, const int64_t* labels,
                  float* logits, float* dlogits, float* loss, float* correct, int32_t n_groups, int32_t imgs_per_group,
                  int32_t C, int32_t classes, float label_smoothing, int32_t only_incorrect, void* stream);
+/* evaluation helpers (training.py:343-388): BN in eval mode as scale = gamma*rsqrt(running_var+eps), shift = beta - running_mean*scale
+ * (torch BatchNorm2d.eval()); and the test-time-flip epilogue (training.py:370-373): outputs = softmax(z_a) + softmax(z_b),
+ * loss_sum[0] = sum_n CE(outputs_n, label_n) (cross entropy applied to the summed probabilities, like the reference), correct[0] =
+ * #(argmax outputs == label). */
+int fb_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, float* scale,
+                      float* shift, int32_t C, void* stream);
+int fb_head_tta(const float* logits_a, const float* logits_b, const int64_t* labels, int32_t n, int32_t classes, float* ws /* 2n floats */,
+                float* loss_sum, float* correct, void* stream);
 /* dW_fc[g], db_fc[g] into the gradient arena and d_a = (dlogits @ W)/HW broadcast over the HW pixels */
 int fb_head_bwd(const float* feat, const float* dlogits, const float* fc_w, int64_t param_group_stride, float* dfc_w,
                 float* dfc_b, int64_t grad_group_stride, void* d_a, int32_t n_groups, int32_t imgs_per_group, int32_t HW,
@@ -184,6 +196,13 @@ int fb_mt_fd_perturb(const float* theta0, const float* g, int64_t group_stride, 
 /* vhp = (ga - gb)/eps_n[g]; gt = g + cf*vhp; avg += (gt-avg)/(counter0+j+1)   (modules.py:232-240 + training.py:45-47) */
 int fb_mt_fd_combine_accumulate(float* avg, const float* g, const float* ga, const float* gb, int64_t group_stride,
                                 int32_t n_groups, int64_t n, const float* eps_n, float cf, int32_t counter0, void* stream);
+/* The two halves of fb_mt_fd_combine_accumulate as separate steps, for hyp.batch_clip (training.py:166-167 clips the REGULARISED
+ * chunk gradient before it is averaged):  fb_mt_fd_combine: g[j] += cf*(ga[j]-gb[j])/eps_n[j] in place;
+ * fb_mt_chunk_clip (_clip_gradient_list, training/utils.py:4-19, p = 2): with norm = sqrt(sq[j]): if norm > clip then
+ * g[j] *= clip/(norm + 1e-6) and clipped[j] = 1 else clipped[j] = 0. */
+int fb_mt_fd_combine(float* g, const float* ga, const float* gb, int64_t group_stride, int32_t n_groups, int64_t n, const float* eps_n,
+                     float cf, void* stream);
+int fb_mt_chunk_clip(float* g, int64_t group_stride, int32_t n_groups, int64_t n, const float* sq, float clip, float* clipped, void* stream);
 /* out[0] = |a|^2, out[1] = |b|^2 over [0,n) (grad norm for clipping, training.py:202-204; param_norm, :92) */
 int fb_mt_norms2(const float* a, const float* b, int64_t n, float* out, float* ws, void* stream);
 /* clip (training.py:206-207) + torch.optim.SGD step with weight decay, momentum, dampening, Nesterov.

@@ -520,12 +520,14 @@ def _gradient_evaluation(spec, params, buffers, X, Y, hyp, lr, stats, chunk, q=i
         block_ids = range(n_blocks) if chunk_range is None else sorted({k * chunk // block for k in chunk_range})
         for counter, b in enumerate(block_ids):
             g0, _, _ = chunk_gradient(spec, params, buffers, X[b * block:(b + 1) * block], Y[b * block:(b + 1) * block], q)
+            if hyp.get("batch_clip") is not None:  # training.py:138-139
+                clip_gradient_list(g0, hyp["batch_clip"], hyp.get("grad_clip_norm", 2))
             for a, g in zip(pre, g0):
                 g.sub_(a)
                 a.add_(g, alpha=1 / (counter + 1))
     avg = [torch.zeros_like(p) for p in params.values()]
     grad_norms = torch.zeros(n_chunks, dtype=avg[0].dtype)
-    step_loss, step_preds, datapoints = 0.0, 0.0, 0
+    step_loss, step_preds, datapoints, clipped_batches = 0.0, 0.0, 0, 0
     ks = range(n_chunks) if chunk_range is None else chunk_range
     for counter, k in enumerate(ks):
         xk, yk = X[k * chunk:(k + 1) * chunk], Y[k * chunk:(k + 1) * chunk]
@@ -534,6 +536,8 @@ def _gradient_evaluation(spec, params, buffers, X, Y, hyp, lr, stats, chunk, q=i
         grad_norms[k] = sqnorm(grads)  # training.py:162
         grads = gradreg(spec, params, buffers, grads, xk, yk, lr, hyp["block_strength"], hyp["eps"],
                         hyp["implementation"], q, acc, pre)  # training.py:163
+        if hyp.get("batch_clip") is not None:  # training.py:166-167: the REGULARISED chunk gradient is clipped before it is averaged
+            clipped_batches += clip_gradient_list(grads, hyp["batch_clip"], hyp.get("grad_clip_norm", 2))
         for a, g in zip(avg, grads):  # _stable_mean_accumulation, training.py:45-47
             g.sub_(a)
             a.add_(g, alpha=1 / (counter + 1))
@@ -554,6 +558,8 @@ def _gradient_evaluation(spec, params, buffers, X, Y, hyp, lr, stats, chunk, q=i
     stats["param_norm"].append(float(param_norm))
     stats["grad_norm"].append(float(full_grad_norm.sqrt()))
     stats["full_loss"].append(float(full_loss))
+    if hyp.get("batch_clip") is not None:  # what training.py:117-118 means to record (the reference's line raises NameError: the counter is
+        stats["clipped_batches"].append(clipped_batches)  # a local of _accumulate_full_gradient, invisible inside _record_stats)
     # _modify_gradient_params, training.py:187-211: external norm bias, then the clip
     nb = hyp.get("norm_bias") or {}
     if nb.get("strength", 0.0) > 0.0:  # training.py:188-196
@@ -587,6 +593,20 @@ def _gradient_evaluation(spec, params, buffers, X, Y, hyp, lr, stats, chunk, q=i
         for g in avg:
             g.mul_(1 + gn["multiplicative"] * torch.randn_like(g))
     return avg
+
+
+def clip_gradient_list(grads, scaled_clip, norm_type=2, eps=1e-6):
+    """``_clip_gradient_list`` (reference training/utils.py:4-19): in-place clip of a gradient list to ``scaled_clip`` in the p-norm of the
+    per-tensor p-norms (or the max-abs for inf); returns 1 if it clipped."""
+    if float(norm_type) == float("inf"):
+        grad_norm = max(g.abs().max() for g in grads)
+    else:
+        grad_norm = torch.norm(torch.stack([torch.norm(g, float(norm_type)) for g in grads]), float(norm_type))
+    if grad_norm > scaled_clip:
+        for g in grads:
+            g.mul_(scaled_clip / (grad_norm + eps))
+        return 1
+    return 0
 
 
 def sgd_step(params, grads, momentum, lr, hyp):

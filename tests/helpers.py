@@ -29,7 +29,8 @@ def hyp_from_cfg(cfg):
                 grad_clip_norm=cfg.hyp.grad_clip_norm, norm_bias=dict(cfg.hyp.norm_bias), evaluate_ema=cfg.hyp.evaluate_ema,
                 eval_ema_momentum=cfg.hyp.eval_ema_momentum, test_time_flips=cfg.hyp.test_time_flips,
                 only_linear_layers_weight_decay=cfg.hyp.only_linear_layers_weight_decay, label_smoothing=cfg.hyp.label_smoothing,
-                loss_modification=cfg.hyp.loss_modification, grad_noise=dict(cfg.hyp.grad_noise), block=cfg.data.batch_size)
+                loss_modification=cfg.hyp.loss_modification, grad_noise=dict(cfg.hyp.grad_noise), block=cfg.data.batch_size,
+                batch_clip=cfg.hyp.batch_clip)
 
 
 def rel_err(a, b):

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), name
     assert set(lib.EXPORTS) == declared
-    assert handle.fb_abi_version() == 6
+    assert handle.fb_abi_version() == lib.EXPECTED_ABI
 
 
 def test_workspace_size_queries():

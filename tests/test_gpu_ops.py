@@ -187,7 +187,7 @@ def test_batchnorm_fwd_bwd(dtype, C, hw, ipg, groups):
     xd, resd, doutd = (nhwc(t).to(dtype).cuda() for t in (x, res, dout))
     y = torch.empty_like(xd)
     bits = torch.zeros(xd.numel() * xd.element_size() // 16, dtype=torch.uint8, device="cuda")
-    lib.call("fb_bn_apply", xd.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), resd.data_ptr(), None, None, px, C, ppg, 1,
+    lib.call("fb_bn_apply", xd.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), resd.data_ptr(), None, None, px, C, ppg, 0, 1,
              bits.data_ptr(), lib.dtype_code(dtype))
     # reference, per group
     ys, dxs, dgs, dbs = [], [], [], []

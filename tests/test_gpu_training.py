@@ -56,7 +56,11 @@ def _run(meta, name, extra=(), tmp_path=None, valid_full=False):
                                             ("fb_smooth", 8e-3, 2), ("fb_incorrect", 1e-2, 1),
                                             ("fb_clip_l1", 2e-4, 2),                                 # p-norm clip, p = 1
                                             # shuffling train loader (lr 0.4 without warm-up: the loss climbs 2.4 -> 3.9 -> 7.0 and fp32 noise with it; steps 1-2 agree to 3e-4)
-                                            ("fb_shuffle", 1e-2, 2)])
+                                            ("fb_shuffle", 1e-2, 2),
+                                            # round 2: per-chunk clip (hyp.batch_clip), chunk sizes off the 128-pixel statistics grid (stored padded
+                                            # with zero images), Bottleneck + finite differences (ResNet-50, standard stem, 64 px)
+                                            ("fb_batchclip", 2e-4, 2), ("fb_batchclip_gradreg", 8e-3, 2), ("fb_ragged", 2e-4, 3),
+                                            ("fb_ragged_gradreg", 8e-3, 2), ("fb_r50_gradreg", 8e-3, 2)])
 def test_train_matches_reference_run_f32(golden, name, tol, group, tmp_path):
     data, meta = golden
     cfg, model, stats = _run(meta, name, [f"impl.engine.chunk_group={group}"], tmp_path)
@@ -76,6 +80,8 @@ def test_train_matches_reference_run_f32(golden, name, tol, group, tmp_path):
             # 2.5 %, CPU oracle fp32: 7 % at step 3); only the first step is a sharp check of fb_mt_absmax2
             bound[1:] = 0.1 * np.abs(r64[1:])
         assert np.all(np.abs(np.array(stats[key]) - r64) <= bound), (key, stats[key], r32, r64)
+    if name == "fb_batchclip":       # the count the reference means to log: chunks whose (here: raw) norm exceeds the clip
+        assert stats["clipped_batches"] == [sum(1 for k in range(4) if data[f"{name}@f64/stat/grad_norm_train_{k}"][s] > 11.6) for s in range(3)]
     n_chunks = len([k for k in stats if k.startswith("grad_norm_train_")])
     assert n_chunks == meta["scenarios"][name]["n"] // min(cfg.data.batch_size, cfg.hyp.sub_batch)
     for k in range(n_chunks):

@@ -116,7 +116,9 @@ TRAIN_CASES = ["fb_plain", "fb_gradreg", "fb_clip_warm", "fb_gradreg_c32", "fb_c
                "fb_clip_l1",                    # p-norm clip, p = 1
                "fb_acc_sub",                    # acc_strength pre-pass over whole blocks, main loop over sub-chunks
                "fb_shuffle",                    # shuffling train loader: a new permutation (chunk composition) every step
-               "fb_noise"]                      # additive + multiplicative gradient noise from the seeded default generator; L-inf clip, norm bias, EMA / mirrored evaluation (scenarios_a9.npz)
+               "fb_noise",
+               # round 2 (scenarios_r2.npz): per-chunk clip, chunk sizes off the 128-pixel grid, Bottleneck + finite differences
+               "fb_batchclip", "fb_batchclip_gradreg", "fb_ragged", "fb_ragged_gradreg", "fb_r50_gradreg"]                      # additive + multiplicative gradient noise from the seeded default generator; L-inf clip, norm bias, EMA / mirrored evaluation (scenarios_a9.npz)
 
 
 @pytest.mark.parametrize("name", TRAIN_CASES)
@@ -124,7 +126,7 @@ def test_training_float64_pin(golden, name):
     """Multi-step run in float64: stats, per-chunk norms, final parameters/buffers all within 1e-7 of the reference."""
     data, meta = golden
     cfg, model, state, x, y = _setup(meta, name, F64)
-    spec = orc.Spec(cfg.model.depth)
+    spec = orc.Spec(cfg.model.depth, stem=cfg.model.stem)
     chunk = min(cfg.data.batch_size, cfg.hyp.sub_batch)
     if "noise" in name:
         torch.manual_seed(NOISE_SEED)
@@ -175,3 +177,40 @@ def test_lr_sequences(golden, hyp):
         sched.step()
     idx = [i for i in meta["lr_index"] if i < len(seq)]
     assert np.allclose([seq[i] for i in idx], meta["lr"][hyp], rtol=1e-12, atol=0)
+
+
+def test_clip_gradient_list_matches_reference(golden):
+    """`clip_gradient_list` (per-chunk clip of hyp.batch_clip) against the reference's `_clip_gradient_list` called directly
+    (training/utils.py:4-19) on a seeded list, for p = 2, 1, inf, clipping and not clipping."""
+    data, _ = golden
+    gen = torch.Generator().manual_seed(77)
+    base = [torch.randn(7, 5, generator=gen), torch.randn(11, generator=gen) * 3, torch.randn(2, 3, 3, 3, generator=gen) * 0.1]
+    assert np.array_equal(torch.cat([t.reshape(-1) for t in base]).numpy(), data["clip_list/input"])
+    for norm in (2.0, 1.0, float("inf")):
+        for clip in (0.5, 1e3):
+            grads = [t.clone() for t in base]
+            hit = orc.clip_gradient_list(grads, clip, norm)
+            assert hit == int(data[f"clip_list/p{norm}/clip{clip}/hit"][0]) == (1 if clip == 0.5 else 0)
+            assert np.allclose(torch.cat([t.reshape(-1) for t in grads]).numpy(), data[f"clip_list/p{norm}/clip{clip}"], rtol=1e-6, atol=0)
+
+
+def test_batch_clip_counts(golden):
+    """The count the reference means to log (its own stats line raises NameError): step 1 of fb_batchclip clips the two chunks whose
+    raw norm exceeds 11.6 (plain gradients: regularised == raw), later steps none."""
+    data, meta = golden
+    cfg, model, state, x, y = _setup(meta, "fb_batchclip", F64)
+    stats = orc.train(orc.Spec(18), state, x, y, hyp_from_cfg(cfg), cfg.hyp.steps, 32, cfg.hyp.scheduler, cfg.hyp.warmup)
+    want = [sum(1 for k in range(4) if data[f"fb_batchclip@f64/stat/grad_norm_train_{k}"][s] > 11.6) for s in range(3)]
+    assert stats["clipped_batches"] == want and want[0] == 2
+
+
+def test_checkpoint_interchange_recorded(golden):
+    """tests/golden/make_golden.py --r2 had the REFERENCE write a checkpoint that this package loaded and vice versa (file level,
+    ResNet-18, 90 MB each, not committed): all differences are exactly zero and the step / lr / scheduler position agree."""
+    _, meta = golden
+    rec = meta["checkpoint_interchange"]
+    assert rec["same_structure"] is True
+    for way, step in (("we_load_reference", 3), ("reference_loads_ours", 5)):
+        r = rec[way]
+        assert r["step"] == step and r["state_maxabs"] == 0.0 and r["momentum_maxabs"] == 0.0
+        assert r["lr"][0] == r["lr"][1] and r["sched_last_epoch"][0] == r["sched_last_epoch"][1] == step
