@@ -420,6 +420,7 @@ class FullBatchTrainer:
         else:
             self.valid = _stage(validloader, self.device) if validloader is not None else None
         self.stats = defaultdict(list)
+        self.enqueue_times = []
 
     # ------------------------------------------------------------------------------------------------------------------
     def step(self):
@@ -589,6 +590,7 @@ class FullBatchTrainer:
     def _record_stats(self, loss_k, correct_k, sq_k, norms2, lr, train_time):
         """Same keys/formulas as reference training.py:85-119 and :205-211 (one host sync per step, after the update is queued)."""
         hyp, stats = self.cfg.hyp, self.stats
+        self.enqueue_times.append(time.time() - train_time)         # everything of the step is queued; the read-back below waits for it
         pre2 = self._pre_sqnorm if getattr(self, "_pre_sqnorm", None) is not None else torch.zeros(1, device=norms2.device)
         host = torch.cat([loss_k, correct_k, sq_k, norms2, pre2]).cpu()
         K = self.n_chunks

@@ -159,8 +159,8 @@ def bn_train_fwd(x, gamma, beta, buffers, name, update):
     y = xhat * gamma[None, :, None, None] + beta[None, :, None, None]
     if update:
         rm, rv = buffers[f"{name}.running_mean"], buffers[f"{name}.running_var"]
-        rm.mul_(1 - BN_MOMENTUM).add_(mean, alpha=BN_MOMENTUM)
-        rv.mul_(1 - BN_MOMENTUM).add_(var * (n / (n - 1)), alpha=BN_MOMENTUM)
+        rm.mul_(1 - BN_MOMENTUM).add_(mean.detach(), alpha=BN_MOMENTUM)
+        rv.mul_(1 - BN_MOMENTUM).add_(var.detach() * (n / (n - 1)), alpha=BN_MOMENTUM)
         buffers[f"{name}.num_batches_tracked"] += 1
     return y, (xhat, invstd)
 
@@ -330,6 +330,18 @@ def chunk_gradient(spec, params, buffers, x, y, q=identity, update_bn=True):
     return [grads[name] for name in params], loss, correct
 
 
+def chunk_gradient_autograd(spec, params, buffers, x, y, q=identity, update_bn=True):
+    """The same quantity as ``chunk_gradient`` obtained the way the reference obtains it (training.py:76-83): the forward of this file
+    recorded by autograd, then ``torch.autograd.grad(loss, parameters)`` -- torch's own (oneDNN) backward kernels instead of the explicit
+    layer backward above.  Checked equal to the explicit path in tests/test_oracle_golden.py; it is the faster way to get a weight
+    gradient on CPU (``torch.nn.grad.conv2d_weight`` is slow), so bench.py's ``cpu_baseline`` times this one."""
+    leaves = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in params.items())
+    logits, _ = forward(spec, leaves, buffers, x, q, update_bn, train=True)
+    loss, correct, _ = cross_entropy_fwd_bwd(logits, y, getattr(spec, "label_smoothing", 0.0), getattr(spec, "only_incorrect", False))
+    grads = torch.autograd.grad(loss, list(leaves.values()))
+    return [g.detach() for g in grads], loss.detach(), correct
+
+
 def sqnorm(tensors):
     """``torch.stack([g.pow(2).sum() for g in grads]).sum()`` -- reference training.py:162, modules.py:223."""
     return torch.stack([t.pow(2).sum() for t in tensors]).sum()
@@ -343,7 +355,8 @@ IMPLEMENTATIONS = (
 )
 
 
-def gradreg(spec, params, buffers, grads, x, y, lr, block_strength, eps, implementation, q=identity, acc_strength=0.0, pre_grads=None):
+def gradreg(spec, params, buffers, grads, x, y, lr, block_strength, eps, implementation, q=identity, acc_strength=0.0, pre_grads=None,
+            chunk_gradient=chunk_gradient):
     """In-place modification of ``grads`` for one chunk; mirrors modules.py:211-241 / 243-264 / 266-300.
 
     Parameters are perturbed in place and restored exactly like the reference (clone/copy, or subtract for legacy).

@@ -103,8 +103,9 @@ def test_out_of_scope_options_raise():
         _check_scope(compose(["hyp=base_sgd"]))                    # stochastic branch
     _check_scope(compose(["hyp=fb1", "hyp.grad_reg.acc_strength=0.1"]))                       # supported: pre-pass over whole blocks
     _check_scope(compose(["hyp=fb1", "hyp.grad_reg.acc_strength=0.1", "data.batch_size=128", "hyp.sub_batch=32"]))   # ... also sub-chunked
+    _check_scope(compose(["hyp=fb1", "hyp.batch_clip=1.0"]))                                  # per-chunk L2 clip (fb_mt_chunk_clip)
     with pytest.raises(NotImplementedError):
-        _check_scope(compose(["hyp=fb1", "hyp.batch_clip=1.0"]))                              # broken in the reference itself
+        _check_scope(compose(["hyp=fb1", "hyp.batch_clip=1.0", "hyp.grad_clip_norm=inf"]))    # ... in the L2 norm only
     with pytest.raises(NotImplementedError):
         _check_scope(compose(["hyp=fbclip", "hyp.grad_clip_norm=0.5"]))                       # p-norms with p >= 1 (or inf)
     for ok in (["hyp=fbclip", "hyp.grad_clip_norm=inf"], ["hyp=fbclip", "hyp.grad_clip_norm=1"], ["hyp=fb1", "hyp.norm_bias.strength=0.1"], ["hyp=fb1", "hyp.evaluate_ema=True"],
@@ -114,6 +115,18 @@ def test_out_of_scope_options_raise():
     cfg.hyp.optim.name = "L-BFGS"
     with pytest.raises(NotImplementedError):
         optim_interface(torch.nn.Linear(2, 2), cfg.hyp)
+
+
+def test_padded_chunk_sizes():
+    """Chunk sizes as stored: whole 128-pixel statistics blocks on every feature map (data.batch_size=125 -> 128 images at 32 px)."""
+    from fullbatchtraining_amd.cfg import compose
+    from fullbatchtraining_amd.engine import Plan, padded_chunk
+    from fullbatchtraining_amd.models import construct_model
+
+    model = construct_model(compose([]).model, 3, 10)
+    assert padded_chunk(Plan(model, 32), 128) == 128 and padded_chunk(Plan(model, 32), 125) == 128 and padded_chunk(Plan(model, 32), 500) == 504
+    assert padded_chunk(Plan(model, 16), 25) == 32 and padded_chunk(Plan(model, 16), 32) == 32
+    assert Plan(model, 32, arena_align=64 * 7).P % 7 == 0 and Plan(model, 32).P % 64 == 0
 
 
 def test_group_cap_keeps_activations_in_32bit_range():

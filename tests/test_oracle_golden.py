@@ -214,3 +214,28 @@ def test_checkpoint_interchange_recorded(golden):
         r = rec[way]
         assert r["step"] == step and r["state_maxabs"] == 0.0 and r["momentum_maxabs"] == 0.0
         assert r["lr"][0] == r["lr"][1] and r["sched_last_epoch"][0] == r["sched_last_epoch"][1] == step
+
+
+@pytest.mark.parametrize("depth,stem,pixels", [(18, "CIFAR", 16), (50, "standard", 32)])
+def test_autograd_restatement_equals_explicit_backward(depth, stem, pixels):
+    """``chunk_gradient_autograd`` (torch's backward kernels, what bench.py's cpu_baseline times) == the explicit layer backward that is
+    pinned to the reference above: float64, gradients and BN buffer updates, with and without the regulariser."""
+    cfg = compose([f"model=resnet{depth}", f"model.stem={stem}"])
+    torch.manual_seed(5)
+    model = construct_model(cfg.model, 3, 10)
+    x, y = make_data(16, pixels)
+    outs = []
+    for fn in (orc.chunk_gradient, orc.chunk_gradient_autograd):
+        state = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+        params, buffers = orc.split_state(state)
+        spec = orc.Spec(depth, stem=stem)
+        g, loss, correct = fn(spec, params, buffers, x.double(), y)
+        reg = orc.gradreg(spec, params, buffers, [t.clone() for t in g], x.double(), y, 0.1, 0.5, 1e-2, "forward-differences", chunk_gradient=fn)
+        outs.append((g, float(loss), float(correct), reg, buffers))
+    (g0, l0, c0, r0, b0), (g1, l1, c1, r1, b1) = outs
+    assert l0 == pytest.approx(l1, rel=1e-12) and c0 == c1
+    cat = lambda ts: torch.cat([t.reshape(-1) for t in ts])      # noqa: E731
+    assert float((cat(g0) - cat(g1)).norm() / cat(g0).norm()) < 1e-11
+    assert float((cat(r0) - cat(r1)).norm() / cat(r0).norm()) < 1e-7
+    for k in b0:
+        assert torch.allclose(b0[k].double(), b1[k].double(), rtol=1e-9, atol=1e-12), k      # (the FD pass perturbs by eps_n * g: g differs in the last bits)
