@@ -154,10 +154,16 @@ def test_sharded_checkpoint_holds_whole_momentum(tmp_path):
     c1 = torch.load(os.path.join(out1, "checkpoints", "sharded.pth"), weights_only=False)
     c2 = torch.load(os.path.join(out2, "checkpoints", "sharded.pth"), weights_only=False)
     assert c1[4] == c2[4] == 3
+    worst = 0.0
     for idx, st in c1[0]["state"].items():
         a, b = st["momentum_buffer"], c2[0]["state"][idx]["momentum_buffer"]
-        scale = max(float(a.abs().max()), 1e-3)
-        assert float((a - b).abs().max()) < 2e-3 * scale, idx                 # zeros / stale values outside rank 0's shard would be O(scale)
+        # zeros / stale values outside rank 0's shard would be off by the tensor's own scale; the two runs themselves differ by fp32
+        # chunk-gradient noise (the ranks sum the full-batch gradient in another order), ~1e-3 of a typical momentum entry (1e-2)
+        scale = max(float(a.abs().max()), 2e-2)
+        worst = max(worst, float((a - b).abs().max()) / scale)
+        assert float((a - b).abs().max()) < 1e-2 * scale, idx
+        assert float(b.abs().max()) > 0.2 * float(a.abs().max()), idx         # not zeros
+    print(f"momentum buffers of the 2-rank checkpoint vs the 1-process one: worst relative difference {worst:.2e}")
     ref = torch.load(os.path.join(out1, "w1_r0.pt"))
     for r in range(2):
         got = torch.load(os.path.join(out2, f"w2_r{r}.pt"))
