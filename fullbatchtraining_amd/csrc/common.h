@@ -81,6 +81,52 @@ template <> __device__ __forceinline__ f32x4_t mma_chunk<float>(const uint4& a, 
     return c;
 }
 
+// ---- fp32 operands on the bf16 matrix pipe: three-way split, six products ("bf16x6") -------------------------------------
+// The exact-f32 MFMA (v_mfma_f32_16x16x4_f32) runs at 1/16 of the bf16 rate.  An fp32 value is EXACTLY the sum of three bf16
+// pieces x = h + m + l (8 significand bits each: h = bf16(x), m = bf16(x - h), l = bf16(x - h - m); both subtractions are exact in
+// fp32), so a product a*b = sum of nine piece products, each of them exact in fp32.  Keeping the six largest (hh, hm, mh, hl, lh,
+// mm; the dropped ml + lm + ll are below 2^-23 |ab|) and accumulating in the MFMA's fp32 accumulators gives fp32-class products at
+// 6/16 of the f32-MFMA time.  The finite-difference regulariser needs exactly that: emulating operand storage in the float64 oracle
+// shows that 16 significand bits (three products) put 14 % of error on the regularised gradient where fp32 puts 3.5 %
+// (tools/split_precision_experiment.py), because round(w + eps v) - round(w) must resolve a perturbation of 1e-4 |w|.
+// f32s_tag: fp32 STORAGE (all elementwise kernels see plain float), split arithmetic inside the convolution kernels.
+struct f32s_tag {};
+template <> struct ET<f32s_tag> : ET<float> {};
+struct split3_t { bf16x8_t h, m, l; };
+// eight fp32 values of one lane (two 16-byte chunks = its K-slots of a 32-deep step) -> three bf16x8 operands
+__device__ __forceinline__ split3_t split_f32x8(const uint4& c0, const uint4& c1) {
+    const unsigned w[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    unsigned hp[4], mp[4], lp[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float x0 = __uint_as_float(w[2 * q]), x1 = __uint_as_float(w[2 * q + 1]);
+        hp[q] = pack_bf16x2(x0, x1);
+        const float r0 = x0 - __uint_as_float(hp[q] << 16), r1 = x1 - __uint_as_float(hp[q] & 0xffff0000u);
+        mp[q] = pack_bf16x2(r0, r1);
+        const float s0 = r0 - __uint_as_float(mp[q] << 16), s1 = r1 - __uint_as_float(mp[q] & 0xffff0000u);
+        lp[q] = pack_bf16x2(s0, s1);
+    }
+    split3_t o;
+    o.h = __builtin_bit_cast(bf16x8_t, make_uint4(hp[0], hp[1], hp[2], hp[3]));
+    o.m = __builtin_bit_cast(bf16x8_t, make_uint4(mp[0], mp[1], mp[2], mp[3]));
+    o.l = __builtin_bit_cast(bf16x8_t, make_uint4(lp[0], lp[1], lp[2], lp[3]));
+    return o;
+}
+// six bf16 MFMAs, smallest terms first
+__device__ __forceinline__ f32x4_t mma_split6(const split3_t& a, const split3_t& b, f32x4_t c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.l, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, c, 0, 0, 0);
+    return c;
+}
+template <typename T> struct is_split { static constexpr bool value = false; };
+template <> struct is_split<f32s_tag> { static constexpr bool value = true; };
+// FB_F32_EXACT=1 (environment, read once): fp32 convolutions on the exact-f32 MFMA instead of the split path (A/B and reference)
+bool fb_f32_split_enabled();
+
 // Sum over the 16 lanes of a DPP row (lanes 16k..16k+15), result in every lane: four v_add_f32 with row_ror modifiers --
 // no LDS traffic (``__shfl_xor`` lowers to ds_bpermute_b32, which queues behind the fragment reads of the co-resident workgroup).
 __device__ __forceinline__ float row16_sum(float v) {

@@ -233,6 +233,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 h4_static_for<0, 4>([&](auto j) { pf0[decltype(j)::value] = h4_read16<(A * PITCH + h4_frag_rows<W>(decltype(j)::value)) * 128>(pa[B][0]); });
                 h4_static_for<0, 4>([&](auto i) { wf1[decltype(i)::value] = h4_read16<decltype(i)::value * 2048 + BUF * WT_BYTES>(wa[1]); });
                 h4_static_for<0, 4>([&](auto j) { pf1[decltype(j)::value] = h4_read16<(A * PITCH + h4_frag_rows<W>(decltype(j)::value)) * 128>(pa[B][1]); });
+                if constexpr (is_split<T>::value) {      // fp32 operands as three bf16 pieces each, six MFMAs per fragment pair (common.h)
+                    h4_wait_lgkmcnt<0>();
+                    split3_t sw[4], sp[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sw[i] = split_f32x8(wf0[i], wf1[i]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sp[j] = split_f32x8(pf0[j], pf1[j]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] = mma_split6(sw[i], sp[j], acc[i][j]);
+                } else {
                 h4_wait_lgkmcnt<8>();
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -243,6 +255,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = mma_chunk<T>(wf1[i], pf1[j], acc[i][j]);
+                }
                 if constexpr (U == 8) {
                     __builtin_amdgcn_s_barrier();         // every wave is done with this halo slice
                     if (more) {
@@ -398,7 +411,11 @@ int fb_try_conv3x3_halo4(const fb_conv_args* a, hipStream_t st) {
     p.trace = g_h4_trace;
 #endif
     dim3 grid(p.n_tiles < 2 * n_cu ? p.n_tiles : 2 * n_cu);
-    if (a->dtype == FB_F32) {
+    if (a->dtype == FB_F32 && fb_f32_split_enabled()) {
+        if (W == 32) hipLaunchKernelGGL((conv3x3s1_halo4_kernel<f32s_tag, 32>), grid, dim3(256), 0, st, p);
+        else if (W == 16) hipLaunchKernelGGL((conv3x3s1_halo4_kernel<f32s_tag, 16>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv3x3s1_halo4_kernel<f32s_tag, 8>), grid, dim3(256), 0, st, p);
+    } else if (a->dtype == FB_F32) {
         if (W == 32) hipLaunchKernelGGL((conv3x3s1_halo4_kernel<float, 32>), grid, dim3(256), 0, st, p);
         else if (W == 16) hipLaunchKernelGGL((conv3x3s1_halo4_kernel<float, 16>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv3x3s1_halo4_kernel<float, 8>), grid, dim3(256), 0, st, p);

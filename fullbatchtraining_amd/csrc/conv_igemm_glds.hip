@@ -164,6 +164,18 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(const ConvParams p, 
             static_for<0, FJ>([&](auto j) { pf0[decltype(j)::value] = lds_read16<decltype(j)::value * 2048>(p0); });
             static_for<0, FI>([&](auto i) { wf1[decltype(i)::value] = lds_read16<decltype(i)::value * 2048>(w1); });
             static_for<0, FJ>([&](auto j) { pf1[decltype(j)::value] = lds_read16<decltype(j)::value * 2048>(p1); });
+            if constexpr (is_split<T>::value) {      // fp32 operands as three bf16 pieces each, six MFMAs per fragment pair (common.h)
+                wait_lgkmcnt<0>();
+                split3_t sw[FI], sp[FJ];
+#pragma unroll
+                for (int i = 0; i < FI; ++i) sw[i] = split_f32x8(wf0[i], wf1[i]);
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) sp[j] = split_f32x8(pf0[j], pf1[j]);
+#pragma unroll
+                for (int i = 0; i < FI; ++i)
+#pragma unroll
+                    for (int j = 0; j < FJ; ++j) acc[i][j] = mma_split6(sw[i], sp[j], acc[i][j]);
+            } else {
             wait_lgkmcnt<FI + FJ>();                 // first half has landed (LDS returns in order)
 #pragma unroll
             for (int i = 0; i < FI; ++i)
@@ -174,6 +186,7 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(const ConvParams p, 
             for (int i = 0; i < FI; ++i)
 #pragma unroll
                 for (int j = 0; j < FJ; ++j) acc[i][j] = mma_chunk<T>(wf1[i], pf1[j], acc[i][j]);
+            }
             wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
         }
@@ -272,6 +285,7 @@ int fb_launch_igemm_glds(const ConvParams& p, int classes, int dtype, hipStream_
     const int EB = dtype == FB_F32 ? 4 : 2;
     const long long bytesA = (long long)p.n_img * p.Hs * p.Ws * p.Cs * EB, bytesW = (long long)p.Cd * p.R * p.S * p.Cs * EB;
     if (bytesA >= (1LL << 31) || bytesW >= (1LL << 31)) return 0;
-    if (dtype == FB_F32) launch<float>(p, classes, st); else launch<bf16_tag>(p, classes, st);
+    if (dtype == FB_F32) { if (fb_f32_split_enabled()) launch<f32s_tag>(p, classes, st); else launch<float>(p, classes, st); }
+    else launch<bf16_tag>(p, classes, st);
     return 1;
 }

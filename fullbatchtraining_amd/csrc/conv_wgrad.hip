@@ -23,6 +23,7 @@ struct WgradParams {
 template <typename T> struct WG;
 template <> struct WG<bf16_tag> { static constexpr int PAD = 16; };
 template <> struct WG<float> { static constexpr int PAD = 64; };
+template <> struct WG<f32s_tag> : WG<float> {};
 
 // transposed fragment: for channels c0..c0+15 (lane&15) and pixels pb + 8*(lane>>4) .. +7 (bf16) -> one 16-byte chunk
 template <typename T> __device__ __forceinline__ void load_frag_t(const char* tile, int row_bytes, int pb, int c0, int lane, uint4 (&out)[2]);
@@ -46,6 +47,10 @@ template <> __device__ __forceinline__ void load_frag_t<float>(const char* tile,
     for (int e = 0; e < 8; ++e) v[e] = *(const unsigned*)(a0 + 4 * e * row_bytes);
     out[0] = make_uint4(v[0], v[1], v[2], v[3]);
     out[1] = make_uint4(v[4], v[5], v[6], v[7]);
+}
+
+template <> __device__ __forceinline__ void load_frag_t<f32s_tag>(const char* tile, int row_bytes, int pb, int c0, int lane, uint4 (&out)[2]) {
+    load_frag_t<float>(tile, row_bytes, pb, c0, lane, out);
 }
 
 template <typename T, int WM, int WN, int WK, int KREP, int NJ>
@@ -125,6 +130,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
             for (int i = 0; i < 4; ++i) load_frag_t<T>(tileA, ROW_A, pb, wm * 64 + i * 16, lane, af[i]);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) load_frag_t<T>(tileB, ROW_B, pb, wn * 16 * NJ + j * 16, lane, bf[j]);
+            if constexpr (is_split<T>::value) {      // fp32 operands as three bf16 pieces each, six MFMAs per fragment pair (common.h)
+                split3_t sa[4], sb[NJ];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sa[i] = split_f32x8(af[i][0], af[i][1]);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) sb[j] = split_f32x8(bf[j][0], bf[j][1]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = mma_split6(sa[i], sb[j], acc[i][j]);
+            } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -132,6 +148,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
                     acc[i][j] = mma_chunk<T>(af[i][0], bf[j][0], acc[i][j]);
                     if constexpr (EB == 4) acc[i][j] = mma_chunk<T>(af[i][1], bf[j][1], acc[i][j]);
                 }
+            }
         }
     }
 
@@ -191,19 +208,23 @@ extern "C" int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream) {
     const int kstep = big ? (a->dtype == FB_F32 ? 32 : 64) : 128;
     p.px_per_split = (int)(ceil_div64(ceil_div64(p.px_per_group, a->split_k), kstep) * kstep);
     const int taps = a->R * a->S;
+    const bool split = fb_f32_split_enabled();
     const int prof = fb_prof_begin(FB_PROF_WGRAD, st);
     if (fb_try_wgrad3x3_v2(a, st) || fb_try_wgrad3x3(a, st)) {
     } else if (big) {
         dim3 grid((a->Cd / 128) * (a->Cs / 128), taps, n_groups * a->split_k);
-        if (a->dtype == FB_F32) hipLaunchKernelGGL((conv_wgrad_kernel<float, 2, 2, 1, 1, 4>), grid, dim3(256), 0, st, p);
+        if (a->dtype == FB_F32 && split) hipLaunchKernelGGL((conv_wgrad_kernel<f32s_tag, 2, 2, 1, 1, 4>), grid, dim3(256), 0, st, p);
+        else if (a->dtype == FB_F32) hipLaunchKernelGGL((conv_wgrad_kernel<float, 2, 2, 1, 1, 4>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_tag, 2, 2, 1, 2, 4>), grid, dim3(256), 0, st, p);
     } else if (a->Cs % 64 == 0) {
         dim3 grid((a->Cd / 64) * (a->Cs / 64), taps, n_groups * a->split_k);
-        if (a->dtype == FB_F32) hipLaunchKernelGGL((conv_wgrad_kernel<float, 1, 1, 4, 1, 4>), grid, dim3(256), 0, st, p);
+        if (a->dtype == FB_F32 && split) hipLaunchKernelGGL((conv_wgrad_kernel<f32s_tag, 1, 1, 4, 1, 4>), grid, dim3(256), 0, st, p);
+        else if (a->dtype == FB_F32) hipLaunchKernelGGL((conv_wgrad_kernel<float, 1, 1, 4, 1, 4>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_tag, 1, 1, 4, 1, 4>), grid, dim3(256), 0, st, p);
     } else {   // Cs multiple of 32 only (pre-gathered stem patches): 64 x 32 tiles
         dim3 grid((a->Cd / 64) * (a->Cs / 32), taps, n_groups * a->split_k);
-        if (a->dtype == FB_F32) hipLaunchKernelGGL((conv_wgrad_kernel<float, 1, 1, 4, 1, 2>), grid, dim3(256), 0, st, p);
+        if (a->dtype == FB_F32 && split) hipLaunchKernelGGL((conv_wgrad_kernel<f32s_tag, 1, 1, 4, 1, 2>), grid, dim3(256), 0, st, p);
+        else if (a->dtype == FB_F32) hipLaunchKernelGGL((conv_wgrad_kernel<float, 1, 1, 4, 1, 2>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_tag, 1, 1, 4, 1, 2>), grid, dim3(256), 0, st, p);
     }
     fb_prof_end(prof, st);

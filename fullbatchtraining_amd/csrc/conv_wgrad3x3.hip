@@ -21,6 +21,7 @@ struct Wgrad3Params {
 template <typename T> struct W3 { };
 template <> struct W3<bf16_tag> { static constexpr int PAD = 16; };
 template <> struct W3<float> { static constexpr int PAD = 64; };
+template <> struct W3<f32s_tag> : W3<float> {};
 
 // A operand: dY tile rows are the step's pixels in order
 template <typename T> __device__ __forceinline__ void frag_plain(const char* tile, int row_bytes, int pb, int c0, int lane, uint4 (&out)[2]);
@@ -80,6 +81,10 @@ template <int W> __device__ __forceinline__ void frag_halo_f32(const char* tile,
 }
 template <> __device__ __forceinline__ void frag_halo<float, 32>(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) { frag_halo_f32<32>(tile, row_bytes, pb, r, s, c0, lane, out); }
 template <> __device__ __forceinline__ void frag_halo<float, 16>(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) { frag_halo_f32<16>(tile, row_bytes, pb, r, s, c0, lane, out); }
+
+template <> __device__ __forceinline__ void frag_plain<f32s_tag>(const char* tile, int row_bytes, int pb, int c0, int lane, uint4 (&out)[2]) { frag_plain<float>(tile, row_bytes, pb, c0, lane, out); }
+template <> __device__ __forceinline__ void frag_halo<f32s_tag, 32>(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) { frag_halo_f32<32>(tile, row_bytes, pb, r, s, c0, lane, out); }
+template <> __device__ __forceinline__ void frag_halo<f32s_tag, 16>(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) { frag_halo_f32<16>(tile, row_bytes, pb, r, s, c0, lane, out); }
 
 template <typename T, int W>
 __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p) {
@@ -150,6 +155,19 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p
             uint4 af[4][2];
 #pragma unroll
             for (int i = 0; i < 4; ++i) frag_plain<T>(tileA, ROW, pb, i * 16, lane, af[i]);
+            if constexpr (is_split<T>::value) {      // fp32 operands as three bf16 pieces each, six MFMAs per fragment pair (common.h)
+                split3_t sa[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sa[i] = split_f32x8(af[i][0], af[i][1]);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    uint4 bf[2];
+                    frag_halo<T, W>(tileB, ROW, pb, t / 3, t % 3, wave * 16, lane, bf);
+                    const split3_t sb = split_f32x8(bf[0], bf[1]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[t][i] = mma_split6(sa[i], sb, acc[t][i]);
+                }
+            } else {
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 uint4 bf[2];
@@ -159,6 +177,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p
                     acc[t][i] = mma_chunk<T>(af[i][0], bf[0], acc[t][i]);
                     if constexpr (EB == 4) acc[t][i] = mma_chunk<T>(af[i][1], bf[1], acc[t][i]);
                 }
+            }
             }
         }
     }
@@ -192,7 +211,10 @@ int fb_try_wgrad3x3(const fb_wgrad_args* a, hipStream_t st) {
     p.imgs_per_group = a->imgs_per_group; p.split_k = a->split_k; p.imgs_per_block = (a->imgs_per_group + a->split_k - 1) / a->split_k;   // ragged last K slice allowed
     const int n_groups = a->n_img / a->imgs_per_group;
     dim3 grid((a->Cd / 64) * (a->Cs / 64), n_groups * a->split_k);
-    if (a->dtype == FB_F32) {
+    if (a->dtype == FB_F32 && fb_f32_split_enabled()) {
+        if (W == 32) hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32s_tag, 32>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32s_tag, 16>), grid, dim3(256), 0, st, p);
+    } else if (a->dtype == FB_F32) {
         if (W == 32) hipLaunchKernelGGL((conv_wgrad3x3_kernel<float, 32>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv_wgrad3x3_kernel<float, 16>), grid, dim3(256), 0, st, p);
     } else {

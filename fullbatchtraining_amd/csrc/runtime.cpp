@@ -1,4 +1,5 @@
 // Error string + optional per-kernel-class timing with HIP events on the launch stream (used by bench.py's roofline leg).
+#include <stdlib.h>
 #include <vector>
 
 #include "common.h"
@@ -19,6 +20,11 @@ extern "C" int64_t fb_ws_wgrad_slab_floats(const fb_wgrad_args* a) {
 }
 extern "C" int64_t fb_ws_bn_partial_floats(int64_t n_pixels, int32_t C) { return 2 * ((n_pixels + 127) / 128) * C; }
 extern "C" int64_t fb_ws_mt_floats(int32_t n_groups) { return (int64_t)(n_groups > 2 ? n_groups : 2) * FB_MT_BLOCKS; }
+
+bool fb_f32_split_enabled() {
+    static const bool on = getenv("FB_F32_EXACT") == nullptr || getenv("FB_F32_EXACT")[0] == '0';
+    return on;
+}
 
 namespace {
 struct Pair { hipEvent_t a, b; int cls; };
