@@ -96,6 +96,58 @@ def cpu_baseline(budget_s=24.0):
             "reference_in_build_container": "SURVEY.md section 6: the real reference, 8 threads: ~122 images/s (off), ~50 images/s (on)"}
 
 
+def side_configs(args, device, X, Y, main_trainer):
+    """Timed in the same run as the headline line (N = 1): BASELINE config 3 (GradRegularizer block_strength 0.5, forward differences,
+    fp32 passes) and the distance between the bf16 path that produced `value` and the fp32 path on the mean gradient of 16 chunks."""
+    from fullbatchtraining_amd.cfg import compose
+    from fullbatchtraining_amd.models import construct_model
+    from fullbatchtraining_amd.training import FullBatchTrainer
+
+    n_steps, warm = 2, 1
+    cfg = compose(["hyp=gradreg", "hyp.warmup=0", f"hyp.steps={n_steps + warm}", "hyp.grad_reg.block_strength=0.5",
+                   f"impl.engine.chunk_group={args.chunk_group}", "impl.mixed_precision=False", "data.augmentations_train="],
+                  original_cwd=os.path.join(ROOT, "gpurun_out"), name="bench_gradreg")
+    torch.manual_seed(1)
+    model = construct_model(cfg.model, 3, 10)
+    setup = dict(device=device, dtype=torch.float, memory_format=torch.contiguous_format)
+    tr = FullBatchTrainer(model, (X, Y), None, setup, cfg)
+    for _ in range(warm):
+        tr.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        tr.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n_steps
+    flop = 2 * 3328997376 * tr.datapoints
+    out = {"configs": {"gradreg": {
+        "workload": f"ResNet-18 CIFAR-10 full-batch GD step + GradRegularizer block_strength=0.5 (forward differences, eps 1e-2), {tr.n_chunks} chunks x "
+                    f"{tr.chunk}, fp32 storage; convolutions on the bf16 matrix pipe with an exact three-way split of every fp32 operand (bf16x6)",
+        "ms_per_step": round(1000 * dt, 1), "value": round(tr.datapoints / dt, 1), "unit": "images/s", "steps": n_steps, "warmup": warm, "dtype": "f32",
+        "tflops": round(flop / dt / 1e12, 1),
+        "roofline": {"bound": "mfma", "peak": PEAK_BF16_TFLOPS / 6, "unit": "TFLOP/s (fp32-equivalent: six bf16 MFMAs per fp32 product)",
+                     "achieved": round(flop / dt / 1e12, 1), "frac": round(flop / dt / 1e12 / (PEAK_BF16_TFLOPS / 6), 4),
+                     "frac_of_f32_mfma_peak": round(flop / dt / 1e12 / PEAK_F32_TFLOPS, 4)}}}}
+    # bf16 vs fp32 on the mean gradient of the first 16 chunks at the benchmark's parameters (tests/test_gpu_bf16_parity.py)
+    K = 16
+    e16, e32 = main_trainer.engine, tr.engine
+    e32.theta.copy_(e16.theta), e32.running_mean.copy_(e16.running_mean), e32.running_var.copy_(e16.running_var)
+    res = []
+    for eng, t in ((e16, main_trainer), (e32, tr)):
+        rm, rv, nbt = eng.running_mean.clone(), eng.running_var.clone(), eng.num_batches_tracked
+        eng.full_gradient(t.patches[:K * t.chunk_pad], t.labels[:K * t.chunk_pad], 0.1)
+        eng.running_mean.copy_(rm), eng.running_var.copy_(rv)
+        eng.num_batches_tracked = nbt
+        res.append(eng.avg.double().clone())
+    a, b = res[1], res[0]
+    out["parity"] = {"bf16_vs_f32_mean_gradient_rel_l2": round(float((a - b).norm() / a.norm()), 4),
+                     "cosine": round(float((a * b).sum() / (a.norm() * b.norm())), 5), "chunks": K,
+                     "note": "error of the bf16 path on the MEAN gradient of 16 chunks at the benchmark's current parameters; it is noise, not bias: "
+                             "0.22 / 0.15 / 0.08 / 0.04 at K = 1 / 4 / 16 / 64 chunks (tests/test_gpu_bf16_parity.py), f32 path vs float64 oracle "
+                             "2.5e-6..2e-3 (tests/test_gpu_engine.py)"}
+    return out
+
+
 def self_launch(n_gpus):
     """Run this script as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>` in a child
     process and pass its output through.  Nothing in the calling process may have initialised the GPU."""
@@ -138,6 +190,7 @@ def main():
     ap.add_argument("--stem", default="CIFAR", choices=["CIFAR", "standard"])
     ap.add_argument("--pixels", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-configs", action="store_true", help="skip the grad_reg (BASELINE config 3) timing and the bf16 parity figure")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--serialize", action="store_true",
                     help="run the weight-gradient kernels on the main stream and take the per-kernel HIP-event timings inside the "
@@ -198,7 +251,6 @@ def main():
     model = construct_model(cfg.model, 3, 10)
     setup = dict(device=device, dtype=torch.float, memory_format=torch.contiguous_format)
     trainer = FullBatchTrainer(model, (X, Y), None, setup, cfg)
-    del X
     eng = trainer.engine
 
     def sync():
@@ -209,7 +261,7 @@ def main():
     for _ in range(args.warmup):
         trainer.step()
     timing = not args.no_kernel_timing
-    if timing and args.serialize:
+    if timing:            # HIP events around every convolution launch, on its launch stream, INSIDE the timed region
         lib.profile_enable(True, 65536)
     sync()
     t0 = time.perf_counter()
@@ -217,19 +269,18 @@ def main():
         trainer.step()
     sync()
     elapsed = time.perf_counter() - t0
-    prof, prof_steps = None, args.steps
-    if timing and not args.serialize:
-        # In the timed region the weight-gradient kernels run on their own stream, concurrently with dgrad / BN backward, so a
-        # HIP-event bracket around a launch there measures a kernel sharing the GPU.  The roofline figures come from one more
-        # step of the same workload with that stream folded into the main one (each kernel alone on the device).
-        saved, eng.wstream = eng.wstream, None
-        lib.profile_enable(True, 65536)
-        trainer.step()
-        sync()
-        eng.wstream = saved
-        prof_steps = 1
+    prof, prof_iso = None, None
     if timing:
         prof = lib.profile_read()
+        if not args.serialize:
+            # In the timed region the weight-gradient kernels run on their own stream beside dgrad / BN backward, so an event bracket there
+            # times a kernel that shares the GPU.  One more step of the same workload with that stream folded into the main one gives
+            # the duration of each kernel alone on the device ("isolated"), which is what the rocprofv3 summaries in profiles/ show.
+            saved, eng.wstream = eng.wstream, None
+            trainer.step()
+            sync()
+            eng.wstream = saved
+            prof_iso = lib.profile_read()
         lib.profile_enable(False)
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:
@@ -259,16 +310,19 @@ def main():
                                 "forward/backward passes, running mean, clip + SGD update, statistics read-back",
         }
         if prof is not None:
-            n_local = trainer.shard.count * trainer.chunk * prof_steps * passes
-            flops = conv_flops(eng.plan, n_local)
             peak = PEAK_BF16_TFLOPS if trainer.dtype == torch.bfloat16 else PEAK_F32_TFLOPS
-            kernels = {}
-            for k, (ms, launches, dropped) in prof.items():
-                if launches:
-                    scale = launches / max(launches + dropped, 1)
-                    kernels[k] = {"ms_total": round(ms, 2), "launches": launches, "dropped": dropped,
-                                  "avg_launch_us": round(1000 * ms / launches, 2),
+
+            def per_class(table, n_steps):
+                flops = conv_flops(eng.plan, trainer.shard.count * trainer.chunk * n_steps * passes)
+                res = {}
+                for k, (ms, launches, dropped) in table.items():
+                    if launches:
+                        scale = launches / max(launches + dropped, 1)
+                        res[k] = {"ms_total": round(ms, 2), "launches": launches, "dropped": dropped, "avg_launch_us": round(1000 * ms / launches, 2),
                                   "tflops": round(flops[k] * scale / (ms * 1e-3) / 1e12, 1)}
+                return res, flops
+
+            kernels, flops = per_class(prof, args.steps)
             dom = max(kernels, key=lambda k: kernels[k]["ms_total"])
             # HBM bytes per launch of the same kernel class from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, one counter per rocprofv3
             # pass as MI355X_MICROARCH.md prescribes; tools/pmc_bench.sh writes the file, profiles/ keeps the copy behind the number)
@@ -284,10 +338,13 @@ def main():
                                "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                                "flop_per_launch": flops[dom] / max(kernels[dom]["launches"] + kernels[dom]["dropped"], 1),
                                "avg_launch_us": kernels[dom]["avg_launch_us"], "kernels": kernels,
-                               "measured": "HIP events inside the timed region (--serialize)" if args.serialize else
-                                           "HIP events over one extra step after the timed region, weight-gradient stream folded into the "
-                                           "main stream (inside the timed region wgrad overlaps dgrad/BN backward)",
+                               "measured": "HIP events on the launch stream around every launch of the class, inside the timed region"
+                                           + (" (--serialize: one stream)" if args.serialize else " (production schedule: weight-gradient kernels "
+                                              "run on a second stream beside these launches; `isolated` = the same from one extra step with one stream)"),
+                               "isolated": per_class(prof_iso, 1)[0] if prof_iso is not None else None,
                                "step_mfma_frac": round((3328997376 if headline else sum(conv_flops(eng.plan, 1).values())) * passes * images_per_step * steps_per_sec / world / (peak * 1e12), 4)}
+        if world == 1 and headline and args.grad_reg == 0 and trainer.dtype == torch.bfloat16 and not args.no_side_configs:
+            out.update(side_configs(args, device, X, Y, trainer))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
