@@ -112,15 +112,22 @@ __device__ __forceinline__ split3_t split_f32x8(const uint4& c0, const uint4& c1
     o.l = __builtin_bit_cast(bf16x8_t, make_uint4(lp[0], lp[1], lp[2], lp[3]));
     return o;
 }
-// six bf16 MFMAs, smallest terms first
+// Six bf16 MFMAs, smallest terms first, into a ZERO-started accumulator; the 32-deep partial sum is then added to the running
+// accumulator with v_add_f32 (round to nearest even).  Measured on one 16x16 block with K = 4608 against float64
+// (tools/mfma_accum_probe.hip): accumulating the six products straight into the running sum has the L2 error of the exact-f32 MFMA
+// chain (1.1e-6 vs 1.2e-6) but twice its one-sided bias (-3.4e-7: the matrix pipe truncates small addends against a large
+// accumulator), and that bias is what a BN-normalised gradient amplifies (chunk gradient 1e-3..5e-3 from float64 instead of
+// 2.5e-6..2e-3); zero-started, the same products give 2.2e-7 with a bias of -2.5e-8 -- five times tighter than the exact-f32 chain,
+// whose rounding happens every 4 terms instead of every 32.  All nine products instead of six change nothing (2.2e-7).
 __device__ __forceinline__ f32x4_t mma_split6(const split3_t& a, const split3_t& b, f32x4_t c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b.h, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.l, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.m, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.h, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.m, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, c, 0, 0, 0);
-    return c;
+    f32x4_t t = {0.f, 0.f, 0.f, 0.f};
+    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b.h, t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.l, t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.m, t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.h, t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.m, t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, t, 0, 0, 0);
+    return c + t;
 }
 template <typename T> struct is_split { static constexpr bool value = false; };
 template <> struct is_split<f32s_tag> { static constexpr bool value = true; };

@@ -126,6 +126,11 @@ class Plan:
                 self.blocks.append(Block(convs, shortcut, stride, cin, h, h))
                 cin, h = cout, convs[-1].hout
         self.feat, self.h_final = cin, h
+        # "late bucket" of the arena: the parameters of the last stage and the classifier.  The backward pass finishes their gradients
+        # first (it walks the blocks in reverse), so their share of the gradient exchange can start while it is still working on the
+        # earlier stages (parallel.BucketExchange).  late_block = index of the first block of the last stage.
+        self.late_block = sum(len(stage) for stage in list(model.layers)[:-1])
+        self.late_offset = self.offsets[f"layers.{len(model.layers) - 1}.0.conv1.weight"]
         self.layers = [self.stem] + [c for b in self.blocks for c in b.convs + ([b.shortcut] if b.shortcut else [])]
         # execution-order independent tables: BN channel table follows state_dict order of BN modules
         order = {name: i for i, name in enumerate(self.param_names)}
@@ -563,8 +568,9 @@ class Engine:
         a = self._dgrad_args(L, one, one, one, one, G, wsets, 1, one)
         return bool(lib.load().fb_conv_masked_addend_supported(lib.C.byref(a)))
 
-    def backward(self, patches, G, wsets, theta, gout, pidx):
-        """Explicit backward through the DAG; per-chunk gradients are written to ``gout[g]`` (shape [G, P])."""
+    def backward(self, patches, G, wsets, theta, gout, pidx, on_block_done=None):
+        """Explicit backward through the DAG; per-chunk gradients are written to ``gout[g]`` (shape [G, P]).  ``on_block_done(bi)`` is
+        called when every launch that writes the gradients of block ``bi`` (and of everything after it) has been queued."""
         plan, pool = self.plan, self.pool
         n = G * self.chunk
         hw = plan.h_final * plan.h_final
@@ -613,6 +619,8 @@ class Engine:
             pool.put(cur_dx, event=ev_cur)
             pool.put(d if lazy else dy)
             d = d_in
+            if on_block_done is not None:
+                on_block_done(bi)
         S = plan.stem
         if plan.stem_pool:
             d_r = pool.get((n, S.hout, S.wout, 64))
@@ -627,15 +635,15 @@ class Engine:
             torch.cuda.current_stream().wait_stream(self.wstream)
 
     # ------------------------------------------------------------------------------------------- chunk-group gradient --
-    def group_gradient(self, patches, labels, G, gout, wsets=1, theta=None, pidx=0):
+    def group_gradient(self, patches, labels, G, gout, wsets=1, theta=None, pidx=0, on_block_done=None):
         """fwd + bwd for ``G`` chunks: per-chunk raw gradients in gout[:G], losses/corrects in self.loss/self.correct."""
         theta = self.theta if theta is None else theta
         self.forward(patches, labels, G, wsets, theta, pidx)
-        self.backward(patches, G, wsets, theta, gout, pidx)
+        self.backward(patches, G, wsets, theta, gout, pidx, on_block_done)
 
     # --------------------------------------------------------------------------------------- full-batch gradient + step --
     def full_gradient(self, patches, labels, lr, block_strength=0.0, eps=1e-2, implementation="forward-differences",
-                      chunk_ids=None, counter0=0, acc_strength=0.0, after_pre_pass=None, pre_block=None, batch_clip=None):
+                      chunk_ids=None, counter0=0, acc_strength=0.0, after_pre_pass=None, pre_block=None, batch_clip=None, late_bucket=None):
         """Accumulate the regularised gradient over chunks (reference training.py:144-174) into ``self.avg``.
 
         ``patches``/``labels`` hold the whole resident dataset; chunk k = rows [k*chunk, (k+1)*chunk).  ``chunk_ids``
@@ -646,6 +654,10 @@ class Engine:
         ``batch_clip``: ``hyp.batch_clip`` -- every (regularised) chunk gradient is clipped to this L2 norm before it enters the running
         mean (reference training.py:166-167, _clip_gradient_list training/utils.py:4-19; also the pre-pass blocks, :138-139);
         ``self.clipped_all`` then holds the per-chunk 0/1 flags of the main loop.
+        ``late_bucket = (b, started)``: multi-GPU overlap of the exchange with the backward pass.  As soon as the LAST backward pass of the
+        LAST chunk group has left the last stage, the slice [b, P) of the running mean (last stage + classifier, 3/4 of ResNet-18's
+        parameters) is completed on a side stream and ``started()`` is called there (the caller starts that bucket's reduce-scatter);
+        the slice [0, b) follows at the end as usual.
         """
         chunk, P, G = self.chunk, self.plan.P, self.G
         n_chunks = patches.shape[0] // chunk if chunk_ids is None else len(chunk_ids)
@@ -710,13 +722,44 @@ class Engine:
         if overlap and getattr(self, "g_alt", None) is None:
             self.g_alt, self.acc_ws = torch.zeros_like(self.g), torch.zeros_like(self.mt_ws)
         done, group_idx = 0, 0
+        if late_bucket is not None and getattr(self, "side", None) is None:
+            self.side = torch.cuda.Stream(device=self.device)
+            self.sq_late, self.ws_late = torch.zeros_like(self.sq), torch.zeros_like(self.mt_ws)
         while done < n_chunks:
             g_n = min(G, n_chunks - done)
             lo = (k_first + done) * chunk
             xb, yb = patches[lo:lo + g_n * chunk], labels[lo:lo + g_n * chunk]
             gbuf = self.g_alt if (overlap and group_idx & 1) else self.g
             group_idx += 1
-            self.group_gradient(xb, yb, g_n, gbuf, 1, self.theta, 0)
+            # early completion of the late bucket: only for the last group, and only where the running mean is folded in one piece
+            early = late_bucket is not None and done + g_n == n_chunks and not overlap and batch_clip is None
+            lb = late_bucket[0] if early else 0
+            central = fd and implementation == "central-differences"
+            legacy = fd and implementation == "forward-differences-legacy"
+            cf = (lr / 4 * (block_strength if legacy else 1.0)) if fd else 0.0
+
+            def finish_late(bi, _g_n=g_n, _done=done):
+                """Called by the last backward pass of the group: gradients of the arena slice [lb, P) are complete."""
+                if bi != self.plan.late_block:
+                    return
+                ready = [torch.cuda.current_stream().record_event()]
+                if self.wstream is not None:
+                    ready.append(self.wstream.record_event())
+                with torch.cuda.stream(self.side):
+                    for ev in ready:
+                        self.side.wait_event(ev)
+                    n_late = P - lb
+                    if not fd:
+                        call("fb_mt_accumulate", self.avg.data_ptr() + 4 * lb, self.g.data_ptr() + 4 * lb, P, _g_n, n_late, counter0 + _done,
+                             self.sq_late.data_ptr(), self.ws_late.data_ptr())
+                    else:
+                        gb = self.g_fd[1] if central else self.g
+                        call("fb_mt_fd_combine_accumulate", self.avg.data_ptr() + 4 * lb, self.g.data_ptr() + 4 * lb, self.g_fd[0].data_ptr() + 4 * lb,
+                             gb.data_ptr() + 4 * lb, P, _g_n, n_late, self.eps_n.data_ptr(), cf, counter0 + _done)
+                    late_bucket[1]()
+
+            hook = finish_late if early else None
+            self.group_gradient(xb, yb, g_n, gbuf, 1, self.theta, 0, on_block_done=hook if not fd else None)
             loss_all[done:done + g_n].copy_(self.loss[:g_n])
             correct_all[done:done + g_n].copy_(self.correct[:g_n])
             n_passes = 1
@@ -731,13 +774,14 @@ class Engine:
                 call("fb_mt_chunk_clip", self.g.data_ptr(), P, g_n, P, self.sq.data_ptr(), float(batch_clip), self.clipped.data_ptr())
                 call("fb_mt_accumulate", self.avg.data_ptr(), self.g.data_ptr(), P, g_n, P, counter0 + done, None, self.mt_ws.data_ptr())
             elif not fd:
-                call("fb_mt_accumulate", self.avg.data_ptr(), self.g.data_ptr(), P, g_n, P, counter0 + done, self.sq.data_ptr(),
+                # (with an early late bucket the slice [lb, P) has been folded on the side stream; |g_k|^2 is the sum of the two parts)
+                call("fb_mt_accumulate", self.avg.data_ptr(), self.g.data_ptr(), P, g_n, lb if early else P, counter0 + done, self.sq.data_ptr(),
                      self.mt_ws.data_ptr())
+                if early:
+                    torch.cuda.current_stream().wait_stream(self.side)
+                    self.sq[:g_n].add_(self.sq_late[:g_n])
             else:
-                legacy = implementation == "forward-differences-legacy"
-                central = implementation == "central-differences"
                 s = 1.0 if legacy else float(block_strength)
-                cf = lr / 4 * (block_strength if legacy else 1.0)
                 # finite-difference direction v = s*g_k + acc*pre (modules.py:217-221; the legacy variant ignores pre, :243-245)
                 vpre, vacc = (None, 0.0) if (legacy or pre is None) else (pre.data_ptr(), float(acc_strength))
                 call("fb_mt_sqnorm", self.g.data_ptr(), P, g_n, P, 1.0, None, 0.0, self.sq.data_ptr(), self.mt_ws.data_ptr())
@@ -745,18 +789,20 @@ class Engine:
                 call("fb_mt_fd_perturb", self.theta.data_ptr(), self.g.data_ptr(), P, g_n, P, s, float(eps), 0.5 if central else 1.0,
                      self.vnorm2.data_ptr(), self.eps_n.data_ptr(), vpre, vacc, self.theta_k.data_ptr())
                 self.prep_weights(self.theta_k, g_n, per_chunk=True)
-                self.group_gradient(xb, yb, g_n, self.g_fd[0], 2, self.theta_k, 1)
+                self.group_gradient(xb, yb, g_n, self.g_fd[0], 2, self.theta_k, 1, on_block_done=None if central else hook)
                 n_passes = 2
                 if central:
                     call("fb_mt_fd_perturb", self.theta.data_ptr(), self.g.data_ptr(), P, g_n, P, s, float(eps), -0.5,
                          self.vnorm2.data_ptr(), self.eps_n.data_ptr(), vpre, vacc, self.theta_k.data_ptr())
                     self.prep_weights(self.theta_k, g_n, per_chunk=True)
-                    self.group_gradient(xb, yb, g_n, self.g_fd[1], 2, self.theta_k, 2)
+                    self.group_gradient(xb, yb, g_n, self.g_fd[1], 2, self.theta_k, 2, on_block_done=hook)
                     n_passes = 3
                 gb = self.g_fd[1] if central else self.g                 # vhp = (g(theta+) - g(theta-)) / eps_n  or  (g(theta+) - g) / eps_n
                 if batch_clip is None:
-                    call("fb_mt_fd_combine_accumulate", self.avg.data_ptr(), self.g.data_ptr(), self.g_fd[0].data_ptr(), gb.data_ptr(), P, g_n, P,
-                         self.eps_n.data_ptr(), cf, counter0 + done)
+                    call("fb_mt_fd_combine_accumulate", self.avg.data_ptr(), self.g.data_ptr(), self.g_fd[0].data_ptr(), gb.data_ptr(), P, g_n,
+                         lb if early else P, self.eps_n.data_ptr(), cf, counter0 + done)
+                    if early:
+                        torch.cuda.current_stream().wait_stream(self.side)
                 else:      # the regularised chunk gradients are materialised, clipped one by one, then averaged
                     call("fb_mt_fd_combine", self.g.data_ptr(), self.g_fd[0].data_ptr(), gb.data_ptr(), P, g_n, P, self.eps_n.data_ptr(), cf)
                     call("fb_mt_sqnorm", self.g.data_ptr(), P, g_n, P, 1.0, None, 0.0, self.vnorm2.data_ptr(), self.mt_ws.data_ptr())

@@ -62,6 +62,70 @@ class ShardOps:
         self.scale, self.sqnorm, self.update = scale, sqnorm, update
 
 
+class BucketExchange:
+    """The gradient exchange of one step in buckets of the flat arena (``bounds`` = [0, b, P]: early parameters, late parameters).
+
+    Every bucket is reduce-scattered on its own (rank r owns the r-th part of EACH bucket), so a bucket whose gradients are complete
+    can leave while the backward pass still works on the other: ``start(i)`` (scale by K_r/K + asynchronous reduce-scatter) may be
+    called early -- from the stream on which bucket i's running mean was completed (``Engine.full_gradient(late_bucket=...)``) -- and
+    ``finish()`` starts whatever has not left yet, waits, all-reduces the squared norm, runs the shard-local clip + update on the
+    rank's range of every bucket and all-gathers the updated parameters bucket by bucket.
+    Total traffic is that of ONE reduce-scatter + ONE all-gather of the arena, cut in two messages each."""
+
+    def __init__(self, avg, theta, plan, ops, bounds, group=None):
+        self.avg, self.theta, self.plan, self.ops, self.group = avg, theta, plan, ops, group
+        self.bounds = list(bounds)
+        for lo, hi in zip(self.bounds, self.bounds[1:]):
+            assert (hi - lo) % plan.world == 0 and lo % 4 == 0, "bucket bounds must be multiples of lcm(4, world)"
+        self.pending = {}
+
+    def ranges(self):
+        """This rank's (lo, n) range of every bucket."""
+        out = []
+        for lo, hi in zip(self.bounds, self.bounds[1:]):
+            n = (hi - lo) // self.plan.world
+            out.append((lo + self.plan.rank * n, n))
+        return out
+
+    def start(self, i):
+        lo, hi = self.bounds[i], self.bounds[i + 1]
+        n = (hi - lo) // self.plan.world
+        part = self.avg[lo:hi]
+        self.ops.scale(part, self.plan.count / self.plan.n_chunks)
+        shard = torch.empty(n, device=part.device, dtype=part.dtype)
+        if dist.get_backend(self.group) == "gloo":          # no reduce_scatter in gloo: all-reduce, keep the local part
+            dist.all_reduce(part, group=self.group)
+            shard.copy_(part[self.plan.rank * n:(self.plan.rank + 1) * n])
+            work = None
+        else:
+            work = dist.reduce_scatter_tensor(shard, part, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.pending[i] = (shard, work, torch.cuda.current_stream().record_event() if part.is_cuda else None)
+
+    def finish(self):
+        n_buckets = len(self.bounds) - 1
+        for i in reversed(range(n_buckets)):               # late buckets first: the order every rank issues its collectives in, whether or
+            if i not in self.pending:                      # not it started a bucket early
+                self.start(i)
+        gnorm2 = None
+        for i, (lo_r, n) in enumerate(self.ranges()):
+            shard, work, ev = self.pending[i]
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)  # the stream the bucket was started on (scale + gloo copy)
+            if work is not None:
+                work.wait()                                 # current stream waits for the collective
+            self.avg[lo_r:lo_r + n].copy_(shard)
+            part2 = self.ops.sqnorm(self.avg[lo_r:lo_r + n]).reshape(1).clone()
+            gnorm2 = part2 if gnorm2 is None else gnorm2 + part2
+        dist.all_reduce(gnorm2, group=self.group)
+        for lo_r, n in self.ranges():
+            self.ops.update(lo_r, n, gnorm2)
+        for i, (lo_r, n) in enumerate(self.ranges()):
+            lo, hi = self.bounds[i], self.bounds[i + 1]
+            dist.all_gather_into_tensor(self.theta[lo:hi], self.theta[lo_r:lo_r + n].clone(), group=self.group)
+        self.pending = {}
+        return gnorm2[0]
+
+
 def reduce_scatter_update_all_gather(avg, theta, plan, ops, group=None):
     """avg: this rank's local running mean (flat, numel divisible by world); theta: replicated parameters (flat).
 
@@ -158,13 +222,12 @@ def replicated_reduce(trainer, loss_k, correct_k, sq_k):
     return gathered[0], gathered[1], gathered[2]
 
 
-def sharded_update(trainer, loss_k, correct_k, sq_k, lr, weight_decay=None):
-    """Product wiring of the above for ``FullBatchTrainer`` (HIP kernels as ShardOps).  ``weight_decay`` overrides hyp.optim's (the
-    LARS / LARC wrappers step without it)."""
+def shard_ops(trainer, lr, weight_decay=None):
+    """HIP kernels as ShardOps for ``FullBatchTrainer``.  ``weight_decay`` overrides hyp.optim's (LARS / LARC step without it)."""
     from .lib import call
-    eng, hyp, plan = trainer.engine, trainer.cfg.hyp, trainer.shard
+    eng, hyp = trainer.engine, trainer.cfg.hyp
     o = hyp.optim
-    P = eng.plan.P
+    first = eng.first_step
 
     def scale(t, a):
         call("fb_mt_scale", t.data_ptr(), t.numel(), float(a))
@@ -175,12 +238,34 @@ def sharded_update(trainer, loss_k, correct_k, sq_k, lr, weight_decay=None):
 
     def update(lo, n, gnorm2):
         eng.norms2[0:1].copy_(gnorm2)
+        eng.first_step = first                   # one optimizer step, several arena ranges
         eng.sgd_step(lr, o.weight_decay if weight_decay is None else weight_decay, o.momentum, o.dampening, o.nesterov, hyp.grad_clip, lo=lo, n=n)
 
+    return ShardOps(scale, sqnorm, update)
+
+
+def exchange_bounds(trainer):
+    """[0, b, P]: b = start of the last stage's parameters rounded UP to the shard granule (the late bucket then holds only gradients
+    that are complete once the backward pass has left the last stage)."""
+    eng, world = trainer.engine, trainer.shard.world
+    granule = 4 * world // __import__("math").gcd(4, world)
+    b = (eng.plan.late_offset + granule - 1) // granule * granule
+    return [0, b, eng.plan.P]
+
+
+def sharded_update(trainer, loss_k, correct_k, sq_k, lr, weight_decay=None, exchange=None):
+    """Product wiring of the above for ``FullBatchTrainer`` (HIP kernels as ShardOps).  ``weight_decay`` overrides hyp.optim's (the
+    LARS / LARC wrappers step without it).  ``exchange``: the step's ``BucketExchange`` when the closure has already started its late
+    bucket."""
+    from .lib import call
+    eng, hyp, plan = trainer.engine, trainer.cfg.hyp, trainer.shard
+    P = eng.plan.P
     # parameter norm of the (replicated) pre-update parameters for the stats
     call("fb_mt_norms2", eng.theta.data_ptr(), None, P, eng.norms2.data_ptr(), eng.mt_ws.data_ptr())
     pnorm2 = eng.norms2[0].clone()
-    gnorm2 = reduce_scatter_update_all_gather(eng.avg, eng.theta, plan, ShardOps(scale, sqnorm, update))
+    if exchange is None:
+        exchange = BucketExchange(eng.avg, eng.theta, plan, shard_ops(trainer, lr, weight_decay), exchange_bounds(trainer))
+    gnorm2 = exchange.finish()
     eng.norms2[0] = gnorm2
     eng.norms2[1] = pnorm2
     # BN running statistics: recombine the rank-local EMAs
@@ -199,7 +284,8 @@ def gather_sharded_state(trainer, group=None):
     checkpoint is written (rank 0 saves the whole ``momentum_buffer`` list, reference training/utils.py:43-49) or ``p.grad`` is
     exposed (closure contract), the shards are all-gathered into the full arenas.  Collective: every rank calls it."""
     eng, plan = trainer.engine, trainer.shard
-    n = eng.plan.P // plan.world
-    lo = plan.rank * n
-    for arena in (eng.mom, eng.avg):
-        dist.all_gather_into_tensor(arena, arena[lo:lo + n].clone(), group=group)
+    bounds = exchange_bounds(trainer)
+    for lo, hi in zip(bounds, bounds[1:]):          # the shard layout of BucketExchange: rank r owns the r-th part of every bucket
+        n = (hi - lo) // plan.world
+        for arena in (eng.mom, eng.avg):
+            dist.all_gather_into_tensor(arena[lo:hi], arena[lo + plan.rank * n:lo + (plan.rank + 1) * n].clone(), group=group)

@@ -437,6 +437,19 @@ class FullBatchTrainer:
             self._running0 = torch.stack([eng.running_mean, eng.running_var]).clone()
         mod = hyp.optim_modification.name
 
+        # more than one rank, plain step: the gradient exchange leaves in two buckets, the late one (last stage + classifier) as soon as
+        # the last backward pass has left the last stage (parallel.BucketExchange, Engine.full_gradient(late_bucket=...))
+        noisy = hyp.grad_noise["additive"] is not None or hyp.grad_noise["multiplicative"] is not None
+        replicated = self.multi and (mod == "SAM" or hyp.norm_bias.strength > 0 or hyp.only_linear_layers_weight_decay or noisy
+                                     or (hyp.grad_clip is not None and float(hyp.grad_clip_norm) != 2.0))
+        exchange = late = None
+        if self.multi and not replicated:
+            from .parallel import BucketExchange, exchange_bounds, shard_ops
+            exchange = BucketExchange(eng.avg, eng.theta, self.shard, shard_ops(self, lr, 0.0 if mod in ("LARS", "LARC") else None),
+                                      exchange_bounds(self))
+            if self.shard.count > 0 and os.environ.get("FB_EXCHANGE_OVERLAP", "1") != "0":
+                late = (exchange.bounds[1], lambda: exchange.start(1))
+
         def closure():
             """``gradient_evaluation`` (reference training.py:217-225) up to the clip, which is fused into the consumer of ``eng.avg``."""
             hook = None
@@ -444,7 +457,8 @@ class FullBatchTrainer:
                 from .parallel import reduce_pre_pass
                 hook = lambda: reduce_pre_pass(self)          # noqa: E731
             out = eng.full_gradient(self.patches, self.labels, lr, gr.block_strength, gr.eps, gr.implementation, acc_strength=gr.acc_strength,
-                                    after_pre_pass=hook, pre_block=self.block // self.chunk * self.chunk_pad, batch_clip=hyp.batch_clip)
+                                    after_pre_pass=hook, pre_block=self.block // self.chunk * self.chunk_pad, batch_clip=hyp.batch_clip,
+                                    late_bucket=late)
             self._pre_sqnorm = None
             if gr.acc_strength != 0:             # |pre_grads|^2 for full_loss (reference training.py:98-101)
                 lib.call("fb_mt_norms2", eng.pre.data_ptr(), None, eng.plan.P, eng.norms2.data_ptr(), eng.mt_ws.data_ptr())
@@ -453,9 +467,6 @@ class FullBatchTrainer:
 
         # more than one rank: the plain step shards the update (reduce-scatter, shard-local clip + SGD, all-gather); the options that
         # need the whole averaged gradient on every rank all-reduce it instead and then run the 1-process code below, replicated
-        noisy = hyp.grad_noise["additive"] is not None or hyp.grad_noise["multiplicative"] is not None
-        replicated = self.multi and (mod == "SAM" or hyp.norm_bias.strength > 0 or hyp.only_linear_layers_weight_decay or noisy
-                                         or (hyp.grad_clip is not None and float(hyp.grad_clip_norm) != 2.0))
         if replicated:
             from .parallel import replicated_reduce
             local_closure = closure
@@ -468,7 +479,7 @@ class FullBatchTrainer:
         if self.multi and not replicated:
             from .parallel import sharded_update
             loss_k, correct_k, sq_k = sharded_update(self, loss_k, correct_k, sq_k, lr,
-                                                    weight_decay=0.0 if mod in ("LARS", "LARC") else None)
+                                                    weight_decay=0.0 if mod in ("LARS", "LARC") else None, exchange=exchange)
             self._state_is_sharded = True        # momentum / clipped gradient complete only on each rank's shard until gather_state()
         else:
             o = hyp.optim

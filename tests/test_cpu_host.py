@@ -200,7 +200,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, K, P, out_dir):
+def _worker(rank, world, port, K, P, out_dir, bucketed=False):
     import sys
     sys.path.insert(0, REPO)
     from fullbatchtraining_amd.parallel import (ShardOps, ShardPlan, all_gather_chunk_stats, combine_running_stats,
@@ -231,7 +231,14 @@ def _worker(rank, world, port, K, P, out_dir):
         theta[lo:lo + n] -= lr * (d + mu * mom[lo:lo + n])
 
     ops = ShardOps(scale=lambda t, a: t.mul_(a), sqnorm=lambda t: t.pow(2).sum(), update=update)
-    gnorm2 = reduce_scatter_update_all_gather(avg, theta, plan, ops)
+    if bucketed:       # two buckets; rank 0 starts the late one early (as the engine does from its side stream), rank 1 only in finish()
+        from fullbatchtraining_amd.parallel import BucketExchange
+        ex = BucketExchange(avg, theta, plan, ops, [0, 64 * 2, P])
+        if rank == 0:
+            ex.start(1)
+        gnorm2 = ex.finish()
+    else:
+        gnorm2 = reduce_scatter_update_all_gather(avg, theta, plan, ops)
     full_stats = all_gather_chunk_stats(stats[plan.first:plan.first + plan.count].clone(), plan)
     mine = stats[plan.first:plan.first + plan.count]
     full_rows = all_gather_chunk_stats(torch.stack([mine, 2 * mine, mine + 1]), plan)          # several statistics, one collective
@@ -242,19 +249,21 @@ def _worker(rank, world, port, K, P, out_dir):
         for u in range(2):
             r_local = 0.9 * r_local + 0.1 * bn_mean[k, u].expand(2, 5)
     combined = combine_running_stats(r0, r_local, plan, updates_per_chunk=2)
-    torch.save(dict(theta=theta, gnorm2=gnorm2, stats=full_stats, running=combined, mom_shard=mom.clone(), lo=rank * (P // world)),
+    owned = ex.ranges() if bucketed else [(rank * (P // world), P // world)]
+    torch.save(dict(theta=theta, gnorm2=gnorm2, stats=full_stats, running=combined, mom_shard=mom.clone(), owned=owned),
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
 
-def test_sharded_step_matches_single_process(tmp_path):
+@pytest.mark.parametrize("bucketed", [False, True])
+def test_sharded_step_matches_single_process(tmp_path, bucketed):
     """2 gloo ranks: reduce-scatter(sum of K_r/K-scaled local means) + sharded clip/SGD + all-gather == 1-process step on the
     exact mean (checked with the oracle's SGD), stats gathered in chunk order, BN running stats recombined exactly."""
     from oracle import fb_oracle as orc
 
     K, P, world = 7, 64 * 6, 2
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, K, P, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, K, P, str(tmp_path), bucketed), nprocs=world, join=True)
     torch.manual_seed(0)
     g, theta, mom, stats = torch.randn(K, P), torch.randn(P), torch.randn(P) * 0.1, torch.rand(K)
     bn_mean = torch.randn(K, 2, 5)
@@ -275,6 +284,6 @@ def test_sharded_step_matches_single_process(tmp_path):
         assert torch.allclose(o["gnorm2"], norm ** 2, rtol=1e-5)
         assert torch.equal(o["stats"], stats)
         assert torch.allclose(o["running"], running, rtol=1e-5, atol=1e-6)
-        n = P // world
-        assert torch.allclose(o["mom_shard"][o["lo"]:o["lo"] + n], momentum[0][o["lo"]:o["lo"] + n], rtol=1e-5, atol=1e-6)
+        for lo, n in o["owned"]:           # sharded momentum: this rank's range of every bucket
+            assert torch.allclose(o["mom_shard"][lo:lo + n], momentum[0][lo:lo + n], rtol=1e-5, atol=1e-6)
     assert torch.equal(outs[0]["theta"], outs[1]["theta"])
