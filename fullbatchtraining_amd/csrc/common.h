@@ -127,7 +127,30 @@ __device__ __forceinline__ f32x4_t mma_split6(const split3_t& a, const split3_t&
     t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.h, t, 0, 0, 0);
     t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.m, t, 0, 0, 0);
     t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, t, 0, 0, 0);
-    return c + t;
+    c += t;
+    asm volatile("" : "+v"(c));             // pin the sum here: LLVM otherwise sinks the whole add chain below the K loop and spills every t
+    return c;
+}
+// One A fragment against NJ B fragments: NJ zero-started chains, interleaved product by product (independent MFMAs back to back)
+template <int NJ> __device__ __forceinline__ void mma_split6_row(const split3_t& a, const split3_t (&b)[NJ], f32x4_t (&c)[NJ]) {
+    f32x4_t t[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) t[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b[j].h, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) t[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b[j].l, t[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) t[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b[j].m, t[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) t[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b[j].h, t[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) t[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b[j].m, t[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) t[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b[j].h, t[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        c[j] += t[j];
+        asm volatile("" : "+v"(c[j]));      // pin the sum here: LLVM otherwise sinks the whole add chain below the K loop and spills every t
+    }
 }
 template <typename T> struct is_split { static constexpr bool value = false; };
 template <> struct is_split<f32s_tag> { static constexpr bool value = true; };

@@ -235,15 +235,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 h4_static_for<0, 4>([&](auto j) { pf1[decltype(j)::value] = h4_read16<(A * PITCH + h4_frag_rows<W>(decltype(j)::value)) * 128>(pa[B][1]); });
                 if constexpr (is_split<T>::value) {      // fp32 operands as three bf16 pieces each, six MFMAs per fragment pair (common.h)
                     h4_wait_lgkmcnt<0>();
-                    split3_t sw[4], sp[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) sw[i] = split_f32x8(wf0[i], wf1[i]);
+                    split3_t sp[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) sp[j] = split_f32x8(pf0[j], pf1[j]);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[i][j] = mma_split6(sw[i], sp[j], acc[i][j]);
+                    for (int i = 0; i < 4; ++i) {                  // one weight fragment split at a time: four zero-started chains in flight
+                        const split3_t sw = split_f32x8(wf0[i], wf1[i]);
+                        mma_split6_row<4>(sw, sp, acc[i]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 } else {
                 h4_wait_lgkmcnt<8>();
 #pragma unroll
