@@ -112,6 +112,15 @@ __device__ __forceinline__ uint4 ld_stream(const uint4* p) {
     const bn_u32x4_t v = __builtin_nontemporal_load((const bn_u32x4_t*)p);
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
+// loads of the backward REDUCE pass: the apply pass re-reads the same (dout, x) rows right afterwards; -DFB_BN_REDUCE_PLAIN keeps them
+// cacheable (tools/bn_mall_experiment.py: sub-batched reduce -> apply out of the Infinity Cache)
+__device__ __forceinline__ uint4 ld_reduce(const uint4* p) {
+#ifdef FB_BN_REDUCE_PLAIN
+    return *p;
+#else
+    return ld_stream(p);
+#endif
+}
 __device__ __forceinline__ void st_stream(uint4* p, const uint4& v) {
     __builtin_nontemporal_store((bn_u32x4_t){v.x, v.y, v.z, v.w}, (bn_u32x4_t*)p);
 }
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(256) void bn_apply_span_kernel(const uint4* __restr
                                                             const float* __restrict__ shift, const uint4* __restrict__ res,
                                                             const float* __restrict__ rscale, const float* __restrict__ rshift, long long n_vec,
                                                             int cvec, long long vec_per_group, int C, int relu, unsigned char* __restrict__ mask_out,
-                                                            int span, long long valid_vec) {
+                                                            int span, long long valid_vec, uint4* __restrict__ pool_out) {
     constexpr int V = ET<T>::VEC;
     const long long g = blockIdx.y, base = g * vec_per_group;
     const long long lim = n_vec - base < vec_per_group ? n_vec - base : vec_per_group;
@@ -151,14 +160,31 @@ __global__ __launch_bounds__(256) void bn_apply_span_kernel(const uint4* __restr
         if (i >= valid_vec) { packed = make_uint4(0, 0, 0, 0); m = 0; }      // padding pixels of a ragged statistics group
         st_stream(y + i, packed);
         if (mask_out) mask_out[i] = (unsigned char)m;
+        return packed;
     };
     long long i = lo + threadIdx.x;
     for (; i + (BN_SPAN_U - 1) * 256 < hi; i += BN_SPAN_U * 256) {
-        uint4 xr[BN_SPAN_U], rr[BN_SPAN_U];
+        uint4 xr[BN_SPAN_U], rr[BN_SPAN_U], outp[BN_SPAN_U];
 #pragma unroll
         for (int u = 0; u < BN_SPAN_U; ++u) { xr[u] = ld_stream(x + i + u * 256); if (RES) rr[u] = ld_stream(res + i + u * 256); }
 #pragma unroll
-        for (int u = 0; u < BN_SPAN_U; ++u) one(xr[u], rr[u], i + u * 256);
+        for (int u = 0; u < BN_SPAN_U; ++u) outp[u] = one(xr[u], rr[u], i + u * 256);
+        if (pool_out) {
+            // AvgPool2d(2,2) of the block output for the next block's shortcut (reference resnets.py:149), fused: the host passes
+            // pool_out only when a run is exactly two image rows (W * cvec == 256, span == 512), so the two vectors of a thread are
+            // vertical neighbours and the horizontal neighbour sits cvec lanes away.  Pooled from the STORED (rounded) values in the
+            // order of avgpool2_fwd_kernel: bit-identical to the separate kernel, one full read of the activation less.
+            static_assert(BN_SPAN_U == 2, "the fused pooling pairs the two vectors of a thread");
+            float r0[V], r1[V], acc[V];
+            ET<T>::unpack(outp[0], r0); ET<T>::unpack(outp[1], r1);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float n0 = __shfl_xor(r0[k], cvec), n1 = __shfl_xor(r1[k], cvec);
+                acc[k] = (((r0[k] + n0) + r1[k]) + n1) * 0.25f;
+            }
+            const int px = (int)threadIdx.x / cvec;
+            if ((px & 1) == 0) pool_out[((base + lo) >> 9) * 128 + (px >> 1) * cvec + (threadIdx.x % cvec)] = ET<T>::pack(acc);
+        }
     }
     for (; i < hi; i += 256) { uint4 rr = make_uint4(0, 0, 0, 0); if (RES) rr = res[i]; one(x[i], rr, i); }
 }
@@ -170,16 +196,17 @@ static inline int bn_span(long long) { return 512; }
 
 template <typename T>
 static void launch_bn_apply(const void* x, void* y, const float* scale, const float* shift, const void* res, const float* rscale,
-                            const float* rshift, int64_t n_pixels, int C, int64_t ppg, int64_t valid_ppg, int relu, unsigned char* mask_out, hipStream_t st) {
+                            const float* rshift, int64_t n_pixels, int C, int64_t ppg, int64_t valid_ppg, int relu, unsigned char* mask_out, uint4* pool_out,
+                            hipStream_t st) {
     const int cvec = C / ET<T>::VEC;
     const long long n_vec = n_pixels * cvec, vpg = ppg * cvec;
     const long long valid_vec = (valid_ppg > 0 && valid_ppg < ppg ? valid_ppg : ppg) * cvec;
     if (256 % cvec == 0 && vpg > 0) {
         const int span = bn_span(n_vec);
         const dim3 grid((unsigned)((vpg + span - 1) / span), (unsigned)((n_vec + vpg - 1) / vpg));
-        if (!res) hipLaunchKernelGGL((bn_apply_span_kernel<T, 0>), grid, dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, nullptr, nullptr, nullptr, n_vec, cvec, vpg, C, relu, mask_out, span, valid_vec);
-        else if (!rscale) hipLaunchKernelGGL((bn_apply_span_kernel<T, 1>), grid, dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, nullptr, nullptr, n_vec, cvec, vpg, C, relu, mask_out, span, valid_vec);
-        else hipLaunchKernelGGL((bn_apply_span_kernel<T, 2>), grid, dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, rscale, rshift, n_vec, cvec, vpg, C, relu, mask_out, span, valid_vec);
+        if (!res) hipLaunchKernelGGL((bn_apply_span_kernel<T, 0>), grid, dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, nullptr, nullptr, nullptr, n_vec, cvec, vpg, C, relu, mask_out, span, valid_vec, pool_out);
+        else if (!rscale) hipLaunchKernelGGL((bn_apply_span_kernel<T, 1>), grid, dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, nullptr, nullptr, n_vec, cvec, vpg, C, relu, mask_out, span, valid_vec, pool_out);
+        else hipLaunchKernelGGL((bn_apply_span_kernel<T, 2>), grid, dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, rscale, rshift, n_vec, cvec, vpg, C, relu, mask_out, span, valid_vec, pool_out);
         return;
     }
     const int blocks = (int)((n_vec + 255) / 256 < 8192 ? (n_vec + 255) / 256 : 8192);
@@ -188,13 +215,20 @@ static void launch_bn_apply(const void* x, void* y, const float* scale, const fl
     else hipLaunchKernelGGL((bn_apply_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, rscale, rshift, n_vec, cvec, vpg, C, relu, mask_out, valid_vec);
 }
 
+// fused AvgPool2d(2,2) output of fb_bn_apply: a 512-vector run of the span kernel must be exactly two image rows
+extern "C" int32_t fb_bn_apply_can_pool(int32_t C, int32_t W, int64_t pixels_per_group, int32_t dtype) {
+    return dtype == FB_BF16 && W > 0 && (W & 1) == 0 && (long long)W * C == 2048 && C % 8 == 0 && 256 % (C / 8) == 0 && pixels_per_group % (2 * W) == 0;
+}
+
 extern "C" int fb_bn_apply(const void* x, void* y, const float* scale, const float* shift, const void* res, const float* rscale,
                            const float* rshift, int64_t n_pixels, int32_t C, int64_t pixels_per_group, int64_t valid_pixels_per_group,
-                           int32_t relu, void* mask_out, int32_t dtype, void* stream) {
+                           int32_t relu, void* mask_out, void* pool_out, int32_t pool_W, int32_t dtype, void* stream) {
     if (!x || !y || !scale || !shift) FB_FAIL(FB_ERR_ARG, "fb_bn_apply: null pointer");
     if (C % 8 != 0) FB_FAIL(FB_ERR_SHAPE, "fb_bn_apply: C=%d must be a multiple of 8", C);
-    if (dtype == FB_F32) launch_bn_apply<float>(x, y, scale, shift, res, rscale, rshift, n_pixels, C, pixels_per_group, valid_pixels_per_group, relu, (unsigned char*)mask_out, (hipStream_t)stream);
-    else launch_bn_apply<bf16_tag>(x, y, scale, shift, res, rscale, rshift, n_pixels, C, pixels_per_group, valid_pixels_per_group, relu, (unsigned char*)mask_out, (hipStream_t)stream);
+    if (pool_out && !fb_bn_apply_can_pool(C, pool_W, pixels_per_group, dtype))
+        FB_FAIL(FB_ERR_UNSUPPORTED, "fb_bn_apply: fused 2x2 average pooling needs bf16, W * C == 2048 and whole row pairs per group (C=%d W=%d)", C, pool_W);
+    if (dtype == FB_F32) launch_bn_apply<float>(x, y, scale, shift, res, rscale, rshift, n_pixels, C, pixels_per_group, valid_pixels_per_group, relu, (unsigned char*)mask_out, (uint4*)pool_out, (hipStream_t)stream);
+    else launch_bn_apply<bf16_tag>(x, y, scale, shift, res, rscale, rshift, n_pixels, C, pixels_per_group, valid_pixels_per_group, relu, (unsigned char*)mask_out, (uint4*)pool_out, (hipStream_t)stream);
     FB_CHECK_LAUNCH("fb_bn_apply");
     return FB_OK;
 }
@@ -287,7 +321,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint4* __restr
             uint4 dr[BN_SPAN_U], xr[BN_SPAN_U];
             unsigned mk[BN_SPAN_U];
 #pragma unroll
-            for (int u = 0; u < BN_SPAN_U; ++u) { dr[u] = ld_stream(dout + i + u * 256); xr[u] = ld_stream(x + i + u * 256); mk[u] = mask_at(i + u * 256); }
+            for (int u = 0; u < BN_SPAN_U; ++u) { dr[u] = ld_reduce(dout + i + u * 256); xr[u] = ld_reduce(x + i + u * 256); mk[u] = mask_at(i + u * 256); }
 #pragma unroll
             for (int u = 0; u < BN_SPAN_U; ++u) one(dr[u], xr[u], mk[u]);
         }

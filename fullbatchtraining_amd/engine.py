@@ -439,12 +439,17 @@ class Engine:
              self.mean_tab[pidx].data_ptr(), self.var_tab[pidx].data_ptr(), self.plan.ch_total, L.ch_off,
              L.scale.data_ptr(), L.shift.data_ptr(), L.invstd.data_ptr())
 
-    def _bn_apply(self, L, out, G, relu=True, res=None, resL=None):
+    def _bn_apply(self, L, out, G, relu=True, res=None, resL=None, pool=None):
+        """``pool``: the 2x2-average-pooled copy of ``out`` the NEXT block's shortcut reads, written by the same pass where the library can
+        (``fb_bn_apply_can_pool``); returns True if it was."""
         px = G * self.chunk * L.hout * L.wout
+        ppg = self.chunk * L.hout * L.wout
+        fused = pool is not None and bool(lib.load().fb_bn_apply_can_pool(L.cout, L.wout, ppg, self.dtc)) and os.environ.get("FB_FUSED_POOL", "1") != "0"
         call("fb_bn_apply", L.x.data_ptr(), out.data_ptr(), L.scale.data_ptr(), L.shift.data_ptr(), _ptr(res),
              resL.scale.data_ptr() if resL is not None else None, resL.shift.data_ptr() if resL is not None else None,
-             px, L.cout, self.chunk * L.hout * L.wout, self.valid * L.hout * L.wout if self.valid < self.chunk else 0, 1 if relu else 0,
-             _ptr(self._mask_of(out)) if relu else None, self.dtc)
+             px, L.cout, ppg, self.valid * L.hout * L.wout if self.valid < self.chunk else 0, 1 if relu else 0,
+             _ptr(self._mask_of(out)) if relu else None, _ptr(pool) if fused else None, L.wout, self.dtc)
+        return fused
 
     def _mask_of(self, act):
         """ReLU bitmask buffer (1 byte per 16-byte vector) paired with a post-ReLU activation tensor, created on first use."""
@@ -469,7 +474,10 @@ class Engine:
             s = plan.stem
             call("fb_maxpool3s2_fwd", a.data_ptr(), self.stem_pooled.data_ptr(), G * self.chunk, s.hout, s.wout, 64, self.dtc)
             a = self.stem_pooled
-        for b in plan.blocks:
+        pooled_ready = False                         # the previous block's output pass already wrote this block's pooled input
+        for bi, b in enumerate(plan.blocks):
+            nxt = plan.blocks[bi + 1] if bi + 1 < len(plan.blocks) else None
+            next_pool = nxt.pooled if nxt is not None else None
             a0 = a
             cur = a0
             for i, L in enumerate(b.convs):
@@ -481,12 +489,13 @@ class Engine:
             if b.shortcut is not None:
                 src = a0
                 if b.pooled is not None:
-                    call("fb_avgpool2_fwd", a0.data_ptr(), b.pooled.data_ptr(), G * self.chunk, b.hin, b.win, b.cin, self.dtc)
+                    if not pooled_ready:
+                        call("fb_avgpool2_fwd", a0.data_ptr(), b.pooled.data_ptr(), G * self.chunk, b.hin, b.win, b.cin, self.dtc)
                     src = b.pooled
                 self._conv_bn_fwd(b.shortcut, src, G, wsets, theta, pidx)
-                self._bn_apply(last, b.out, G, res=b.shortcut.x, resL=b.shortcut)
+                pooled_ready = self._bn_apply(last, b.out, G, res=b.shortcut.x, resL=b.shortcut, pool=next_pool)
             else:
-                self._bn_apply(last, b.out, G, res=a0)
+                pooled_ready = self._bn_apply(last, b.out, G, res=a0, pool=next_pool)
             a = b.out
         n = G * self.chunk
         hw = plan.h_final * plan.h_final

@@ -9,7 +9,7 @@ import os
 import torch
 
 FB_F32, FB_BF16 = 0, 1
-EXPECTED_ABI = 7          # fb_abi_version() the ctypes structs / signatures below were written for
+EXPECTED_ABI = 8          # fb_abi_version() the ctypes structs / signatures below were written for
 MT_BLOCKS = 1024
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libfbengine.so")
 
@@ -37,7 +37,8 @@ _SIGS = {
     "fb_weight_prep": [c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "fb_bn_fwd_finalize": [c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_i64, c_float, c_void_p, c_void_p, c_int,
                            c_int, c_void_p, c_void_p, c_void_p, c_void_p],
-    "fb_bn_apply": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_i64, c_int, c_void_p, c_int, c_void_p],
+    "fb_bn_apply": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_i64, c_int, c_void_p, c_void_p, c_int,
+                    c_int, c_void_p],
     "fb_bn_running_update": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_void_p, c_int, c_int, c_float, c_void_p],
     "fb_bn_bwd_reduce": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_i64, c_int, c_i64, c_int, c_void_p],
     "fb_bn_bwd_finalize": [c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
@@ -75,7 +76,8 @@ _SIGS = {
     "fb_mt_grad_noise": [c_void_p, c_void_p, c_i64, c_float, c_int, c_void_p],
 }
 EXPORTS = tuple(_SIGS) + ("fb_last_error_string", "fb_abi_version", "fb_profile_enable", "fb_profile_read", "fb_ws_conv_stat_floats",
-                          "fb_ws_wgrad_slab_floats", "fb_ws_bn_partial_floats", "fb_ws_mt_floats", "fb_bn_bwd_reduce_rows", "fb_conv_masked_addend_supported")
+                          "fb_ws_wgrad_slab_floats", "fb_ws_bn_partial_floats", "fb_ws_mt_floats", "fb_bn_bwd_reduce_rows", "fb_conv_masked_addend_supported",
+                          "fb_bn_apply_can_pool")
 PROF_CLASSES = ("igemm_fwd", "igemm_dgrad", "wgrad")
 
 
@@ -124,6 +126,7 @@ def load():
         lib.fb_ws_mt_floats.argtypes, lib.fb_ws_mt_floats.restype = [c_int], c_i64
         lib.fb_bn_bwd_reduce_rows.argtypes, lib.fb_bn_bwd_reduce_rows.restype = [c_i64, c_i64], c_int
         lib.fb_conv_masked_addend_supported.argtypes, lib.fb_conv_masked_addend_supported.restype = [C.POINTER(ConvArgs)], c_int
+        lib.fb_bn_apply_can_pool.argtypes, lib.fb_bn_apply_can_pool.restype = [c_int, c_int, c_i64, c_int], c_int
         _lib = lib
     return _lib
 

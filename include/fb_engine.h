@@ -112,7 +112,11 @@ int fb_bn_fwd_finalize(const float* stat_partial, int32_t n_mblocks, int32_t n_g
  * (BatchNorm2d + ReLU(inplace) + `out += identity`, resnets.py:217-228) */
 int fb_bn_apply(const void* x, void* y, const float* scale, const float* shift, const void* res, const float* rscale,
                 const float* rshift, int64_t n_pixels, int32_t C, int64_t pixels_per_group, int64_t valid_pixels_per_group,
-                int32_t relu, void* mask_out, int32_t dtype, void* stream);
+                int32_t relu, void* mask_out, void* pool_out, int32_t pool_W, int32_t dtype, void* stream);
+/* pool_out (optional): AvgPool2d(2,2) of y, [n_img][H/2][W/2][C] (the 'C' downsample shortcut of the NEXT block, resnets.py:149), written
+ * by the same pass -- bit-identical to fb_avgpool2_fwd on y, one read of the activation less.  pool_W = image width of y; only where
+ * fb_bn_apply_can_pool() says so (bf16, W*C == 2048: the 64@32, 128@16, 256@8 maps of ResNet-18/34). */
+int32_t fb_bn_apply_can_pool(int32_t C, int32_t W, int64_t pixels_per_group, int32_t dtype);
 /* valid_pixels_per_group (0 = all): chunk sizes that do not fill whole 128-pixel statistics blocks (data.batch_size=125, reference
  * data_preparation.py:64-72) are stored padded with zero images; the pixels [valid, pixels_per_group) of every group are written as
  * exact zeros with a clear mask, so they stay out of every later sum (statistics are divided by the REAL count). */

@@ -188,7 +188,7 @@ def test_batchnorm_fwd_bwd(dtype, C, hw, ipg, groups):
     y = torch.empty_like(xd)
     bits = torch.zeros(xd.numel() * xd.element_size() // 16, dtype=torch.uint8, device="cuda")
     lib.call("fb_bn_apply", xd.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), resd.data_ptr(), None, None, px, C, ppg, 0, 1,
-             bits.data_ptr(), lib.dtype_code(dtype))
+             bits.data_ptr(), None, 0, lib.dtype_code(dtype))
     # reference, per group
     ys, dxs, dgs, dbs = [], [], [], []
     for g in range(groups):
@@ -584,3 +584,35 @@ def test_clip_scale_and_grad_noise_kernels():
     lib.call("fb_mt_grad_noise", gd.data_ptr(), nd.data_ptr(), n, 0.1, 1)
     ref.mul_(1 + 0.1 * noise)
     assert torch.equal(gd.cpu(), ref)
+
+
+@pytest.mark.parametrize("C,W", [(64, 32), (128, 16), (256, 8)])
+def test_bn_apply_fused_avgpool_is_bit_identical(C, W):
+    """fb_bn_apply(pool_out=...): the 2x2 average pooling of the block output for the next block's 'C' shortcut (reference resnets.py:149),
+    written by the BN pass itself, equals fb_avgpool2_fwd applied to the stored activation bit for bit (bf16, with residual + ReLU)."""
+    from fullbatchtraining_amd import lib
+
+    G, ipg = 3, 4
+    n = G * ipg
+    px, ppg = n * W * W, ipg * W * W
+    dt = lib.dtype_code(torch.bfloat16)
+    assert lib.load().fb_bn_apply_can_pool(C, W, ppg, dt) == 1 and lib.load().fb_bn_apply_can_pool(C, W, ppg, lib.dtype_code(torch.float32)) == 0
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(n, W, W, C, generator=gen).bfloat16().cuda()
+    res = torch.randn(n, W, W, C, generator=gen).bfloat16().cuda()
+    scale, shift = (torch.rand(G, C, generator=gen) + 0.5).cuda(), torch.randn(G, C, generator=gen).cuda()
+    y, y2 = torch.empty_like(x), torch.empty_like(x)
+    pooled = torch.full((n, W // 2, W // 2, C), 7.0, dtype=torch.bfloat16, device="cuda")
+    want = torch.empty_like(pooled)
+    bits = torch.zeros(x.numel() // 8, dtype=torch.uint8, device="cuda")
+    lib.call("fb_bn_apply", x.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), res.data_ptr(), None, None, px, C, ppg, 0, 1,
+             bits.data_ptr(), pooled.data_ptr(), W, dt)
+    lib.call("fb_bn_apply", x.data_ptr(), y2.data_ptr(), scale.data_ptr(), shift.data_ptr(), res.data_ptr(), None, None, px, C, ppg, 0, 1,
+             bits.data_ptr(), None, 0, dt)
+    lib.call("fb_avgpool2_fwd", y2.data_ptr(), want.data_ptr(), n, W, W, C, dt)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+    assert torch.equal(pooled.view(torch.int16), want.view(torch.int16))
+    ref = torch.relu(x.float() * scale.repeat_interleave(ipg, 0)[:, None, None, :] + shift.repeat_interleave(ipg, 0)[:, None, None, :] + res.float())
+    ref = ref.bfloat16().float().view(n, W // 2, 2, W // 2, 2, C).mean(dim=(2, 4))
+    assert float((pooled.float() - ref).abs().max()) < 2e-2 * float(ref.abs().max())

@@ -178,4 +178,6 @@ def test_sharded_checkpoint_holds_whole_momentum(tmp_path):
     for r in range(2):
         got = torch.load(os.path.join(out2, f"resumed_r{r}.pt"))
         for key in ("train_loss", "grad_norm", "param_norm", "full_loss"):
-            assert np.allclose(got["stats"][key], ref["stats"][key], rtol=1e-3), (key, got["stats"][key], ref["stats"][key])
+            # steps 4-5 of the run: the ranks sum the full-batch gradient in another order than one process, and fp32 chunk-gradient noise
+            # has grown to ~2e-3 by step 5 (a resumed shard without its momentum would be off by tens of per cent)
+            assert np.allclose(got["stats"][key], ref["stats"][key], rtol=1e-2), (key, got["stats"][key], ref["stats"][key])

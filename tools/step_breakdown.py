@@ -1,7 +1,7 @@
 """Per-launch breakdown of one chunk group (forward + backward) of the benchmark workload: every library call of the schedule with its
 shape, duration (HIP events, one stream), algorithmic TFLOP/s and GB/s.  GPU box:
 
-    FB_WGRAD_STREAM=0 python tools/step_breakdown.py [bf16|f32] [G]
+    FB_WGRAD_STREAM=0 python tools/step_breakdown.py [bf16|f32] [G] [model stem pixels chunk]
 """
 import os
 import sys
@@ -21,12 +21,14 @@ def main():
     dtype = torch.float32 if (len(sys.argv) > 1 and sys.argv[1] == "f32") else torch.bfloat16
     G = int(sys.argv[2]) if len(sys.argv) > 2 else (98 if dtype == torch.bfloat16 else 49)
     eb = 2 if dtype == torch.bfloat16 else 4
+    model_name, stem, pixels, chunk = (sys.argv[3:7] + ["resnet18", "CIFAR", "32", "128"][len(sys.argv[3:7]):])
+    pixels, chunk = int(pixels), int(chunk)
     torch.manual_seed(1)
-    model = construct_model(compose([]).model, 3, 10)
-    eng = E.Engine(model, 32, 128, G, compute_dtype=dtype)
+    model = construct_model(compose([f"model={model_name}", f"model.stem={stem}"]).model, 3, 10)
+    eng = E.Engine(model, pixels, chunk, G, compute_dtype=dtype)
     gen = torch.Generator().manual_seed(1234)
-    x = torch.randn(G * 128, 3, 32, 32, generator=gen)
-    y = torch.randint(0, 10, (G * 128,), generator=gen).cuda()
+    x = torch.randn(G * chunk, 3, pixels, pixels, generator=gen)
+    y = torch.randint(0, 10, (G * chunk,), generator=gen).cuda()
     patches = E.stem_patches(x.cuda(), eng.plan.stem, dtype)
     eng.prep_weights(eng.theta, 1)
     records = []
@@ -49,7 +51,7 @@ def main():
                 px, C, passes = args[9], args[10], 2
             else:
                 px, C, passes = args[7], args[8], 3 + (1 if args[6] else 0)
-            return f"{name[3:]} C{C} px/img {px // (G * 128)}", 0, px * C * eb * passes
+            return f"{name[3:]} C{C} px/img {px // (G * chunk)}", 0, px * C * eb * passes
         return name[3:], 0, 0
 
     def timed_call(name, *args):
@@ -72,10 +74,13 @@ def main():
         rows.append((us, desc, flop, byt))
         classes[name] += us
     total = sum(r[0] for r in rows)
-    print(f"one chunk group of {G} chunks ({G * 128} images), {str(dtype)}: {total / 1e3:.2f} ms of launches; x {390 / G:.2f} groups per step = {total / 1e3 * 390 / G:.1f} ms\n")
+    print(f"{model_name} {stem} {pixels}px: one chunk group of {G} chunks ({G * chunk} images), {str(dtype)}: {total / 1e3:.2f} ms of launches"
+          + (f"; x {390 / G:.2f} groups per step = {total / 1e3 * 390 / G:.1f} ms" if model_name == "resnet18" else f" = {G * chunk / total * 1e6:.0f} images/s") + "\n")
     print("| # | call | us | TFLOP/s | GB/s (algorithmic) |\n|---|---|---|---|---|")
     for i, (us, desc, flop, byt) in enumerate(rows):
         if us < 15:
+            continue
+        if model_name != 'resnet18' and us < total / 400:
             continue
         print(f"| {i} | {desc} | {us:.0f} | {flop / us / 1e6:.0f} | {byt / us / 1e3:.0f} |")
     print("\n| entry point | ms per group | share |\n|---|---|---|")
