@@ -48,7 +48,8 @@ def krsc(w):  # [co, ci, kh, kw] -> [co, kh*kw, ci]
                                                    (32, 64, 1, 1, 8, 4), (256, 256, 3, 1, 4, 32), (96, 64, 3, 1, 6, 3),
                                                    (64, 64, 3, 1, 32, 2), (128, 128, 3, 1, 16, 3), (64, 128, 3, 1, 16, 2),   # LDS-halo kernel
                                                    (256, 128, 3, 1, 8, 4), (128, 64, 3, 1, 8, 12), (192, 64, 3, 1, 32, 1),
-                                                   (64, 64, 3, 1, 8, 2400), (64, 128, 3, 1, 16, 300), (64, 64, 3, 1, 32, 160)])   # > 2 tiles per persistent workgroup
+                                                   (64, 64, 3, 1, 8, 2400), (64, 128, 3, 1, 16, 300), (64, 64, 3, 1, 32, 160),   # > 2 tiles per persistent workgroup
+                                                   (32, 64, 1, 1, 32, 40), (32, 64, 1, 1, 32, 300)])   # stem on patches: streaming K = 32 kernel (bf16), grid-stride
 def test_conv_fwd_and_stats(dtype, cin, cout, k, stride, hw, n):
     lib = _lib()
     torch.manual_seed(0)

@@ -7,6 +7,10 @@ from fullbatchtraining_amd import lib
 CASES = {  # name: (cin, cout, k, stride, hw, n_img)
     "l1": (64, 64, 3, 1, 32, 1664), "l2": (128, 128, 3, 1, 16, 1664), "l3": (256, 256, 3, 1, 8, 1664), "l4": (512, 512, 3, 1, 4, 1664),
     "l2s": (64, 128, 3, 2, 32, 1664), "stem": (32, 64, 1, 1, 32, 1664),
+    # the downsampling blocks at the benchmark's group size (98 chunks): stride-2 3x3 and the 1x1 shortcut (on the pooled input)
+    "d2": (64, 128, 3, 2, 32, 12544), "d3": (128, 256, 3, 2, 16, 12544), "d4": (256, 512, 3, 2, 8, 12544),
+    "s2": (64, 128, 1, 1, 16, 12544), "s3": (128, 256, 1, 1, 8, 12544), "s4": (256, 512, 1, 1, 4, 12544),
+    "l2g": (128, 128, 3, 1, 16, 12544), "l3g": (256, 256, 3, 1, 8, 12544), "l4g": (512, 512, 3, 1, 4, 12544), "stemg": (32, 64, 1, 1, 32, 12544),
     "l1big": (64, 64, 3, 1, 32, 3840), "l2big": (128, 128, 3, 1, 16, 3840), "l3big": (256, 256, 3, 1, 8, 3840), "l4big": (512, 512, 3, 1, 4, 3840),
 }
 
@@ -44,6 +48,8 @@ def main():
         t = bench(lambda: lib.conv2d(dy, wt, dx, k, k, stride, pad, 1))
         print(f"{name:5s} dgrad {t:8.1f} us  {flops / t / 1e6:7.1f} TF/s")
         ipg = 128
+        if os.environ.get("NO_WGRAD"):
+            continue
         for split in ((32, 8, 1) if k == 3 and stride == 1 else (8, 1)):
             slab = torch.empty(n // ipg * split * cout * k * k * cin, device="cuda")
             try:
