@@ -131,6 +131,17 @@ __device__ __forceinline__ f32x4_t mma_split6(const split3_t& a, const split3_t&
     asm volatile("" : "+v"(c));             // pin the sum here: LLVM otherwise sinks the whole add chain below the K loop and spills every t
     return c;
 }
+// The six products straight into the running accumulator (no temporaries, no v_add): for the weight-gradient kernels, whose result is
+// not renormalised by a BatchNorm and whose two finite-difference passes see the same bias (it cancels in g' - g).
+__device__ __forceinline__ f32x4_t mma_split6_direct(const split3_t& a, const split3_t& b, f32x4_t c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.l, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, c, 0, 0, 0);
+    return c;
+}
 // One A fragment against NJ B fragments: NJ zero-started chains, interleaved product by product (independent MFMAs back to back)
 template <int NJ> __device__ __forceinline__ void mma_split6_row(const split3_t& a, const split3_t (&b)[NJ], f32x4_t (&c)[NJ]) {
     f32x4_t t[NJ];

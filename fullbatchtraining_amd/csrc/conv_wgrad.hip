@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) acc[i][j] = mma_split6(sa[i], sb[j], acc[i][j]);
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = mma_split6_direct(sa[i], sb[j], acc[i][j]);
             } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)

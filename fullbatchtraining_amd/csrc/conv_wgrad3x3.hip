@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p
                     frag_halo<T, W>(tileB, ROW, pb, t / 3, t % 3, wave * 16, lane, bf);
                     const split3_t sb = split_f32x8(bf[0], bf[1]);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[t][i] = mma_split6(sa[i], sb, acc[t][i]);
+                    for (int i = 0; i < 4; ++i) acc[t][i] = mma_split6_direct(sa[i], sb, acc[t][i]);
                 }
             } else {
 #pragma unroll
