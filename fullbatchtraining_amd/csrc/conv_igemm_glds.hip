@@ -38,9 +38,7 @@ __device__ __forceinline__ int xcd_remap1d(int b, int n) {
 }
 #define FB_OOB 0x80000000u
 
-// NS = LDS stages: 2 = the K-step after the current one is in flight; 3 = two K-steps ahead (the short-K convolutions -- stride-2 3x3,
-// 1x1 shortcuts -- spend a K-step's MFMAs (~550 cycles) well inside one L2/HBM round trip, so with one step of cover every step waits)
-template <typename T, int BN_CO, int NS = 2>
+template <typename T, int BN_CO>
 __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(const ConvParams p, const int mblocks, const int n_co) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource builtins do not exist there)
     constexpr int EB = ET<T>::EB;
@@ -48,8 +46,7 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(const ConvParams p, 
     constexpr int WROWS = BN_CO / 32;
     constexpr int FI = BN_CO / 32, FJ = 4;
     constexpr int TILE_BYTES = (128 + BN_CO) * 128;
-    __shared__ __attribute__((aligned(16))) char lds[NS * TILE_BYTES];
-    constexpr int LOADS = 4 + WROWS;                 // LDS-DMA instructions one wave issues per K-step
+    __shared__ __attribute__((aligned(16))) char lds[2 * TILE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -155,20 +152,11 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(const ConvParams p, 
 
     if (n_iter > 0) {
         advance(); issue(0);
-        if constexpr (NS == 3) {
-            if (n_iter > 1) { advance(); issue(1); wait_vmcnt<LOADS>(); } else wait_vmcnt<0>();
-        } else {
-            wait_vmcnt<0>();
-        }
+        wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        int cur = 0;
         for (int it = 0; it < n_iter; ++it) {
-            if constexpr (NS == 3) {
-                // step it+2 goes into the buffer step it-1 used (every wave has passed the barrier that ended it-1)
-                if (it + 2 < n_iter) { advance(); issue(cur == 0 ? 2 : cur - 1); }
-            } else {
-                if (it + 1 < n_iter) { advance(); issue(cur ^ 1); }
-            }
+            const int cur = it & 1;
+            if (it + 1 < n_iter) { advance(); issue(cur ^ 1); }
             const unsigned so = cur * TILE_BYTES;
             const unsigned w0 = wb + pc0 + so, w1 = wb + pc1 + so, p0 = pb + pc0 + so, p1 = pb + pc1 + so;
             uint4 wf0[FI], pf0[FJ], wf1[FI], pf1[FJ];
@@ -199,13 +187,7 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(const ConvParams p, 
 #pragma unroll
                 for (int j = 0; j < FJ; ++j) acc[i][j] = mma_chunk<T>(wf1[i], pf1[j], acc[i][j]);
             }
-            if constexpr (NS == 3) {
-                if (it + 2 < n_iter) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();     // step it+1 has landed; step it+2 may still be in flight
-                cur = cur == 2 ? 0 : cur + 1;
-            } else {
-                wait_vmcnt<0>();
-                cur ^= 1;
-            }
+            wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
         }
     }
@@ -289,20 +271,6 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(const ConvParams p, 
 
 template <typename T> static void launch(const ConvParams& p, int classes, hipStream_t st) {
     const int mblocks = (p.M + 127) / 128;
-    // FB_IGEMM_CFG (A/B): "64x3" / "128x3" = three LDS stages for every shape, "short3" = for the short-K shapes only (K-steps <= 18)
-    static const char* cfg = getenv("FB_IGEMM_CFG");
-    const int ksteps = p.R * p.S * ((p.Cs * (int)ET<T>::EB + 127) / 128);
-    const bool want3 = cfg && (strstr(cfg, "x3") || (strstr(cfg, "short3") && ksteps <= 18));
-    if (want3 && !(cfg && strstr(cfg, "128x3") && p.Cd % 128 == 0)) {
-        const int n_co = p.Cd / 64;
-        hipLaunchKernelGGL((conv_igemm_v3_kernel<T, 64, 3>), dim3(mblocks * n_co * classes), dim3(256), 0, st, p, mblocks, n_co);
-        return;
-    }
-    if (want3) {
-        const int n_co = p.Cd / 128;
-        hipLaunchKernelGGL((conv_igemm_v3_kernel<T, 128, 3>), dim3(mblocks * n_co * classes), dim3(256), 0, st, p, mblocks, n_co);
-        return;
-    }
     if (p.Cd % 128 == 0 && (long long)mblocks * (p.Cd / 128) * classes >= 512) {
         const int n_co = p.Cd / 128;
         hipLaunchKernelGGL((conv_igemm_v3_kernel<T, 128>), dim3(mblocks * n_co * classes), dim3(256), 0, st, p, mblocks, n_co);

@@ -45,8 +45,10 @@ def _run(meta, name, extra=(), tmp_path=None, valid_full=False):
                                             # optimizer wrappers around the closure: SAM records two closures per step
                                             ("fb_sam", 1e-3, 3), ("fb_sam_gradreg", 8e-3, 2),
                                             # (3 steps without warm-up: steps 1-2 agree with the float64 run to 1e-7..1e-5, the third sits on the fp32
-                                            # noise floor of the moved parameters -- up to 2e-3 here, 3e-3 for the reference's own fp32 run on fb_lars)
-                                            ("fb_lars", 3e-3, 1), ("fb_larc", 3e-3, 2),
+                                            # noise floor of the moved parameters: the last-step losses of ALL scenarios scatter between 1e-7 and 5e-3 around the float64 run
+                                            # for the exact-f32 engine, the split-bf16 engine and the reference's own fp32 run alike, without order --
+                                            # profiles/r2_split_vs_exact_parity.md)
+                                            ("fb_lars", 5e-3, 1), ("fb_larc", 5e-3, 2),
                                             # off-by-default options of the gradient modification: L-inf clip, norm bias
                                             # (the L-inf norm is ONE gradient element: its fp32 noise, ~1e-3, scales the whole update -- the CPU oracle in fp32
                                             # lands 3.6e-3 from the reference's float64 loss at step 3 as well)

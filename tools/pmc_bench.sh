@@ -7,7 +7,7 @@ out=gpurun_out/pmcbench_$tag; mkdir -p $out
 i=0
 for c in FETCH_SIZE WRITE_SIZE; do
   i=$((i+1))
-  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/p$i -o p$i -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --serialize > $out/p$i.txt 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/p$i -o p$i -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-side-configs --serialize > $out/p$i.txt 2>&1
 done
 python3 - <<PY > $out/summary.md
 import csv, collections
@@ -45,12 +45,12 @@ for d in sorted(per):
     b = (2 * per[d][0] + per[d][1]) * 1e3                      # KB -> bytes, FETCH_SIZE doubled (MI355X_MICROARCH.md, gfx950)
     if n.startswith("void conv_wgrad") :
         cls["wgrad"].append(b)
-    elif any(t in n for t in ("conv3x3s1_halo4", "conv3x3s1_c64_halo5", "conv_igemm_v3", "conv_igemm_kernel")):
+    elif any(t in n for t in ("conv3x3s1_halo4", "conv3x3s1_c64_halo5", "conv_igemm_v3", "conv_igemm_kernel", "conv1x1_k32")):
         cls["igemm_fwd" if k % 39 < 20 else "igemm_dgrad"].append(b)
         if "halo5_kernel<0" in n: assert k % 39 < 20, (k, n)
         if "halo5_kernel<1" in n: assert k % 39 >= 20, (k, n)
         k += 1
-print(json.dumps({"command": "tools/pmc_bench.sh $tag (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per pass, bench.py --steps 1 --warmup 0 --serialize)",
+print(json.dumps({"command": "tools/pmc_bench.sh $tag (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per pass, bench.py --steps 1 --warmup 0 --no-side-configs --serialize)",
                   "unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)",
                   "classes": {c: {"launches": len(v), "bytes_per_launch": sum(v) / len(v)} for c, v in cls.items()}}, indent=1))
 PY
