@@ -323,7 +323,10 @@ def main():
                 return res, flops
 
             kernels, flops = per_class(prof, args.steps)
-            dom = max(kernels, key=lambda k: kernels[k]["ms_total"])
+            iso = per_class(prof_iso, 1)[0] if prof_iso is not None else None
+            # dominant class = the one with the most kernel time when every kernel has the device to itself (inside the timed region the
+            # weight-gradient launches of the second stream overlap the others, so the in-region durations are not additive)
+            dom = max(iso or kernels, key=lambda k: (iso or kernels)[k]["ms_total"])
             # HBM bytes per launch of the same kernel class from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, one counter per rocprofv3
             # pass as MI355X_MICROARCH.md prescribes; tools/pmc_bench.sh writes the file, profiles/ keeps the copy behind the number)
             traffic, traffic_src = None, None
@@ -341,7 +344,8 @@ def main():
                                "measured": "HIP events on the launch stream around every launch of the class, inside the timed region"
                                            + (" (--serialize: one stream)" if args.serialize else " (production schedule: weight-gradient kernels "
                                               "run on a second stream beside these launches; `isolated` = the same from one extra step with one stream)"),
-                               "isolated": per_class(prof_iso, 1)[0] if prof_iso is not None else None,
+                               "achieved_isolated": iso[dom]["tflops"] if iso else None, "frac_isolated": round(iso[dom]["tflops"] / peak, 4) if iso else None,
+                               "isolated": iso,
                                "step_mfma_frac": round((3328997376 if headline else sum(conv_flops(eng.plan, 1).values())) * passes * images_per_step * steps_per_sec / world / (peak * 1e12), 4)}
         if world == 1 and headline and args.grad_reg == 0 and trainer.dtype == torch.bfloat16 and not args.no_side_configs:
             out.update(side_configs(args, device, X, Y, trainer))

@@ -196,7 +196,6 @@ int fb_try_conv3x3_halo4(const fb_conv_args* a, hipStream_t st);   // conv3x3_ha
 int fb_try_conv3x3_halo5(const fb_conv_args* a, hipStream_t st);   // conv3x3_halo5.hip
 int fb_conv3x3_halo5_takes(const fb_conv_args* a);
 int fb_try_conv3x3s2_dgrad_quad(const fb_conv_args* a, hipStream_t st);   // conv3x3s2_dgrad_quad.hip
-int fb_try_conv3x3s2_fwd(const fb_conv_args* a, hipStream_t st);          // conv3x3s2_fwd.hip
 int fb_try_conv1x1_k32(const fb_conv_args* a, hipStream_t st);     // conv1x1_k32.hip (the stem on pre-gathered patches)
 
 // 1 if fb_conv2d accepts `addend_mask` for these arguments (only the resident-filter 64-channel kernel applies the mask so far)
@@ -256,7 +255,7 @@ extern "C" int fb_conv2d(const fb_conv_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int prof = fb_prof_begin(a->mode == 0 ? FB_PROF_IGEMM_FWD : FB_PROF_IGEMM_DGRAD, st);
     static const bool v1 = getenv("FB_IGEMM_V1") != nullptr;
-    if (!fb_try_conv1x1_k32(a, st) && !fb_try_conv3x3s2_dgrad_quad(a, st) && !fb_try_conv3x3s2_fwd(a, st) && !fb_try_conv3x3_halo5(a, st) && !fb_try_conv3x3_halo4(a, st)) {
+    if (!fb_try_conv1x1_k32(a, st) && !fb_try_conv3x3s2_dgrad_quad(a, st) && !fb_try_conv3x3_halo5(a, st) && !fb_try_conv3x3_halo4(a, st)) {
         p.zeros = nullptr;
         if (v1 || !fb_launch_igemm_glds(p, classes, a->dtype, st)) {
             if (a->dtype == FB_F32) launch_conv<float>(p, classes, st); else launch_conv<bf16_tag>(p, classes, st);

