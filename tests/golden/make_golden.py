@@ -432,12 +432,106 @@ def checkpoint_interchange(fullbatch, compose, out):
     return res
 
 
+def lmdb_vectors(fullbatch, out):
+    """the record databases of `fullbatch/data/lmdb_datasets.py`.  The third-party `lmdb` package is not installed here, so
+    the reference's writer (`_create_database`) and reader (`LMDBDataset`) run against a dict-backed stand-in for the small part of
+    its API they use (tests/helpers.py::DictLMDB), plus minimal stand-ins for the three torchvision transform classes they touch.
+    What is recorded: every key/value pair the reference WROTE (CHW and HWC layouts, one and two `rounds`), the base images / labels,
+    and items the reference's own reader returned (cursor and get access)."""
+    from PIL import Image
+
+    from fullbatchtraining_amd.cfg import AttrDict
+    from tests.helpers import DictLMDB
+
+    import importlib
+    mod = importlib.import_module("fullbatch.data.lmdb_datasets")      # lazily imported by the reference as well (data_preparation.py:27)
+
+    class ToTensor:
+        def __call__(self, pic):
+            return torch.from_numpy(np.asarray(pic, dtype=np.uint8).copy()).permute(2, 0, 1).to(torch.float) / 255
+
+    class PILToTensor:
+        def __call__(self, pic):
+            return torch.from_numpy(np.asarray(pic, dtype=np.uint8).copy()).permute(2, 0, 1)
+
+    class Normalize:
+        def __init__(self, mean, std):
+            self.mean, self.std = torch.tensor(mean).view(-1, 1, 1), torch.tensor(std).view(-1, 1, 1)
+
+        def __call__(self, t):
+            return (t - self.mean) / self.std
+
+    class Compose:
+        def __init__(self, transforms):
+            self.transforms = transforms
+
+        def __call__(self, x):
+            for t in self.transforms:
+                x = t(x)
+            return x
+
+    for tv in (sys.modules["torchvision"].transforms, sys.modules["torchvision.transforms"], mod.torchvision.transforms):
+        tv.ToTensor, tv.PILToTensor, tv.Normalize, tv.Compose = ToTensor, PILToTensor, Normalize, Compose
+    mod.lmdb = DictLMDB
+    identity = Compose([])
+    mod._parse_data_augmentations = lambda cfg, PIL_only=False: (identity, identity)      # rounds > 1 re-write the base images un-augmented
+
+    class Base(torch.utils.data.Dataset):                   # a torchvision-style dataset: PIL image in, `transform` applied
+        classes = list(range(10))
+
+        def __init__(self, images, labels, transform):
+            self.images, self.labels, self.transform = images, labels, transform
+
+        def __len__(self):
+            return len(self.labels)
+
+        def __getitem__(self, i):
+            return self.transform(Image.fromarray(self.images[i])), self.labels[i]
+
+    rng = np.random.default_rng(5)
+    n = 23
+    images = rng.integers(0, 256, size=(n, 32, 32, 3), dtype=np.uint8)
+    labels = [int(v) for v in rng.integers(0, 10, size=n)]
+    mean, std = [0.4914, 0.4822, 0.4465], [0.2470, 0.2435, 0.2616]
+    out["lmdb/base_images"], out["lmdb/base_labels"] = images, np.array(labels)
+    out["lmdb/mean_std"] = np.array([mean, std])
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)                                 # the writer sizes its DataLoader workers from it
+    try:
+        for tag, tfs, rounds in (("chw_r1", [ToTensor(), Normalize(mean, std)], 1), ("hwc_r2", [Normalize(mean, std)], 2)):
+            path = os.path.join(tempfile.mkdtemp(), f"{tag}.lmdb")
+            cfg_db = AttrDict(path=os.path.dirname(path), temporary_database=False, rounds=rounds, first_round_clean=True, shuffle_while_writing=False,
+                              augmentations_train=None, augmentations_val=None, rebuild_existing_database=False, access="cursor", max_readers=8,
+                              readahead=False, meminit=False, max_spare_txns=8, write_frequency=7, pixels=32, mean=mean, normalize=True)
+            ds = Base(images, labels, Compose(list(tfs)))
+            chw = isinstance(tfs[0], ToTensor)
+            if chw:                                          # the reference's own constructor: chooses the path, writes, re-opens, reads
+                reader = mod.LMDBDataset(ds, cfg_db, name="train", can_create=True)
+                store = DictLMDB._stores[str(reader.path)]
+                items = [reader[i] for i in (0, 1, 11, 22, 5)]                 # cursor access, out of order
+                reader.access = "get"
+                items += [reader[i] for i in (3, 22)]
+                out[f"lmdb/{tag}/item_index"] = np.array([0, 1, 11, 22, 5, 3, 22])
+                out[f"lmdb/{tag}/item_images"] = np.stack([it[0].numpy() for it in items])
+                out[f"lmdb/{tag}/item_labels"] = np.array([it[1] for it in items])
+            else:                                            # HWC records (a dataset whose first transform is not ToTensor): the writer only
+                mod._create_database(ds, path, cfg_db, db_channels_first=False, name="train")
+                store = DictLMDB._stores[str(path)]
+            keys = sorted(store)
+            out[f"lmdb/{tag}/keys"] = np.array([k.decode("latin1") for k in keys])
+            out[f"lmdb/{tag}/value_lengths"] = np.array([len(store[k]) for k in keys])
+            out[f"lmdb/{tag}/values"] = np.frombuffer(b"".join(store[k] for k in keys), dtype=np.uint8)
+    finally:
+        torch.set_num_threads(threads)
+
+
 def main_r2():
     torch.set_num_threads(8)
     fullbatch = import_reference()
     from fullbatchtraining_amd.cfg import compose
 
     out = {}
+    lmdb_vectors(fullbatch, out)             # first: its DataLoader forks a worker, which must happen before the OpenMP pool has been used
     for name in SCENARIOS_R2:
         run_scenario(fullbatch, compose, name, out)
         run_scenario(fullbatch, compose, name, out, dtype=torch.double)

@@ -53,3 +53,71 @@ def loader_pass_indices(loader):
     (torch DataLoader: the iterator draws a base seed first, then the sampler draws its permutation)."""
     torch.empty((), dtype=torch.int64).random_(generator=loader.generator)
     return torch.tensor([i for batch in loader.batch_sampler for i in batch], dtype=torch.long)
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# A dict-backed stand-in for the part of the third-party `lmdb` API the reference's LMDB dataset code uses (fullbatch/data/
+# lmdb_datasets.py: open / begin / put / get / commit / cursor first-key-value-set_key-next).  tests/golden/make_golden.py --r2 hands it
+# to the REFERENCE's writer and reader (the `lmdb` package is not installed in the build image); the tests rebuild a store from the
+# committed key/value fixture.  Keys iterate in byte order, like LMDB's B+tree.
+class DictLMDB:
+    _stores = {}
+
+    class _Cursor:
+        def __init__(self, store):
+            self.store, self.keys, self.pos = store, sorted(store), 0
+
+        def first(self):
+            self.pos = 0
+            return bool(self.keys)
+
+        def key(self):
+            return self.keys[self.pos] if self.pos < len(self.keys) else b""
+
+        def value(self):
+            return self.store[self.keys[self.pos]] if self.pos < len(self.keys) else b""
+
+        def set_key(self, key):
+            import bisect
+            i = bisect.bisect_left(self.keys, key)
+            if i < len(self.keys) and self.keys[i] == key:
+                self.pos = i
+                return True
+            return False
+
+        def next(self):
+            self.pos += 1
+            return self.pos < len(self.keys)
+
+    class _Txn:
+        def __init__(self, store):
+            self.store = store
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            return False
+
+        def put(self, key, value):
+            self.store[bytes(key)] = bytes(value)
+            return True
+
+        def get(self, key, default=None):
+            return self.store.get(bytes(key), default)
+
+        def commit(self):
+            pass
+
+        def cursor(self):
+            return DictLMDB._Cursor(self.store)
+
+    def __init__(self, store=None):
+        self.store = {} if store is None else store
+
+    def begin(self, write=False, **kwargs):
+        return DictLMDB._Txn(self.store)
+
+    @classmethod
+    def open(cls, path, **kwargs):
+        return cls(cls._stores.setdefault(str(path), {}))

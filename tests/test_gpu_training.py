@@ -299,3 +299,32 @@ def test_device_augmentation_changes_the_feed_every_step(tmp_path):
     assert not torch.equal(feeds_a[0], feeds_a[1]) and not torch.equal(feeds_a[1], feeds_a[2])      # new draw every step
     assert torch.equal(feeds_s[0], feeds_s[2]) and not torch.equal(feeds_s[0], feeds_a[0])          # static feed without the switch
     assert loss_a[0] != loss_s[0] and all(np.isfinite(loss_a))
+
+
+def test_train_from_lmdb_record_database(golden, tmp_path):
+    """N x CIFAR-style feed (SURVEY 8f N3): a record database written by the REFERENCE's LMDB writer (2 rounds over 23 images, HWC records;
+    tests/test_cpu_data.py) decoded by ``LMDBRecords.as_feed`` and trained on -- chunks of 23 images (stored padded to 24) -- against the
+    float64 oracle on the same tensors."""
+    from fullbatchtraining_amd.cfg import compose
+    from fullbatchtraining_amd.data import LMDBRecords
+    from fullbatchtraining_amd.models import construct_model
+    from fullbatchtraining_amd.training import train
+    from oracle import fb_oracle as orc
+    from tests.helpers import DictLMDB, hyp_from_cfg
+    from tests.test_cpu_data import _store
+
+    data, _ = golden
+    rec = LMDBRecords(env=DictLMDB(_store(data, "hwc_r2")), access="cursor")
+    x, y = rec.as_feed(*data["lmdb/mean_std"])
+    assert x.shape == (46, 3, 32, 32)
+    cfg = compose(["hyp=fbclip", "hyp.steps=2", "hyp.warmup=0", "data.batch_size=23", "hyp.sub_batch=23", "impl.validate_every_nth_step=1000",
+                   "impl.engine.chunk_group=2"], original_cwd=str(tmp_path), name="lmdb")
+    torch.manual_seed(2)
+    model = construct_model(cfg.model, 3, 10)
+    state = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+    want = orc.train(orc.Spec(18), state, x.double(), y, hyp_from_cfg(cfg), 2, 23, cfg.hyp.scheduler, cfg.hyp.warmup)
+    setup = dict(device=torch.device("cuda:0"), dtype=torch.float, memory_format=torch.contiguous_format)
+    stats = train(model, (x, y), None, setup, cfg)
+    for key in ("train_loss", "grad_norm", "param_norm", "full_loss", "preclip_gradnorm", "train_acc"):
+        assert np.allclose(stats[key], want[key], rtol=2e-3, atol=1.01 / 46 if key == "train_acc" else 1e-6), (key, stats[key], want[key])
+    assert abs(stats["train_loss"][0] - want["train_loss"][0]) < 1e-5 * want["train_loss"][0]
