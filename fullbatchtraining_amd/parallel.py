@@ -113,6 +113,8 @@ class BucketExchange:
                 torch.cuda.current_stream().wait_event(ev)  # the stream the bucket was started on (scale + gloo copy)
             if work is not None:
                 work.wait()                                 # current stream waits for the collective
+            if shard.is_cuda:
+                shard.record_stream(torch.cuda.current_stream())     # allocated under the side stream, read here
             self.avg[lo_r:lo_r + n].copy_(shard)
             part2 = self.ops.sqnorm(self.avg[lo_r:lo_r + n]).reshape(1).clone()
             gnorm2 = part2 if gnorm2 is None else gnorm2 + part2

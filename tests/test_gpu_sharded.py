@@ -32,7 +32,12 @@ def _run(rank, world, port, out_dir, grad_reg, backend="gloo", tag=None):
 
     dev = rank if backend == "nccl" and world > 1 else 0          # RCCL: one device per rank; gloo: the ranks share cuda:0
     torch.cuda.set_device(dev)
+    # "onegroup*": all chunks of a rank in ONE chunk group (what a rank of an 8-GPU job runs: 49 chunks <= chunk_group 98) -- the only
+    # schedule in which the late bucket of the exchange leaves from inside the backward pass (Engine.full_gradient(late_bucket=...))
+    one = ["impl.engine.chunk_group=8"]
     extra = {False: [], True: ["hyp.grad_reg.block_strength=0.5"], "options": OPTIONS, "shuffle": [], "ckpt": [], "ckpt_resume": ["hyp.steps=5"],
+             "onegroup": one, "onegroup_gradreg": one + ["hyp.grad_reg.block_strength=0.5"],
+             "onegroup_central": one + ["hyp.grad_reg.block_strength=0.5", "hyp.grad_reg.implementation=central-differences"],
              "acc": ["hyp.grad_reg.block_strength=0.0", "hyp.grad_reg.acc_strength=0.5", "hyp.grad_reg.implementation=central-differences"]}
     over = list(OVERRIDES) + extra[grad_reg]
     if world > 1 or backend == "nccl":
@@ -66,7 +71,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("grad_reg", [False, True, "options", "acc", "shuffle"])
+@pytest.mark.parametrize("grad_reg", [False, True, "options", "acc", "shuffle", "onegroup", "onegroup_gradreg", "onegroup_central"])
 def test_two_rank_run_equals_single_process(tmp_path, grad_reg):
     """plain step and regulariser: sharded update (reduce-scatter / all-gather); "options": SAM + L-infinity clip + norm bias +
     per-tensor weight decay + gradient noise (rank 0's draw, broadcast), which all-reduce the gradient and replicate the 1-process update; "acc": the acc_strength pre-pass
@@ -81,7 +86,7 @@ def test_two_rank_run_equals_single_process(tmp_path, grad_reg):
             atol = 1.01 / N if key == "train_acc" else 1e-6          # one prediction may flip once the parameters differ in the last bits
             # ("acc": the central-difference term divides the difference of two fp32 gradients by 2 eps_n -- a last-bit difference in the
             # all-reduced pre-pass mean is 7e-3 on the clip norm of step 3; steps 1-2 are asserted bit-equal below)
-            rtol = {False: 2e-4, "acc": 2e-2}.get(grad_reg, 5e-3)
+            rtol = {False: 2e-4, "onegroup": 2e-4, "acc": 2e-2}.get(grad_reg, 5e-3)
             assert np.allclose(got["stats"][key], ref["stats"][key], rtol=rtol, atol=atol), (key, got["stats"][key], ref["stats"][key])
         if grad_reg == "acc":      # warm-up step (lr = 0) and the step after it see identical parameters: the exchange itself is exact
             for key in ("train_loss", "grad_norm", "full_loss", "param_norm"):
@@ -89,7 +94,7 @@ def test_two_rank_run_equals_single_process(tmp_path, grad_reg):
         for k in range(7):
             # steps 1-2 agree to the bit; from step 3 on the parameters differ in the last bits (the ranks sum the full-batch
             # gradient in a different order) and a chunk gradient amplifies that to ~1e-4 (fp32 noise floor, cf. test_gpu_training)
-            assert np.allclose(got["stats"][f"grad_norm_train_{k}"], ref["stats"][f"grad_norm_train_{k}"], rtol=1e-3 if grad_reg is False else 5e-3), (
+            assert np.allclose(got["stats"][f"grad_norm_train_{k}"], ref["stats"][f"grad_norm_train_{k}"], rtol=1e-3 if grad_reg in (False, "onegroup") else 5e-3), (
                 k, got["stats"][f"grad_norm_train_{k}"], ref["stats"][f"grad_norm_train_{k}"])
         for name, t in ref["state"].items():
             if t.is_floating_point():
@@ -100,7 +105,8 @@ def test_two_rank_run_equals_single_process(tmp_path, grad_reg):
                 # fp32 chunk-gradient noise (order of sums differs); the central-difference acc term divides the difference of two such
                 # gradients by 2 eps_n: a last-bit difference in the all-reduced pre-pass mean moves a weight by up to 4 % after the
                 # first real update (steps 1-2, taken at identical parameters, agree to the bit -- asserted below)
-                tol = {False: 1e-3, True: 1e-2, "options": 1e-2, "acc": 6e-2, "shuffle": 1e-2}[grad_reg]
+                tol = {False: 1e-3, True: 1e-2, "options": 1e-2, "acc": 6e-2, "shuffle": 1e-2, "onegroup": 1e-3, "onegroup_gradreg": 1e-2,
+                       "onegroup_central": 1e-2}[grad_reg]
                 assert float((got["state"][name] - t).abs().max()) < tol * scale + 1e-6, name
             else:
                 assert torch.equal(got["state"][name], t), name
@@ -123,15 +129,19 @@ def test_rccl_collectives_one_rank(tmp_path, monkeypatch):
     backend with a process group of ONE rank on cuda:0 (FB_FORCE_DIST=1 routes the step through the sharded path): on a 1-GPU box this
     is the only way to execute those calls; the arithmetic must equal the plain 1-process step bit for bit."""
     out = str(tmp_path)
-    mp.spawn(_run, args=(1, 0, out, False), nprocs=1, join=True)
-    monkeypatch.setenv("FB_FORCE_DIST", "1")
-    mp.spawn(_run, args=(1, _free_port(), out, False, "nccl", "rccl1"), nprocs=1, join=True)
-    ref, got = torch.load(os.path.join(out, "w1_r0.pt")), torch.load(os.path.join(out, "rccl1_r0.pt"))
-    _compare(got, ref)
-    for key in ("train_loss", "grad_norm", "param_norm"):
-        assert got["stats"][key] == ref["stats"][key], key
-    for a, b in zip(got["grads"], ref["grads"]):
-        assert torch.equal(a, b)
+    for mode in (False, "onegroup", "onegroup_gradreg"):      # "onegroup*": the late bucket's asynchronous reduce-scatter starts on the side stream
+        monkeypatch.delenv("FB_FORCE_DIST", raising=False)
+        mp.spawn(_run, args=(1, 0, out, mode), nprocs=1, join=True)
+        monkeypatch.setenv("FB_FORCE_DIST", "1")
+        mp.spawn(_run, args=(1, _free_port(), out, mode, "nccl", "rccl1"), nprocs=1, join=True)
+        ref, got = torch.load(os.path.join(out, "w1_r0.pt")), torch.load(os.path.join(out, "rccl1_r0.pt"))
+        _compare(got, ref, mode)
+        for key in ("train_loss", "param_norm"):
+            assert got["stats"][key] == ref["stats"][key], (mode, key)
+        # (with an early bucket |g_k|^2 is the sum of two partial sums: last-bit differences in the recorded chunk norms only)
+        assert np.allclose(got["stats"]["grad_norm"], ref["stats"]["grad_norm"], rtol=0 if mode is False else 1e-6), mode
+        for a, b in zip(got["grads"], ref["grads"]):
+            assert torch.equal(a, b), mode
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL wants one device per rank")
