@@ -117,6 +117,7 @@ def side_configs(args, device, X, Y, main_trainer):
     t0 = time.perf_counter()
     for _ in range(n_steps):
         tr.step()
+    tr.flush_stats()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n_steps
     flop = 2 * 3328997376 * tr.datapoints
@@ -267,6 +268,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         trainer.step()
+    trainer.flush_stats()            # the statistics of every timed step are read back and recorded inside the timed region
     sync()
     elapsed = time.perf_counter() - t0
     prof, prof_iso = None, None
