@@ -112,6 +112,35 @@ __device__ __forceinline__ split3_t split_f32x8(const uint4& c0, const uint4& c1
     o.l = __builtin_bit_cast(bf16x8_t, make_uint4(lp[0], lp[1], lp[2], lp[3]));
     return o;
 }
+// four fp32 values (one 16-byte chunk) -> the 8-byte bf16x4 pieces of the three planes (weight-gradient kernels split once per loaded
+// element when they store a tile to LDS and read the planes with the transposed bf16 fragment reads)
+__device__ __forceinline__ void split_f32x4(const uint4& c, uint2& h, uint2& m, uint2& l) {
+    const unsigned w[4] = {c.x, c.y, c.z, c.w};
+    unsigned hp[2], mp[2], lp[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const float x0 = __uint_as_float(w[2 * q]), x1 = __uint_as_float(w[2 * q + 1]);
+        hp[q] = pack_bf16x2(x0, x1);
+        const float r0 = x0 - __uint_as_float(hp[q] << 16), r1 = x1 - __uint_as_float(hp[q] & 0xffff0000u);
+        mp[q] = pack_bf16x2(r0, r1);
+        const float s0 = r0 - __uint_as_float(mp[q] << 16), s1 = r1 - __uint_as_float(mp[q] & 0xffff0000u);
+        lp[q] = pack_bf16x2(s0, s1);
+    }
+    h = make_uint2(hp[0], hp[1]); m = make_uint2(mp[0], mp[1]); l = make_uint2(lp[0], lp[1]);
+}
+// the six products of two already split operands (bf16x8 per plane), straight into the accumulator
+__device__ __forceinline__ f32x4_t mma_planes6(const uint4 (&a)[3], const uint4 (&b)[3], f32x4_t c) {
+    const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, a[0]), am = __builtin_bit_cast(bf16x8_t, a[1]), al = __builtin_bit_cast(bf16x8_t, a[2]);
+    const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, b[0]), bm = __builtin_bit_cast(bf16x8_t, b[1]), bl = __builtin_bit_cast(bf16x8_t, b[2]);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+    return c;
+}
+
 // Six bf16 MFMAs, smallest terms first, into a ZERO-started accumulator; the 32-deep partial sum is then added to the running
 // accumulator with v_add_f32 (round to nearest even).  Measured on one 16x16 block with K = 4608 against float64
 // (tools/mfma_accum_probe.hip): accumulating the six products straight into the running sum has the L2 error of the exact-f32 MFMA
@@ -129,17 +158,6 @@ __device__ __forceinline__ f32x4_t mma_split6(const split3_t& a, const split3_t&
     t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, t, 0, 0, 0);
     c += t;
     asm volatile("" : "+v"(c));             // pin the sum here: LLVM otherwise sinks the whole add chain below the K loop and spills every t
-    return c;
-}
-// The six products straight into the running accumulator (no temporaries, no v_add): for the weight-gradient kernels, whose result is
-// not renormalised by a BatchNorm and whose two finite-difference passes see the same bias (it cancels in g' - g).
-__device__ __forceinline__ f32x4_t mma_split6_direct(const split3_t& a, const split3_t& b, f32x4_t c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b.h, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.l, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.m, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.h, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.m, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, c, 0, 0, 0);
     return c;
 }
 // One A fragment against NJ B fragments: NJ zero-started chains, interleaved product by product (independent MFMAs back to back)

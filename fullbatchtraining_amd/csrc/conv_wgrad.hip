@@ -49,10 +49,6 @@ template <> __device__ __forceinline__ void load_frag_t<float>(const char* tile,
     out[1] = make_uint4(v[4], v[5], v[6], v[7]);
 }
 
-template <> __device__ __forceinline__ void load_frag_t<f32s_tag>(const char* tile, int row_bytes, int pb, int c0, int lane, uint4 (&out)[2]) {
-    load_frag_t<float>(tile, row_bytes, pb, c0, lane, out);
-}
-
 template <typename T, int WM, int WN, int WK, int KREP, int NJ>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     constexpr int EB = ET<T>::EB;
@@ -62,12 +58,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     constexpr int CH_A = TM * EB / 16, CH_B = TN * EB / 16;   // 16-byte chunks per row
     constexpr int LD_A = KPX * CH_A / 256, LD_B = KPX * CH_B / 256;   // chunks per thread
     static_assert(KPX * CH_A % 256 == 0 && KPX * CH_B % 256 == 0, "tile/threads");
-    constexpr int TILE_BYTES = KPX * (ROW_A + ROW_B);
+    // split path (fp32 storage, bf16x6 arithmetic): a tile is stored to LDS as THREE bf16 planes (h, m, l: every loaded element is
+    // split once, 22 VALU per 16-byte chunk) and the fragments come from the transposed bf16 reads of the bf16 kernel -- no per-fragment
+    // split (44 VALU per fragment and wave before), 6 ds_read_b64_tr_b16 instead of 8 ds_read_b32 per fragment
+    constexpr bool SPLIT = is_split<T>::value;
+    constexpr int PROW_A = TM * 2 + WG<bf16_tag>::PAD, PROW_B = TN * 2 + WG<bf16_tag>::PAD;      // plane rows (bf16)
+    constexpr int PLANE_A = KPX * PROW_A, PLANE_B = KPX * PROW_B;
+    constexpr int TILE_BYTES = SPLIT ? 3 * (PLANE_A + PLANE_B) : KPX * (ROW_A + ROW_B);
     constexpr int RED_BYTES = (WK > 1) ? WK * 64 * 16 * NJ * 4 : 0;
     constexpr int LDS_BYTES = TILE_BYTES > RED_BYTES ? TILE_BYTES : RED_BYTES;
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     char* tileA = lds;
-    char* tileB = lds + KPX * ROW_A;
+    char* tileB = lds + (SPLIT ? 3 * PLANE_A : KPX * ROW_A);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
@@ -110,10 +112,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         }
     };
     auto lstore = [&]() {
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int i = 0; i < LD_A; ++i) {
+                const int id = tid + 256 * i, row = id / CH_A, ch = id % CH_A;
+                uint2 h, m, l;
+                split_f32x4(ra[i], h, m, l);
+                char* d = tileA + row * PROW_A + ch * 8;
+                *(uint2*)d = h; *(uint2*)(d + PLANE_A) = m; *(uint2*)(d + 2 * PLANE_A) = l;
+            }
+#pragma unroll
+            for (int i = 0; i < LD_B; ++i) {
+                const int id = tid + 256 * i, row = id / CH_B, ch = id % CH_B;
+                uint2 h, m, l;
+                split_f32x4(rb[i], h, m, l);
+                char* d = tileB + row * PROW_B + ch * 8;
+                *(uint2*)d = h; *(uint2*)(d + PLANE_B) = m; *(uint2*)(d + 2 * PLANE_B) = l;
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < LD_A; ++i) { const int id = tid + 256 * i, row = id / CH_A, ch = id % CH_A; *(uint4*)(tileA + row * ROW_A + ch * 16) = ra[i]; }
 #pragma unroll
         for (int i = 0; i < LD_B; ++i) { const int id = tid + 256 * i, row = id / CH_B, ch = id % CH_B; *(uint4*)(tileB + row * ROW_B + ch * 16) = rb[i]; }
+        }
     };
 
     if (k_begin < k_end) gload(k_begin);
@@ -125,22 +146,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
         for (int rep = 0; rep < KREP; ++rep) {
             const int pb = (wk * KREP + rep) * 32;
+            if constexpr (SPLIT) {
+                uint4 ap[4][3], bp[NJ][3], tmp[2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) { load_frag_t<bf16_tag>(tileA + pl * PLANE_A, PROW_A, pb, wm * 64 + i * 16, lane, tmp); ap[i][pl] = tmp[0]; }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) { load_frag_t<bf16_tag>(tileB + pl * PLANE_B, PROW_B, pb, wn * 16 * NJ + j * 16, lane, tmp); bp[j][pl] = tmp[0]; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = mma_planes6(ap[i], bp[j], acc[i][j]);
+            } else {
             uint4 af[4][2], bf[NJ][2];
 #pragma unroll
             for (int i = 0; i < 4; ++i) load_frag_t<T>(tileA, ROW_A, pb, wm * 64 + i * 16, lane, af[i]);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) load_frag_t<T>(tileB, ROW_B, pb, wn * 16 * NJ + j * 16, lane, bf[j]);
-            if constexpr (is_split<T>::value) {      // fp32 operands as three bf16 pieces each, six MFMAs per fragment pair (common.h)
-                split3_t sa[4], sb[NJ];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) sa[i] = split_f32x8(af[i][0], af[i][1]);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) sb[j] = split_f32x8(bf[j][0], bf[j][1]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) acc[i][j] = mma_split6_direct(sa[i], sb[j], acc[i][j]);
-            } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll

@@ -82,10 +82,6 @@ template <int W> __device__ __forceinline__ void frag_halo_f32(const char* tile,
 template <> __device__ __forceinline__ void frag_halo<float, 32>(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) { frag_halo_f32<32>(tile, row_bytes, pb, r, s, c0, lane, out); }
 template <> __device__ __forceinline__ void frag_halo<float, 16>(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) { frag_halo_f32<16>(tile, row_bytes, pb, r, s, c0, lane, out); }
 
-template <> __device__ __forceinline__ void frag_plain<f32s_tag>(const char* tile, int row_bytes, int pb, int c0, int lane, uint4 (&out)[2]) { frag_plain<float>(tile, row_bytes, pb, c0, lane, out); }
-template <> __device__ __forceinline__ void frag_halo<f32s_tag, 32>(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) { frag_halo_f32<32>(tile, row_bytes, pb, r, s, c0, lane, out); }
-template <> __device__ __forceinline__ void frag_halo<f32s_tag, 16>(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) { frag_halo_f32<16>(tile, row_bytes, pb, r, s, c0, lane, out); }
-
 template <typename T, int W>
 __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p) {
     constexpr int EB = ET<T>::EB;
@@ -95,9 +91,14 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p
     constexpr int CH = 64 * EB / 16;                 // 16-byte chunks per row
     constexpr int LD_A = 64 * CH / 256;              // dY chunks per thread
     constexpr int LD_B = (HROWS * CH + 255) / 256;   // halo chunks per thread
-    __shared__ __attribute__((aligned(16))) char lds[(64 + HROWS) * ROW];
+    // split path (fp32 storage, bf16x6 arithmetic): both tiles are stored as THREE bf16 planes (every loaded element split once, at
+    // the LDS store) and read with the transposed bf16 fragment reads -- no per-fragment split in the tap loop
+    constexpr bool SPLIT = is_split<T>::value;
+    constexpr int PROW = 64 * 2 + W3<bf16_tag>::PAD; // plane row (bf16)
+    constexpr int PLANE_A = 64 * PROW, PLANE_B = HROWS * PROW;
+    __shared__ __attribute__((aligned(16))) char lds[SPLIT ? 3 * (PLANE_A + PLANE_B) : (64 + HROWS) * ROW];
     char* tileA = lds;
-    char* tileB = lds + 64 * ROW;
+    char* tileB = lds + (SPLIT ? 3 * PLANE_A : 64 * ROW);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_n = p.Cs / 64;
@@ -137,10 +138,31 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p
         }
     };
     auto lstore = [&]() {
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int i = 0; i < LD_A; ++i) {
+                const int id = tid + 256 * i, row = id / CH, ch = id % CH;
+                uint2 h, m, l;
+                split_f32x4(ra[i], h, m, l);
+                char* d = tileA + row * PROW + ch * 8;
+                *(uint2*)d = h; *(uint2*)(d + PLANE_A) = m; *(uint2*)(d + 2 * PLANE_A) = l;
+            }
+#pragma unroll
+            for (int i = 0; i < LD_B; ++i) {
+                const int id = tid + 256 * i, row = id / CH, ch = id % CH;
+                if (row < HROWS) {
+                    uint2 h, m, l;
+                    split_f32x4(rb[i], h, m, l);
+                    char* d = tileB + row * PROW + ch * 8;
+                    *(uint2*)d = h; *(uint2*)(d + PLANE_B) = m; *(uint2*)(d + 2 * PLANE_B) = l;
+                }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < LD_A; ++i) { const int id = tid + 256 * i, row = id / CH, ch = id % CH; *(uint4*)(tileA + row * ROW + ch * 16) = ra[i]; }
 #pragma unroll
         for (int i = 0; i < LD_B; ++i) { const int id = tid + 256 * i, row = id / CH, ch = id % CH; if (row < HROWS) *(uint4*)(tileB + row * ROW + ch * 16) = rb[i]; }
+        }
     };
 
     if (n_steps > 0) gload(0);
@@ -152,22 +174,24 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
             const int pb = blk * 32;
+            if constexpr (SPLIT) {
+                uint4 ap[4][3], tmp[2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) { frag_plain<bf16_tag>(tileA + pl * PLANE_A, PROW, pb, i * 16, lane, tmp); ap[i][pl] = tmp[0]; }
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    uint4 bp[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) { frag_halo<bf16_tag, W>(tileB + pl * PLANE_B, PROW, pb, t / 3, t % 3, wave * 16, lane, tmp); bp[pl] = tmp[0]; }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[t][i] = mma_planes6(ap[i], bp, acc[t][i]);
+                }
+            } else {
             uint4 af[4][2];
 #pragma unroll
             for (int i = 0; i < 4; ++i) frag_plain<T>(tileA, ROW, pb, i * 16, lane, af[i]);
-            if constexpr (is_split<T>::value) {      // fp32 operands as three bf16 pieces each, six MFMAs per fragment pair (common.h)
-                split3_t sa[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) sa[i] = split_f32x8(af[i][0], af[i][1]);
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    uint4 bf[2];
-                    frag_halo<T, W>(tileB, ROW, pb, t / 3, t % 3, wave * 16, lane, bf);
-                    const split3_t sb = split_f32x8(bf[0], bf[1]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[t][i] = mma_split6_direct(sa[i], sb, acc[t][i]);
-                }
-            } else {
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 uint4 bf[2];
