@@ -7,6 +7,7 @@ bash tools/profile_bench.sh r2final > gpurun_out/r2final/profile.log 2>&1; tail 
 bash tools/pmc_bench.sh r2final > gpurun_out/r2final/pmc.log 2>&1; tail -6 gpurun_out/r2final/pmc.log | cut -c1-200
 python tools/roofline_table.py gpurun_out/prof_r2final gpurun_out/pmcbench_r2final 3 > gpurun_out/r2final/roofline_per_kernel.md 2>&1; head -12 gpurun_out/r2final/roofline_per_kernel.md | cut -c1-200
 FB_WGRAD_STREAM=0 python tools/step_breakdown.py bf16 98 > gpurun_out/r2final/breakdown_bf16.md 2>&1; tail -14 gpurun_out/r2final/breakdown_bf16.md
+mkdir -p gpurun_out/prof_r2final_gradreg
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r2final_gradreg -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --grad-reg 0.5 --steps 1 --warmup 1 --serialize --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_r2final_gradreg/bench.log 2>&1
 cd $GRAFT_REPO_ROOT; python tools/kernel_stats.py gpurun_out/prof_r2final_gradreg 2 "rocprofv3 --kernel-trace --stats -- python3 bench.py --grad-reg 0.5 --steps 1 --warmup 1 --serialize --no-cpu-baseline" > gpurun_out/r2final/gradreg_kernel_stats.md 2>&1; head -24 gpurun_out/r2final/gradreg_kernel_stats.md | cut -c1-160
