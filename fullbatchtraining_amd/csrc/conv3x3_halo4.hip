@@ -57,32 +57,36 @@ __device__ __forceinline__ int h4_xcd_remap(int b, int n) {          // consecut
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 // halo rows between fragment 0 and fragment j of a wave
-template <int W> constexpr int h4_frag_rows(int j) { return W == 32 ? (j >> 1) * 40 + (j & 1) * 16 : (W == 16 ? j * 18 : j * 2 * 10); }
+template <int W> constexpr int h4_frag_rows(int j) { return W == 32 ? (j >> 1) * 40 + (j & 1) * 16 : (W == 16 ? j * 18 : (W == 8 ? j * 2 * 10 : j * 36)); }
 __device__ __forceinline__ int h4_div(int n, unsigned magic) { return magic ? (int)__umulhi((unsigned)n, magic) : n; }
 constexpr unsigned H4_OOB = 0x80000000u;
 
 template <int W> struct H4Geo {
     static constexpr int TH = W >= 16 ? 256 / W : W;              // image rows per image part of the tile
-    static constexpr int IMGS = W >= 16 ? 1 : 256 / (W * W);      // whole images per tile (W = 8: 4)
+    static constexpr int IMGS = W >= 16 ? 1 : 256 / (W * W);      // whole images per tile (W = 8: 4, W = 4: 16)
     static constexpr int TILES_PER_IMG = W == 32 ? 4 : 1;
     // 32x32: pitch 40 = five 1 KiB load groups per halo row, so the top/bottom halo rows are whole groups (their validity
     // depends on the tile's position in the image and is decided per load on the scalar unit)
     static constexpr int PITCH = W == 32 ? 40 : W + 2;
     static constexpr int IMG_ROWS = (TH + 2) * PITCH;             // halo rows per image part
-    static constexpr int ROWS = IMGS * IMG_ROWS;                  // 400, 324, 400
+    static constexpr int ROWS = IMGS * IMG_ROWS;                  // 400, 324, 400, 576
     static constexpr int NGRP = (ROWS + 7) / 8;                   // 1 KiB groups of 8 rows
 };
 
 struct H4Tile { int pt, ct, n0, y0; };                             // wave-uniform description of one tile
 }  // namespace
 
-template <typename T, int W>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3s1_halo4_kernel(const Halo4Params p) {
+// FI = 16-channel output fragments per wave: 4 (64-channel tiles, two workgroups per CU) or 8 (128-channel tiles, ONE workgroup per CU with
+// 128 accumulator registers: 24 fragment reads per 64 MFMAs instead of 16 per 32, and half the weight / halo bytes from L2 per MFMA --
+// the 512-channel 4x4 layers are limited by exactly that stream in the implicit GEMM)
+template <typename T, int W, int FI = 4>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1 : 2, FI == 8 ? 1 : 2))) void conv3x3s1_halo4_kernel(const Halo4Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using G = H4Geo<W>;
     constexpr int EB = ET<T>::EB;
     constexpr int PITCH = G::PITCH, NGRP = G::NGRP;
-    constexpr int HALO_BYTES = NGRP * 1024, WT_BYTES = 64 * 128, NW = 3, RED_BYTES = 4 * 64 * 2 * 4;
+    constexpr int CO_T = 16 * FI, NWL = FI / 2;                   // output channels per tile; weight LDS-DMA instructions per wave and tap
+    constexpr int HALO_BYTES = NGRP * 1024, WT_BYTES = CO_T * 128, NW = 3, RED_BYTES = 4 * CO_T * 2 * 4;
 #ifndef FB_H4_LDS_PAD
 #define FB_H4_LDS_PAD 0                                     // tools/h4_trace.hip: pad to force one workgroup per CU
 #endif
@@ -96,8 +100,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int lrow8 = lane >> 3;                           // row within a 1 KiB group
 
     // ---- per-lane constants (once per workgroup) ---------------------------------------------------------------------------
-    const unsigned voffW0 = (unsigned)((wave * 8 + lrow8) * 9 * row_b + (((lane & 7) ^ lrow8) * 16));
-    const unsigned voffW1 = voffW0 + (unsigned)(32 * 9 * row_b);
+    const unsigned voffW0 = (unsigned)((wave * 8 + lrow8) * 9 * row_b + (((lane & 7) ^ lrow8) * 16));       // + k * 32 rows, k < NWL
     // halo source offsets relative to the tile's origin pixel (row y0-1, column -1 of the first image); rows outside the
     // image in x (and in y for whole-image tiles) are out of range for good
     constexpr int KH = (NGRP + 3) / 4;
@@ -134,8 +137,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int voffT = ((wave * 64 + (lane & 15)) * p.Cd + (g4 & 1) * 16 + (g4 >> 1) * 8) * EB;
     // BN partial sums: writer lanes (lane & 15 == 0) and the 128 reader threads
     const unsigned red0 = lds0 + HALO_BYTES + NW * WT_BYTES;
-    const unsigned redw = red0 + (wave * 64 + (lane >> 4) * 4) * 8;
-    const unsigned redr = red0 + (((tid >> 6) * 2) * 64 + (tid & 63)) * 8;
+    const unsigned redw = red0 + (wave * CO_T + (lane >> 4) * 4) * 8;
+    const unsigned redr = red0 + (((tid / CO_T) * 2) * CO_T + (tid % CO_T)) * 8;
     unsigned wa[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) wa[h] = lds0 + HALO_BYTES + (lane & 15) * 128 + ((((lane >> 4) + 4 * h) ^ (lane & 7)) * 16);
@@ -178,10 +181,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     auto wt_issue = [&](int buf, const H4Tile& t, int cc, int tap) {
         const __amdgpu_buffer_rsrc_t rW = rsrcW_of(t);
-        const int soff = t.ct * 64 * 9 * row_b + tap * row_b + cc * 128;
+        const int soff = t.ct * CO_T * 9 * row_b + tap * row_b + cc * 128;
         char* dst = lds + HALO_BYTES + buf * WT_BYTES + wave * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)dst, 16, voffW0, soff, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)(dst + 4096), 16, voffW1, soff, 0, 0);
+        h4_static_for<0, NWL>([&](auto kc) {
+            constexpr int K = decltype(kc)::value;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)(dst + K * 4096), 16,
+                                                     voffW0 + (unsigned)(K * 32 * 9 * row_b), soff, 0, 0);
+        });
     };
     // forward walks the taps 0..8, the input gradient walks the flipped filter 8..0
     auto tap_of = [&](int u) { return p.mode == 0 ? u : 8 - u; };
@@ -211,9 +217,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_s_barrier();
         H4_STAMP(2);
 
-        f32x4_t acc[4][4];
+        f32x4_t acc[FI][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < FI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
@@ -228,10 +234,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 else if (more) wt_issue(NBUF, cur, cc + 1, tap_of(U - 7));
                 else if (has_next) wt_issue(NBUF, nxt, 0, tap_of(U - 7));
                 else issued = false;
-                uint4 wf0[4], pf0[4], wf1[4], pf1[4];
-                h4_static_for<0, 4>([&](auto i) { wf0[decltype(i)::value] = h4_read16<decltype(i)::value * 2048 + BUF * WT_BYTES>(wa[0]); });
+                uint4 wf0[FI], pf0[4], wf1[FI], pf1[4];
+                h4_static_for<0, FI>([&](auto i) { wf0[decltype(i)::value] = h4_read16<decltype(i)::value * 2048 + BUF * WT_BYTES>(wa[0]); });
                 h4_static_for<0, 4>([&](auto j) { pf0[decltype(j)::value] = h4_read16<(A * PITCH + h4_frag_rows<W>(decltype(j)::value)) * 128>(pa[B][0]); });
-                h4_static_for<0, 4>([&](auto i) { wf1[decltype(i)::value] = h4_read16<decltype(i)::value * 2048 + BUF * WT_BYTES>(wa[1]); });
+                h4_static_for<0, FI>([&](auto i) { wf1[decltype(i)::value] = h4_read16<decltype(i)::value * 2048 + BUF * WT_BYTES>(wa[1]); });
                 h4_static_for<0, 4>([&](auto j) { pf1[decltype(j)::value] = h4_read16<(A * PITCH + h4_frag_rows<W>(decltype(j)::value)) * 128>(pa[B][1]); });
                 if constexpr (is_split<T>::value) {      // fp32 operands as three bf16 pieces each, six MFMAs per fragment pair (common.h)
                     h4_wait_lgkmcnt<0>();
@@ -239,20 +245,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                     for (int j = 0; j < 4; ++j) sp[j] = split_f32x8(pf0[j], pf1[j]);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {                  // one weight fragment split at a time: four zero-started chains in flight
+                    for (int i = 0; i < FI; ++i) {                 // one weight fragment split at a time: four zero-started chains in flight
                         const split3_t sw = split_f32x8(wf0[i], wf1[i]);
                         mma_split6_row<4>(sw, sp, acc[i]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 } else {
-                h4_wait_lgkmcnt<8>();
+                h4_wait_lgkmcnt<FI + 4>();
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < FI; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = mma_chunk<T>(wf0[i], pf0[j], acc[i][j]);
                 h4_wait_lgkmcnt<0>();
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < FI; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = mma_chunk<T>(wf1[i], pf1[j], acc[i][j]);
                 }
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         halo_issue(nxt, 0);               // lands during the epilogue; the loop top waits for it
                     }
                 } else {
-                    if (issued) h4_wait_vmcnt<2>();       // the weights of the next tap have landed; two loads stay in flight
+                    if (issued) h4_wait_vmcnt<NWL>();     // the weights of the next tap have landed; the NWL loads of the tap after it stay in flight
                     else h4_wait_vmcnt<0>();
                     __builtin_amdgcn_s_barrier();
                 }
@@ -281,16 +287,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                                                 256 * p.Cd * EB, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsrcE = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(p.addend_mode == 1 ? p.addend + (long long)cur.pt * 256 * p.Cd * EB : p.dst), 0, p.addend_mode == 1 ? 256 * p.Cd * EB : 0, 0x00020000);
-        float ssum[4][4], ssq[4][4];
+        float ssum[FI][4], ssq[FI][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < FI; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { ssum[i][r] = 0.f; ssq[i][r] = 0.f; }
         h4_static_for<0, 4>([&](auto jc) {
             constexpr int J = decltype(jc)::value;
-            const int soff = (J * 16 * p.Cd + cur.ct * 64) * EB;
-            unsigned pk[4][2];
-            h4_static_for<0, 4>([&](auto ic) {
+            const int soff = (J * 16 * p.Cd + cur.ct * CO_T) * EB;
+            unsigned pk[FI][2];
+            h4_static_for<0, FI>([&](auto ic) {
                 constexpr int I = decltype(ic)::value;
                 float v[4] = {acc[I][J][0], acc[I][J][1], acc[I][J][2], acc[I][J][3]};
                 if (p.addend_mode == 1) {
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const int img_l = q / (G::TH * W), qi = q - img_l * (G::TH * W);
                     const int oy = cur.y0 + qi / W, ox = qi % W;
                     const long long apix = ((long long)(cur.n0 + img_l) * (p.H >> 1) + (oy >> 1)) * (W >> 1) + (ox >> 1);
-                    const char* ap = p.addend + (apix * p.Cd + cur.ct * 64 + I * 16 + (lane >> 4) * 4) * EB;
+                    const char* ap = p.addend + (apix * p.Cd + cur.ct * CO_T + I * 16 + (lane >> 4) * 4) * EB;
                     if constexpr (EB == 4) { const float4 a = *(const float4*)ap; v[0] += 0.25f * a.x; v[1] += 0.25f * a.y; v[2] += 0.25f * a.z; v[3] += 0.25f * a.w; }
                     else { const uint2 a = *(const uint2*)ap; v[0] += 0.25f * __uint_as_float(a.x << 16); v[1] += 0.25f * __uint_as_float(a.x & 0xffff0000u);
                            v[2] += 0.25f * __uint_as_float(a.y << 16); v[3] += 0.25f * __uint_as_float(a.y & 0xffff0000u); }
@@ -336,11 +342,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // [4 waves][64 co]{sum, sumsq} in its own LDS region (the halo is being refilled); inline-asm LDS ops: the compiler
             // would drain the in-flight LDS-DMA of the next tile before any LDS access it can see
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < FI; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { ssum[i][r] = row16_sum(ssum[i][r]); ssq[i][r] = row16_sum(ssq[i][r]); }
             if ((lane & 15) == 0) {
-                h4_static_for<0, 16>([&](auto c) {
+                h4_static_for<0, 4 * FI>([&](auto c) {
                     constexpr int I = decltype(c)::value / 4, R = decltype(c)::value % 4;
                     const f32x2_t d = {ssum[I][R], ssq[I][R]};
                     const unsigned wr = redw;             // (a plain use: asm operands alone do not capture in a nested lambda)
@@ -349,15 +355,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             h4_wait_lgkmcnt<0>();
             __builtin_amdgcn_s_barrier();
-            if (tid < 128) {
-                const int half = tid >> 6, col = tid & 63;
+            if (tid < 2 * CO_T) {
+                const int half = tid / CO_T, col = tid % CO_T;
                 f32x2_t x, y;
                 asm volatile("ds_read_b64 %0, %1" : "=v"(x) : "v"(redr));
-                asm volatile("ds_read_b64 %0, %1 offset:512" : "=v"(y) : "v"(redr));
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(y) : "v"(redr), "n"(CO_T * 8));
                 h4_wait_lgkmcnt<0>();
                 const long long blk = 2LL * cur.pt + half;
-                p.stat[blk * p.Cd + cur.ct * 64 + col] = x[0] + y[0];
-                p.stat[((long long)p.n_mblocks + blk) * p.Cd + cur.ct * 64 + col] = x[1] + y[1];
+                p.stat[blk * p.Cd + cur.ct * CO_T + col] = x[0] + y[0];
+                p.stat[((long long)p.n_mblocks + blk) * p.Cd + cur.ct * CO_T + col] = x[1] + y[1];
             }
         }
         H4_STAMP(5);
@@ -380,12 +386,20 @@ int fb_try_conv3x3_halo4(const fb_conv_args* a, hipStream_t st) {
     if (a->R != 3 || a->S != 3 || a->stride != 1 || a->pad != 1) return 0;
     if (a->Hs != a->Hd || a->Ws != a->Wd || a->Hs != a->Ws) return 0;
     const int W = a->Ws;
-    if (W != 32 && W != 16 && W != 8) return 0;
+    if (W != 32 && W != 16 && W != 8 && W != 4) return 0;
     const int EB = a->dtype == FB_F32 ? 4 : 2;
     if (a->Cs * EB % 128 != 0 || a->Cd % 64 != 0) return 0;
     const int imgs_per_wset = a->imgs_per_wset > 0 ? a->imgs_per_wset : a->n_img;
-    if (W == 8 && (a->n_img % 4 != 0 || imgs_per_wset % 4 != 0)) return 0;
-    if ((long long)(4 * a->Hs * W + 2 * W + 2) * a->Cs * EB >= (1LL << 31)) return 0;
+    const int imgs_per_tile = W >= 16 ? 1 : 256 / (W * W);
+    if (a->n_img % imgs_per_tile != 0 || imgs_per_wset % imgs_per_tile != 0) return 0;
+    // 128-channel tiles (one workgroup per CU, FI = 8): bf16; always for the 4x4 maps (which have no 64-channel variant), elsewhere only
+    // with FB_H4_WIDE (A/B switch: a list of map widths, e.g. "8,16")
+    static const char* wide_env = getenv("FB_H4_WIDE");
+    char wtag[8];
+    snprintf(wtag, sizeof(wtag), "%d", W);
+    const bool wide = a->dtype == FB_BF16 && a->Cd % 128 == 0 && (W == 4 || (wide_env && W != 32 && strstr(wide_env, wtag)));
+    if (W == 4 && !wide) return 0;
+    if ((long long)(imgs_per_tile * a->Hs * W + 2 * W + 2) * a->Cs * EB >= (1LL << 31)) return 0;
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -401,7 +415,7 @@ int fb_try_conv3x3_halo4(const fb_conv_args* a, hipStream_t st) {
     p.addend_mode = a->addend ? a->addend_mode : 0;
     const int n_pt = a->n_img * a->Hs * W / 256;
     p.n_mblocks = n_pt * 2;
-    p.n_ct = a->Cd / 64;
+    p.n_ct = a->Cd / (wide ? 128 : 64);
     p.n_tiles = n_pt * p.n_ct;
     if ((long long)p.n_tiles * p.n_ct >= (1LL << 32) || (long long)a->n_img * imgs_per_wset >= (1LL << 32)) return 0;
     p.magic_ct = h4_magic(p.n_ct);
@@ -411,6 +425,13 @@ int fb_try_conv3x3_halo4(const fb_conv_args* a, hipStream_t st) {
     p.trace = g_h4_trace;
 #endif
     dim3 grid(p.n_tiles < 2 * n_cu ? p.n_tiles : 2 * n_cu);
+    if (wide) {
+        dim3 grid1(p.n_tiles < n_cu ? p.n_tiles : n_cu);
+        if (W == 16) hipLaunchKernelGGL((conv3x3s1_halo4_kernel<bf16_tag, 16, 8>), grid1, dim3(256), 0, st, p);
+        else if (W == 8) hipLaunchKernelGGL((conv3x3s1_halo4_kernel<bf16_tag, 8, 8>), grid1, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv3x3s1_halo4_kernel<bf16_tag, 4, 8>), grid1, dim3(256), 0, st, p);
+        return 1;
+    }
     if (a->dtype == FB_F32 && fb_f32_split_enabled()) {
         if (W == 32) hipLaunchKernelGGL((conv3x3s1_halo4_kernel<f32s_tag, 32>), grid, dim3(256), 0, st, p);
         else if (W == 16) hipLaunchKernelGGL((conv3x3s1_halo4_kernel<f32s_tag, 16>), grid, dim3(256), 0, st, p);

@@ -50,7 +50,8 @@ def krsc(w):  # [co, ci, kh, kw] -> [co, kh*kw, ci]
                                                    (256, 128, 3, 1, 8, 4), (128, 64, 3, 1, 8, 12), (192, 64, 3, 1, 32, 1),
                                                    (64, 64, 3, 1, 8, 2400), (64, 128, 3, 1, 16, 300), (64, 64, 3, 1, 32, 160),   # > 2 tiles per persistent workgroup
                                                    (32, 64, 1, 1, 32, 40), (32, 64, 1, 1, 32, 300),   # stem on patches: streaming K = 32 kernel (bf16), grid-stride
-                                                   (64, 128, 3, 2, 32, 3), (128, 256, 3, 2, 16, 6), (96, 64, 3, 2, 16, 4)])   # more stride-2 shapes
+                                                   (64, 128, 3, 2, 32, 3), (128, 256, 3, 2, 16, 6), (96, 64, 3, 2, 16, 4),   # more stride-2 shapes
+                                                   (128, 128, 3, 1, 4, 48), (512, 512, 3, 1, 4, 272), (64, 256, 3, 1, 4, 16)])   # 4x4 maps: 128-channel halo tiles (bf16)
 def test_conv_fwd_and_stats(dtype, cin, cout, k, stride, hw, n):
     lib = _lib()
     torch.manual_seed(0)
@@ -80,7 +81,8 @@ def test_conv_fwd_and_stats(dtype, cin, cout, k, stride, hw, n):
                                                           (64, 64, 3, 1, 32, 136, 1), (128, 64, 3, 1, 16, 600, 0),   # persistent workgroups, several tiles each
                                                           # stride-2 quad kernel (bf16): dY 16x16 / 8x8 / 4x4, ragged image counts, all addend modes
                                                           (64, 128, 3, 2, 32, 3, 2), (128, 256, 3, 2, 16, 5, 1), (64, 64, 3, 2, 8, 11, 2),
-                                                          (128, 96, 3, 2, 16, 2, 0), (64, 128, 3, 2, 32, 70, 0)])
+                                                          (128, 96, 3, 2, 16, 2, 0), (64, 128, 3, 2, 32, 70, 0),
+                                                          (256, 128, 3, 1, 4, 32, 1), (128, 256, 3, 1, 4, 16, 0), (512, 512, 3, 1, 4, 272, 1)])   # 4x4 maps, 128-channel halo tiles
 def test_conv_dgrad(dtype, cin, cout, k, stride, hw, n, amode, monkeypatch):
     monkeypatch.setenv("FB_S2_QUAD_ALL", "1")      # the quad kernel also for 4x4 gradients (production keeps the implicit GEMM there)
     lib = _lib()
