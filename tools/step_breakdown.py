@@ -83,6 +83,14 @@ def main():
         if model_name != 'resnet18' and us < total / 400:
             continue
         print(f"| {i} | {desc} | {us:.0f} | {flop / us / 1e6:.0f} | {byt / us / 1e3:.0f} |")
+    if model_name != "resnet18":                               # hundreds of launches: aggregate by shape
+        agg = defaultdict(lambda: [0, 0.0, 0, 0])
+        for us, desc, flop, byt in rows:
+            a = agg[desc]
+            a[0] += 1; a[1] += us; a[2] += flop; a[3] += byt
+        print("\n| call shape | launches | us total | share | TFLOP/s | GB/s (algorithmic) |\n|---|---|---|---|---|---|")
+        for desc, (n, us, flop, byt) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:70]:
+            print(f"| {desc} | {n} | {us:.0f} | {100 * us / total:.1f} % | {flop / us / 1e6:.0f} | {byt / us / 1e3:.0f} |")
     print("\n| entry point | ms per group | share |\n|---|---|---|")
     for k, v in sorted(classes.items(), key=lambda kv: -kv[1]):
         print(f"| {k} | {v / 1e3:.2f} | {100 * v / total:.1f} % |")
