@@ -388,10 +388,12 @@ extern "C" int fb_bn_bwd_reduce(const void* dout, const void* y, const void* mas
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int n_mblocks, int blocks_per_group, int C, double inv_count,
                                        const float* __restrict__ scale, const float* __restrict__ mean_tab, const float* __restrict__ invstd,
                                        int ch_total, int ch_off, float* __restrict__ dgamma, float* __restrict__ dbeta, long long gstride,
-                                       float* __restrict__ coef) {
+                                       float* __restrict__ coef, int raw_x) {
     const int g = blockIdx.y;
     int c; double s1, s2;
     if (!partial_sum2(part, n_mblocks, blocks_per_group, C, g, c, s1, s2)) return;
+    if (raw_x)                                              // partials of dy*x from a convolution epilogue: sum dy*xhat = invstd*(sum dy*x - mean*sum dy)
+        s2 = (double)invstd[(long long)g * C + c] * (s2 - (double)mean_tab[(long long)g * ch_total + ch_off + c] * s1);
     dbeta[(long long)g * gstride + c] = (float)s1;
     dgamma[(long long)g * gstride + c] = (float)s2;
     // dx = scale*(dy - s1/M - xhat*s2/M) = c_dy*dy + c_x*x + c_0
@@ -403,12 +405,12 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int n_mbl
 
 extern "C" int fb_bn_bwd_finalize(const float* partial, int32_t n_mblocks, int32_t n_groups, int32_t C, double count, const float* scale,
                                   const float* mean_tab, const float* invstd, int32_t ch_total, int32_t ch_off, float* dgamma,
-                                  float* dbeta, int64_t grad_group_stride, float* coef, void* stream) {
+                                  float* dbeta, int64_t grad_group_stride, float* coef, int32_t raw_x, void* stream) {
     if (!partial || !scale || !mean_tab || !invstd || !dgamma || !dbeta || !coef) FB_FAIL(FB_ERR_ARG, "fb_bn_bwd_finalize: null pointer");
     if (n_mblocks % n_groups != 0) FB_FAIL(FB_ERR_SHAPE, "fb_bn_bwd_finalize: blocks/groups");
     dim3 grid((C + 15) / 16, n_groups);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, grid, dim3(bn_finalize_threads(n_mblocks / n_groups)), 0, (hipStream_t)stream, partial, n_mblocks, n_mblocks / n_groups, C, 1.0 / count,
-                       scale, mean_tab, invstd, ch_total, ch_off, dgamma, dbeta, (long long)grad_group_stride, coef);
+                       scale, mean_tab, invstd, ch_total, ch_off, dgamma, dbeta, (long long)grad_group_stride, coef, (int)raw_x);
     FB_CHECK_LAUNCH("fb_bn_bwd_finalize");
     return FB_OK;
 }

@@ -183,6 +183,108 @@ template <int NJ> __device__ __forceinline__ void mma_split6_row(const split3_t&
 }
 template <typename T> struct is_split { static constexpr bool value = false; };
 template <> struct is_split<f32s_tag> { static constexpr bool value = true; };
+
+// ---- fp32 operands on the fp16 matrix pipe: scaled two-way split, three products ("fp16x2") -------------------------------
+// Two fp16 pieces carry 22 significand bits: x*s = h + l with h = fp16(x*s), l = fp16(x*s - h) (the subtraction is exact in fp32).  The float64
+// oracle with 22-bit operands puts 3.7e-2 of error on the regularised gradient where fp32 puts 3.5e-2 and 16 bits 1.4e-1
+// (tools/split_precision_experiment.py), so three products hh + hl + lh (the dropped ll is below 2^-22 |ab|) do the job of the six
+// bf16 ones at half the matrix time.  fp16 has 5 exponent bits, hence the scale: s = 2^e per TENSOR, chosen from the tensor's largest
+// magnitude (fb_absmax, one pass) so that it lands in [2^14, 2^15); elements below 2^-25 of the maximum lose their low piece, nothing
+// overflows.  Powers of two commute with every rounding; the 32-deep partial sum is multiplied by 2^-(e_a + e_b) in the v_fma_f32 that
+// adds it to the running accumulator (zero-started chains as above).
+// f32h_tag: fp32 STORAGE, fp16x2 arithmetic inside the convolution kernels (selected per call by fb_conv_args.amax_src / amax_wgt).
+struct f32h_tag {};
+template <> struct ET<f32h_tag> : ET<float> {};
+template <typename T> struct is_hsplit { static constexpr bool value = false; };
+template <> struct is_hsplit<f32h_tag> { static constexpr bool value = true; };
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+struct split2h_t { f16x8_t h, l; };
+__device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){lo, hi}, f16x2_t));
+}
+// 2^e with the largest magnitude m of the tensor scaled into [2^14, 2^15); e clamped so that 2^-(e_a + e_b) stays a normal float
+__device__ __forceinline__ float fb_pow2_scale(float m) {
+    const int ex = (int)((__float_as_uint(m) >> 23) & 0xffu);
+    int e = ex == 0 ? 0 : 14 - (ex - 127);
+    e = e < -100 ? -100 : (e > 60 ? 60 : e);
+    return __uint_as_float((unsigned)(e + 127) << 23);
+}
+__device__ __forceinline__ split2h_t split_h2x8(const uint4& c0, const uint4& c1, float s) {
+    const unsigned w[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    unsigned hp[4], lp[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float x0 = __uint_as_float(w[2 * q]) * s, x1 = __uint_as_float(w[2 * q + 1]) * s;
+        hp[q] = pack_f16x2(x0, x1);
+        const f16x2_t hv = __builtin_bit_cast(f16x2_t, hp[q]);
+        lp[q] = pack_f16x2(x0 - (float)hv[0], x1 - (float)hv[1]);
+    }
+    split2h_t o;
+    o.h = __builtin_bit_cast(f16x8_t, make_uint4(hp[0], hp[1], hp[2], hp[3]));
+    o.l = __builtin_bit_cast(f16x8_t, make_uint4(lp[0], lp[1], lp[2], lp[3]));
+    return o;
+}
+// four fp32 values -> the 8-byte fp16x4 pieces of the two planes (weight-gradient kernels split when they store a tile to LDS)
+__device__ __forceinline__ void split_h2x4(const uint4& c, float s, uint2& h, uint2& l) {
+    const unsigned w[4] = {c.x, c.y, c.z, c.w};
+    unsigned hp[2], lp[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const float x0 = __uint_as_float(w[2 * q]) * s, x1 = __uint_as_float(w[2 * q + 1]) * s;
+        hp[q] = pack_f16x2(x0, x1);
+        const f16x2_t hv = __builtin_bit_cast(f16x2_t, hp[q]);
+        lp[q] = pack_f16x2(x0 - (float)hv[0], x1 - (float)hv[1]);
+    }
+    h = make_uint2(hp[0], hp[1]); l = make_uint2(lp[0], lp[1]);
+}
+__device__ __forceinline__ f32x4_t fma4(const f32x4_t& t, float k, f32x4_t c) {
+    c[0] = fmaf(t[0], k, c[0]); c[1] = fmaf(t[1], k, c[1]); c[2] = fmaf(t[2], k, c[2]); c[3] = fmaf(t[3], k, c[3]);
+    return c;
+}
+// three fp16 MFMAs, smallest terms first, zero-started; c += 2^-(e_a + e_b) * partial
+__device__ __forceinline__ f32x4_t mma_split3h(const split2h_t& a, const split2h_t& b, f32x4_t c, float inv) {
+    f32x4_t t = {0.f, 0.f, 0.f, 0.f};
+    t = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l, b.h, t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, b.l, t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, b.h, t, 0, 0, 0);
+    c = fma4(t, inv, c);
+    asm volatile("" : "+v"(c));
+    return c;
+}
+template <int NJ> __device__ __forceinline__ void mma_split3h_row(const split2h_t& a, const split2h_t (&b)[NJ], f32x4_t (&c)[NJ], float inv) {
+    f32x4_t t[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) t[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l, b[j].h, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) t[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, b[j].l, t[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) t[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, b[j].h, t[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        c[j] = fma4(t[j], inv, c[j]);
+        asm volatile("" : "+v"(c[j]));
+    }
+}
+// the three products of two already split operands, straight into the (scaled) accumulator: weight-gradient kernels unscale once at the end
+__device__ __forceinline__ f32x4_t mma_planes3h_acc(const uint4 (&a)[2], const uint4 (&b)[2], f32x4_t c) {
+    const f16x8_t ah = __builtin_bit_cast(f16x8_t, a[0]), al = __builtin_bit_cast(f16x8_t, a[1]);
+    const f16x8_t bh = __builtin_bit_cast(f16x8_t, b[0]), bl = __builtin_bit_cast(f16x8_t, b[1]);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
+    return c;
+}
+// the three products of two already split operands (fp16x8 per plane), zero-started; c += inv * partial
+__device__ __forceinline__ f32x4_t mma_planes3h(const uint4 (&a)[2], const uint4 (&b)[2], f32x4_t c, float inv) {
+    const f16x8_t ah = __builtin_bit_cast(f16x8_t, a[0]), al = __builtin_bit_cast(f16x8_t, a[1]);
+    const f16x8_t bh = __builtin_bit_cast(f16x8_t, b[0]), bl = __builtin_bit_cast(f16x8_t, b[1]);
+    f32x4_t t = {0.f, 0.f, 0.f, 0.f};
+    t = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, t, 0, 0, 0);
+    t = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, t, 0, 0, 0);
+    return fma4(t, inv, c);
+}
 // FB_F32_EXACT=1 (environment, read once): fp32 convolutions on the exact-f32 MFMA instead of the split path (A/B and reference)
 bool fb_f32_split_enabled();
 

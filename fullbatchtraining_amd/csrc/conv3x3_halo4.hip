@@ -22,6 +22,8 @@
 
 struct Halo4Params {
     const char* src; const char* wgt; char* dst; const char* addend; float* stat;
+    const char* bst_x; const unsigned char* bst_mask;       // BST: input and ReLU bitmask of the BatchNorm whose backward consumes dst
+    const float* amax_src; const float* amax_wgt;           // f32h (fp16x2 split): largest magnitudes of the operand tensors
     int n_img, H, Cs, Cd, mode;
     int imgs_per_wset; long long wset_stride_bytes;
     int addend_mode, n_mblocks, n_ct, n_tiles;
@@ -79,7 +81,9 @@ struct H4Tile { int pt, ct, n0, y0; };                             // wave-unifo
 // FI = 16-channel output fragments per wave: 4 (64-channel tiles, two workgroups per CU) or 8 (128-channel tiles, ONE workgroup per CU with
 // 128 accumulator registers: 24 fragment reads per 64 MFMAs instead of 16 per 32, and half the weight / halo bytes from L2 per MFMA --
 // the 512-channel 4x4 layers are limited by exactly that stream in the implicit GEMM)
-template <typename T, int W, int FI = 4>
+// BST (bf16 input gradient): the reduction pass of the BatchNorm backward that consumes dst, fused into the epilogue -- g = the bf16 output
+// where the bit of bst_mask is set, x = bst_x at the same position; `stat` receives the 128-pixel-block sums of g and of g*x.
+template <typename T, int W, int FI = 4, bool BST = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1 : 2, FI == 8 ? 1 : 2))) void conv3x3s1_halo4_kernel(const Halo4Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using G = H4Geo<W>;
@@ -199,6 +203,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
     // set by the per-CU load/store pipeline, not by idle workgroups.)
     int L = h4_xcd_remap(blockIdx.x, NB);
     if (L >= p.n_tiles) return;
+    float hs_src = 1.f, hs_wgt = 1.f, hs_inv = 1.f;         // f32h: per-tensor power-of-two scales
+    if constexpr (is_hsplit<T>::value) {
+        hs_src = fb_pow2_scale(*p.amax_src); hs_wgt = fb_pow2_scale(*p.amax_wgt);
+        hs_inv = 1.f / (hs_src * hs_wgt);
+    }
     H4Tile cur = decode(L);
     halo_issue(cur, 0);
     wt_issue(0, cur, 0, tap_of(0));
@@ -239,7 +248,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
                 h4_static_for<0, 4>([&](auto j) { pf0[decltype(j)::value] = h4_read16<(A * PITCH + h4_frag_rows<W>(decltype(j)::value)) * 128>(pa[B][0]); });
                 h4_static_for<0, FI>([&](auto i) { wf1[decltype(i)::value] = h4_read16<decltype(i)::value * 2048 + BUF * WT_BYTES>(wa[1]); });
                 h4_static_for<0, 4>([&](auto j) { pf1[decltype(j)::value] = h4_read16<(A * PITCH + h4_frag_rows<W>(decltype(j)::value)) * 128>(pa[B][1]); });
-                if constexpr (is_split<T>::value) {      // fp32 operands as three bf16 pieces each, six MFMAs per fragment pair (common.h)
+                if constexpr (is_hsplit<T>::value) {     // fp32 operands as two scaled fp16 pieces each, three MFMAs per fragment pair (common.h)
+                    h4_wait_lgkmcnt<0>();
+                    split2h_t sp[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sp[j] = split_h2x8(pf0[j], pf1[j], hs_src);
+#pragma unroll
+                    for (int i = 0; i < FI; ++i) {
+                        split2h_t sw;                          // the weights arrive as fp16x2 planes (fb_weight_prep)
+                        sw.h = __builtin_bit_cast(f16x8_t, wf0[i]); sw.l = __builtin_bit_cast(f16x8_t, wf1[i]);
+                        mma_split3h_row<4>(sw, sp, acc[i], hs_inv);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else if constexpr (is_split<T>::value) {      // fp32 operands as three bf16 pieces each, six MFMAs per fragment pair (common.h)
                     h4_wait_lgkmcnt<0>();
                     split3_t sp[4];
 #pragma unroll
@@ -292,10 +313,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
         for (int i = 0; i < FI; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { ssum[i][r] = 0.f; ssq[i][r] = 0.f; }
+        // BST: the mask bytes of the whole tile are requested up front, x one pixel fragment ahead (the other workgroup of the CU covers
+        // the round trips; FI = 8 has no registers for more)
+        h4_u32x2 bx[BST ? 2 : 1][BST ? FI : 1];
+        unsigned bm[BST ? 4 : 1][BST ? FI / 2 : 1];              // CO_T / 8 mask bytes per pixel
+        const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc((void*)(BST ? p.bst_x + (long long)cur.pt * 256 * p.Cd * EB : p.dst), 0,
+                                                                                BST ? 256 * p.Cd * EB : 0, 0x00020000);
+        auto bx_issue = [&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            if constexpr (BST && J < 4) {
+                const int soff = (J * 16 * p.Cd + cur.ct * CO_T) * EB;
+                h4_static_for<0, FI>([&](auto ic) {
+                    constexpr int I = decltype(ic)::value;
+                    bx[J & 1][I] = __builtin_amdgcn_raw_buffer_load_b64(rsrcX, voffD + I * 16 * EB, soff, 0);
+                });
+            }
+        };
+        if constexpr (BST) {
+            const __amdgpu_buffer_rsrc_t rsrcN = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bst_mask + (long long)cur.pt * 32 * p.Cd), 0, 32 * p.Cd, 0x00020000);
+            const int voffN = (wave * 64 + (lane & 15)) * (p.Cd >> 3);
+            h4_static_for<0, 4>([&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                const int soffN = (J * 16 * p.Cd + cur.ct * CO_T) >> 3;
+                if constexpr (FI == 4) {
+                    const h4_u32x2 m = __builtin_amdgcn_raw_buffer_load_b64(rsrcN, voffN, soffN, 0);
+                    bm[J][0] = m[0]; bm[J][1] = m[1];
+                } else {
+                    const h4_u32x4 m = __builtin_amdgcn_raw_buffer_load_b128(rsrcN, voffN, soffN, 0);
+                    bm[J][0] = m[0]; bm[J][1] = m[1]; bm[J][2] = m[2]; bm[J][3] = m[3];
+                }
+            });
+            bx_issue(std::integral_constant<int, 0>{});
+        }
         h4_static_for<0, 4>([&](auto jc) {
             constexpr int J = decltype(jc)::value;
             const int soff = (J * 16 * p.Cd + cur.ct * CO_T) * EB;
             unsigned pk[FI][2];
+            bx_issue(std::integral_constant<int, J + 1>{});
             h4_static_for<0, FI>([&](auto ic) {
                 constexpr int I = decltype(ic)::value;
                 float v[4] = {acc[I][J][0], acc[I][J][1], acc[I][J][2], acc[I][J][3]};
@@ -333,8 +387,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
                         __builtin_amdgcn_raw_buffer_store_b128((h4_u32x4){lo[0], hi[0], lo[1], hi[1]}, rsrcD, voffT + (I >> 1) * 32 * EB, soff, 0);
                     }
                 }
+                if constexpr (BST) {
+                    // mask byte 2I + (g4 >> 1) of the pixel's CO_T / 8 covers this lane's channels in its low (g4 even) or high nibble
+                    const unsigned bits = bm[J][I >> 1] >> (((2 * (I & 1) + (g4 >> 1)) * 8) + (g4 & 1) * 4);
+                    const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 0, 1), m1 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 1, 1);
+                    const unsigned m2 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 2, 1), m3 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 3, 1);
+                    const h4_u32x2 xv = bx[J & 1][I];
+                    const float g0 = __uint_as_float((pk[I][0] << 16) & m0), g1 = __uint_as_float(pk[I][0] & 0xffff0000u & m1);
+                    const float g2 = __uint_as_float((pk[I][1] << 16) & m2), g3 = __uint_as_float(pk[I][1] & 0xffff0000u & m3);
+                    ssum[I][0] += g0; ssum[I][1] += g1; ssum[I][2] += g2; ssum[I][3] += g3;
+                    ssq[I][0] = fmaf(g0, __uint_as_float(xv[0] << 16), ssq[I][0]); ssq[I][1] = fmaf(g1, __uint_as_float(xv[0] & 0xffff0000u), ssq[I][1]);
+                    ssq[I][2] = fmaf(g2, __uint_as_float(xv[1] << 16), ssq[I][2]); ssq[I][3] = fmaf(g3, __uint_as_float(xv[1] & 0xffff0000u), ssq[I][3]);
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { ssum[I][r] += v[r]; ssq[I][r] += v[r] * v[r]; }
+                    for (int r = 0; r < 4; ++r) { ssum[I][r] += v[r]; ssq[I][r] += v[r] * v[r]; }
+                }
             });
         });
         H4_STAMP(4);
@@ -379,8 +446,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
 
 static unsigned h4_magic(int d) { return d <= 1 ? 0u : (unsigned)(((1ULL << 32) + (unsigned)d - 1) / (unsigned)d); }
 
-// returns 1 if the kernel handled the call
-int fb_try_conv3x3_halo4(const fb_conv_args* a, hipStream_t st) {
+// 0: not for this kernel; 1: 64-channel tiles; 2: 128-channel tiles
+static int h4_variant(const fb_conv_args* a) {
     static const bool disabled = getenv("FB_DISABLE_HALO4") != nullptr;
     if (disabled) return 0;
     if (a->R != 3 || a->S != 3 || a->stride != 1 || a->pad != 1) return 0;
@@ -400,6 +467,22 @@ int fb_try_conv3x3_halo4(const fb_conv_args* a, hipStream_t st) {
     const bool wide = a->dtype == FB_BF16 && a->Cd % 128 == 0 && (W == 4 || (wide_env && W != 32 && strstr(wide_env, wtag)));
     if (W == 4 && !wide) return 0;
     if ((long long)(imgs_per_tile * a->Hs * W + 2 * W + 2) * a->Cs * EB >= (1LL << 31)) return 0;
+    const int n_pt = a->n_img * a->Hs * W / 256, n_ct = a->Cd / (wide ? 128 : 64);
+    if ((long long)n_pt * n_ct * n_ct >= (1LL << 32) || (long long)a->n_img * imgs_per_wset >= (1LL << 32)) return 0;
+    // fused BatchNorm-backward reduction: bf16 input gradients on 16x16 / 8x8 / 4x4 maps
+    if (a->bst_x && (a->mode != 1 || !a->bst_mask || !a->stat_partial || a->dtype != FB_BF16 || W == 32)) return 0;
+    return wide ? 2 : 1;
+}
+
+int fb_conv3x3_halo4_takes(const fb_conv_args* a) { return h4_variant(a) != 0; }
+
+// returns 1 if the kernel handled the call
+int fb_try_conv3x3_halo4(const fb_conv_args* a, hipStream_t st) {
+    const int variant = h4_variant(a);
+    if (variant == 0) return 0;
+    const bool wide = variant == 2;
+    const int W = a->Ws, EB = a->dtype == FB_F32 ? 4 : 2;
+    const int imgs_per_wset = a->imgs_per_wset > 0 ? a->imgs_per_wset : a->n_img;
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -409,6 +492,8 @@ int fb_try_conv3x3_halo4(const fb_conv_args* a, hipStream_t st) {
     Halo4Params p;
     p.src = (const char*)a->src; p.wgt = (const char*)a->wgt; p.dst = (char*)a->dst; p.addend = (const char*)a->addend;
     p.stat = a->stat_partial;
+    p.bst_x = (const char*)a->bst_x; p.bst_mask = (const unsigned char*)a->bst_mask;
+    p.amax_src = a->amax_src; p.amax_wgt = a->amax_wgt;
     p.n_img = a->n_img; p.H = a->Hs; p.Cs = a->Cs; p.Cd = a->Cd; p.mode = a->mode;
     p.imgs_per_wset = imgs_per_wset;
     p.wset_stride_bytes = a->wset_stride * EB;
@@ -417,7 +502,6 @@ int fb_try_conv3x3_halo4(const fb_conv_args* a, hipStream_t st) {
     p.n_mblocks = n_pt * 2;
     p.n_ct = a->Cd / (wide ? 128 : 64);
     p.n_tiles = n_pt * p.n_ct;
-    if ((long long)p.n_tiles * p.n_ct >= (1LL << 32) || (long long)a->n_img * imgs_per_wset >= (1LL << 32)) return 0;
     p.magic_ct = h4_magic(p.n_ct);
     p.magic_wset = h4_magic(imgs_per_wset);
 #ifdef FB_H4_TRACE
@@ -425,6 +509,15 @@ int fb_try_conv3x3_halo4(const fb_conv_args* a, hipStream_t st) {
     p.trace = g_h4_trace;
 #endif
     dim3 grid(p.n_tiles < 2 * n_cu ? p.n_tiles : 2 * n_cu);
+    if (a->bst_x) {
+        dim3 grid1(p.n_tiles < n_cu ? p.n_tiles : n_cu);
+        if (wide && W == 16) hipLaunchKernelGGL((conv3x3s1_halo4_kernel<bf16_tag, 16, 8, true>), grid1, dim3(256), 0, st, p);
+        else if (wide && W == 8) hipLaunchKernelGGL((conv3x3s1_halo4_kernel<bf16_tag, 8, 8, true>), grid1, dim3(256), 0, st, p);
+        else if (wide) hipLaunchKernelGGL((conv3x3s1_halo4_kernel<bf16_tag, 4, 8, true>), grid1, dim3(256), 0, st, p);
+        else if (W == 16) hipLaunchKernelGGL((conv3x3s1_halo4_kernel<bf16_tag, 16, 4, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv3x3s1_halo4_kernel<bf16_tag, 8, 4, true>), grid, dim3(256), 0, st, p);
+        return 1;
+    }
     if (wide) {
         dim3 grid1(p.n_tiles < n_cu ? p.n_tiles : n_cu);
         if (W == 16) hipLaunchKernelGGL((conv3x3s1_halo4_kernel<bf16_tag, 16, 8>), grid1, dim3(256), 0, st, p);
@@ -432,7 +525,11 @@ int fb_try_conv3x3_halo4(const fb_conv_args* a, hipStream_t st) {
         else hipLaunchKernelGGL((conv3x3s1_halo4_kernel<bf16_tag, 4, 8>), grid1, dim3(256), 0, st, p);
         return 1;
     }
-    if (a->dtype == FB_F32 && fb_f32_split_enabled()) {
+    if (a->dtype == FB_F32 && a->amax_src && a->amax_wgt) {
+        if (W == 32) hipLaunchKernelGGL((conv3x3s1_halo4_kernel<f32h_tag, 32>), grid, dim3(256), 0, st, p);
+        else if (W == 16) hipLaunchKernelGGL((conv3x3s1_halo4_kernel<f32h_tag, 16>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv3x3s1_halo4_kernel<f32h_tag, 8>), grid, dim3(256), 0, st, p);
+    } else if (a->dtype == FB_F32 && fb_f32_split_enabled()) {
         if (W == 32) hipLaunchKernelGGL((conv3x3s1_halo4_kernel<f32s_tag, 32>), grid, dim3(256), 0, st, p);
         else if (W == 16) hipLaunchKernelGGL((conv3x3s1_halo4_kernel<f32s_tag, 16>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv3x3s1_halo4_kernel<f32s_tag, 8>), grid, dim3(256), 0, st, p);

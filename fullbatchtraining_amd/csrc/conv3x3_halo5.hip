@@ -18,6 +18,7 @@
 struct Halo5Params {
     const char* src; const char* wgt; char* dst; const char* addend; float* stat;
     const unsigned char* addend_mask;                        // ADD == 2: ReLU bitmask of the addend (1 byte per 8 channels)
+    const char* bst_x; const unsigned char* bst_mask;       // BST: input and ReLU bitmask of the BatchNorm whose backward consumes dst
     int n_img, mode, addend_mode, n_mblocks, n_tiles;
 #ifdef FB_H5_TRACE
     long long* trace;                                       // tools/h5_trace.hip: 8 timestamps per tile
@@ -59,7 +60,10 @@ constexpr int H5_KH = (H5_NGRP + 3) / 4;                                        
 // MODE 0: forward (BN partial sums), MODE 1: input gradient (flipped taps; ADD 1: + addend of the same shape, ADD 2: + addend where
 // its ReLU bitmask is set -- the masked gradient of the residual branch without a materialised copy).  Compile-time so that
 // the epilogue slices are straight-line code the scheduler can thread through the MFMA batches.
-template <int MODE, int ADD>
+// BST (input gradient only): the reduction pass of the BatchNorm backward that consumes the output rides along -- with g = the bf16 output
+// where the bit of bst_mask is set and x = bst_x at the same position, `stat` receives the 128-pixel-block sums of g and of g*x (the forward
+// variant's sums / sums of squares slots).  8 more bytes per lane and fragment pair in the prefetch queue, ~20 VALU per fragment.
+template <int MODE, int ADD, int BST = 0>
 __global__ __launch_bounds__(256) void conv3x3s1_c64_halo5_kernel(const Halo5Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int W = H5_W, PITCH = H5_PITCH;
@@ -144,8 +148,17 @@ __global__ __launch_bounds__(256) void conv3x3s1_c64_halo5_kernel(const Halo5Par
     // where it is consumed would stall the whole in-order stream for an HBM round trip
     h5_u32x2 ad[4][2];
     unsigned adm[4];                                        // ADD == 2: the four mask bytes of this lane's pixel and channel half
+    h5_u32x2 bx[4][2];                                      // BST: x of the consuming BatchNorm, same positions as the outputs
+    unsigned bxm[4];
     auto ad_issue = [&](auto jc, const int Lp) {
         constexpr int J = decltype(jc)::value;
+        if constexpr (BST != 0 && J < 8) {
+            const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bst_x + (long long)Lp * 256 * 128), 0, 256 * 128, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) bx[J & 3][i] = __builtin_amdgcn_raw_buffer_load_b64(rsrcX, voffD + i * 32, J * 2048, 0);
+            const __amdgpu_buffer_rsrc_t rsrcN = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bst_mask + (long long)Lp * 256 * 8), 0, 256 * 8, 0x00020000);
+            bxm[J & 3] = __builtin_amdgcn_raw_buffer_load_b32(rsrcN, ((ph * 128 + t) * 8 + ch * 4), J * 128, 0);
+        }
         if constexpr (ADD != 0 && J < 8) {
             const __amdgpu_buffer_rsrc_t rsrcE = __builtin_amdgcn_make_buffer_rsrc((void*)(p.addend + (long long)Lp * 256 * 128), 0, 256 * 128, 0x00020000);
 #pragma unroll
@@ -191,8 +204,21 @@ __global__ __launch_bounds__(256) void conv3x3s1_c64_halo5_kernel(const Halo5Par
                         v[2] += __uint_as_float(a[1] << 16); v[3] += __uint_as_float(a[1] & 0xffff0000u);
                     }
                     pk[i][0] = pack_bf16x2(v[0], v[1]); pk[i][1] = pack_bf16x2(v[2], v[3]);
+                    if constexpr (BST != 0) {
+                        // g = the STORED bf16 value where the consuming BatchNorm's ReLU passed; sums of g and of g * x
+                        const unsigned bits = bxm[J & 3] >> ((2 * i + (g >> 1)) * 8 + (g & 1) * 4);
+                        const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 0, 1), m1 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 1, 1);
+                        const unsigned m2 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 2, 1), m3 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 3, 1);
+                        const h5_u32x2 xv = bx[J & 3][i];
+                        const float g0 = __uint_as_float((pk[i][0] << 16) & m0), g1 = __uint_as_float(pk[i][0] & 0xffff0000u & m1);
+                        const float g2 = __uint_as_float((pk[i][1] << 16) & m2), g3 = __uint_as_float(pk[i][1] & 0xffff0000u & m3);
+                        ssum[i][0] += g0; ssum[i][1] += g1; ssum[i][2] += g2; ssum[i][3] += g3;
+                        ssq[i][0] = fmaf(g0, __uint_as_float(xv[0] << 16), ssq[i][0]); ssq[i][1] = fmaf(g1, __uint_as_float(xv[0] & 0xffff0000u), ssq[i][1]);
+                        ssq[i][2] = fmaf(g2, __uint_as_float(xv[1] << 16), ssq[i][2]); ssq[i][3] = fmaf(g3, __uint_as_float(xv[1] & 0xffff0000u), ssq[i][3]);
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { ssum[i][r] += v[r]; ssq[i][r] += v[r] * v[r]; }
+                        for (int r = 0; r < 4; ++r) { ssum[i][r] += v[r]; ssq[i][r] += v[r] * v[r]; }
+                    }
                 }
                 const h5_u32x2 lo = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);   // rows: (X0,Y0,X2,Y2) / (X1,Y1,X3,Y3)
                 const h5_u32x2 hi = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
@@ -200,14 +226,14 @@ __global__ __launch_bounds__(256) void conv3x3s1_c64_halo5_kernel(const Halo5Par
                 ad_issue(std::integral_constant<int, J + 3>{}, Lp);
             }
         } else if constexpr (S == 16) {
-            if constexpr (MODE == 0) {
+            if constexpr (MODE == 0 || BST != 0) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { ssum[i][r] = row16_sum(ssum[i][r]); ssq[i][r] = row16_sum(ssq[i][r]); }
             }
         } else {
-            if (MODE == 0 && t == 0) {                       // four lanes (g = 0..3): 2 x 16 bytes of sums and of sums of squares each
+            if ((MODE == 0 || BST != 0) && t == 0) {         // four lanes (g = 0..3): 2 x 16 bytes of sums and of sums of squares each
                 const long long blk = 2LL * Lp + ph;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -316,6 +342,7 @@ int fb_conv3x3_halo5_takes(const fb_conv_args* a) {
     if (a->addend && a->addend_mode != 1) return 0;
     if (a->addend_mask && (!a->addend || a->mode != 1)) return 0;
     if (a->mode == 0 && !a->stat_partial) return 0;                            // (the forward variant always writes statistics)
+    if (a->bst_x && (a->mode != 1 || !a->bst_mask || !a->stat_partial)) return 0;
     return 1;
 }
 
@@ -329,8 +356,9 @@ int fb_try_conv3x3_halo5(const fb_conv_args* a, hipStream_t st) {
     }
     Halo5Params p;
     p.src = (const char*)a->src; p.wgt = (const char*)a->wgt; p.dst = (char*)a->dst; p.addend = (const char*)a->addend;
-    p.stat = a->mode == 0 ? a->stat_partial : nullptr;
+    p.stat = (a->mode == 0 || a->bst_x) ? a->stat_partial : nullptr;
     p.addend_mask = (const unsigned char*)a->addend_mask;
+    p.bst_x = (const char*)a->bst_x; p.bst_mask = (const unsigned char*)a->bst_mask;
     p.n_img = a->n_img; p.mode = a->mode; p.addend_mode = a->addend ? 1 : 0;
     p.n_tiles = a->n_img * 4;
     p.n_mblocks = p.n_tiles * 2;
@@ -341,6 +369,10 @@ int fb_try_conv3x3_halo5(const fb_conv_args* a, hipStream_t st) {
     const dim3 grid(p.n_tiles < n_cu ? p.n_tiles : n_cu);
     if (a->mode == 0) {
         hipLaunchKernelGGL((conv3x3s1_c64_halo5_kernel<0, 0>), grid, dim3(256), 0, st, p);
+    } else if (a->bst_x) {
+        if (a->addend && a->addend_mask) hipLaunchKernelGGL((conv3x3s1_c64_halo5_kernel<1, 2, 1>), grid, dim3(256), 0, st, p);
+        else if (a->addend) hipLaunchKernelGGL((conv3x3s1_c64_halo5_kernel<1, 1, 1>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv3x3s1_c64_halo5_kernel<1, 0, 1>), grid, dim3(256), 0, st, p);
     } else if (a->addend && a->addend_mask) {
         hipLaunchKernelGGL((conv3x3s1_c64_halo5_kernel<1, 2>), grid, dim3(256), 0, st, p);
     } else if (a->addend) {

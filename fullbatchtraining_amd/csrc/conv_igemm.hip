@@ -204,6 +204,23 @@ extern "C" int32_t fb_conv_masked_addend_supported(const fb_conv_args* a) {
     return fb_conv3x3_halo5_takes(a);
 }
 
+// 1 if fb_conv2d implements the fused BatchNorm-backward reduction for these arguments: the resident-filter and the persistent halo kernels
+int fb_conv3x3_halo4_takes(const fb_conv_args* a);   // conv3x3_halo4.hip
+extern "C" int32_t fb_conv_bwd_stat_supported(const fb_conv_args* a) {
+    static const bool disabled = getenv("FB_DISABLE_FUSED_BWD_STAT") != nullptr;
+    if (disabled || !a || !a->bst_x || !a->bst_mask || !a->stat_partial || a->mode != 1 || a->dtype != FB_BF16) return 0;
+    if ((long long)a->n_img * a->Hd * a->Wd % 128 != 0) return 0;
+    static const char* widths = getenv("FB_FUSED_BWD_STAT_W");          // A/B switch: list of map widths, e.g. "4,8"
+    if (widths) {
+        char tag[8];
+        snprintf(tag, sizeof(tag), "%d,", a->Wd);
+        char list[64];
+        snprintf(list, sizeof(list), "%s,", widths);
+        if (!strstr(list, tag) || (a->Wd < 10 && list != strstr(list, tag) && *(strstr(list, tag) - 1) != ',')) return 0;
+    }
+    return fb_conv3x3_halo5_takes(a) || fb_conv3x3_halo4_takes(a);
+}
+
 template <typename T> static int launch_conv(const ConvParams& p, int classes, hipStream_t st) {
     const int mblocks = (p.M + 127) / 128;
     if (p.Cd % 128 == 0 && (long long)mblocks * (p.Cd / 128) * classes >= 512) {
@@ -224,6 +241,8 @@ extern "C" int fb_conv2d(const fb_conv_args* a, void* stream) {
     if (a->mode != 0 && a->mode != 1) FB_FAIL(FB_ERR_ARG, "fb_conv2d: mode %d", a->mode);
     if (a->addend_mask && !fb_conv_masked_addend_supported(a))
         FB_FAIL(FB_ERR_UNSUPPORTED, "fb_conv2d: addend_mask is not implemented for this shape (ask fb_conv_masked_addend_supported)");
+    if (a->bst_x && !fb_conv_bwd_stat_supported(a))
+        FB_FAIL(FB_ERR_UNSUPPORTED, "fb_conv2d: the fused BatchNorm-backward reduction is not implemented for this shape (ask fb_conv_bwd_stat_supported)");
     if (a->stride != 1 && a->stride != 2) FB_FAIL(FB_ERR_UNSUPPORTED, "fb_conv2d: stride %d", a->stride);
     ConvParams p;
     p.src = (const char*)a->src; p.wgt = (const char*)a->wgt; p.dst = (char*)a->dst; p.addend = (const char*)a->addend;
@@ -233,6 +252,8 @@ extern "C" int fb_conv2d(const fb_conv_args* a, void* stream) {
     p.imgs_per_wset = a->imgs_per_wset > 0 ? a->imgs_per_wset : a->n_img;
     p.wset_stride_bytes = a->wset_stride * EB;
     p.addend_mode = a->addend ? a->addend_mode : 0;
+    p.amax_src = a->dtype == FB_F32 ? a->amax_src : nullptr; p.amax_wgt = a->dtype == FB_F32 ? a->amax_wgt : nullptr;
+    if ((p.amax_src == nullptr) != (p.amax_wgt == nullptr)) FB_FAIL(FB_ERR_ARG, "fb_conv2d: amax_src and amax_wgt go together");
     int classes = 1;
     if (a->mode == 0) {
         if (a->Hd != (a->Hs + 2 * a->pad - a->R) / a->stride + 1 || a->Wd != (a->Ws + 2 * a->pad - a->S) / a->stride + 1)
@@ -242,7 +263,7 @@ extern "C" int fb_conv2d(const fb_conv_args* a, void* stream) {
         // dst = d_input [Hd x Wd], src = d_output [Hs x Ws]
         if (a->Hs != (a->Hd + 2 * a->pad - a->R) / a->stride + 1 || a->Ws != (a->Wd + 2 * a->pad - a->S) / a->stride + 1)
             FB_FAIL(FB_ERR_SHAPE, "fb_conv2d: dgrad shapes inconsistent");
-        if (a->stat_partial) FB_FAIL(FB_ERR_ARG, "fb_conv2d: statistics only in mode 0");
+        if (a->stat_partial && !a->bst_x) FB_FAIL(FB_ERR_ARG, "fb_conv2d: statistics in mode 1 need bst_x / bst_mask");
         if (a->stride == 1) { p.qH = a->Hd; p.qW = a->Wd; p.os = 1; }
         else {
             if ((a->Hd & 1) || (a->Wd & 1)) FB_FAIL(FB_ERR_SHAPE, "fb_conv2d: stride-2 dgrad needs even input dims");
@@ -258,6 +279,7 @@ extern "C" int fb_conv2d(const fb_conv_args* a, void* stream) {
     if (!fb_try_conv1x1_k32(a, st) && !fb_try_conv3x3s2_dgrad_quad(a, st) && !fb_try_conv3x3_halo5(a, st) && !fb_try_conv3x3_halo4(a, st)) {
         p.zeros = nullptr;
         if (v1 || !fb_launch_igemm_glds(p, classes, a->dtype, st)) {
+            if (p.amax_src) FB_FAIL(FB_ERR_UNSUPPORTED, "fb_conv2d: the register-staged implicit GEMM has no fp16x2 path (tensor beyond 2^31 bytes or FB_IGEMM_V1)");
             if (a->dtype == FB_F32) launch_conv<float>(p, classes, st); else launch_conv<bf16_tag>(p, classes, st);
         }
     }

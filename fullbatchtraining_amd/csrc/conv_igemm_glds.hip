@@ -145,6 +145,11 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(const ConvParams p, 
     for (int i = 0; i < FI; ++i)
 #pragma unroll
         for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float hs_src = 1.f, hs_wgt = 1.f, hs_inv = 1.f;         // f32h: per-tensor power-of-two scales
+    if constexpr (is_hsplit<T>::value) {
+        hs_src = fb_pow2_scale(*p.amax_src); hs_wgt = fb_pow2_scale(*p.amax_wgt);
+        hs_inv = 1.f / (hs_src * hs_wgt);
+    }
 
     const unsigned pc0 = ((lane >> 4) ^ (lane & 7)) * 16, pc1 = (((lane >> 4) + 4) ^ (lane & 7)) * 16;
     const unsigned wb = lds0 + (128 + wave_co * (BN_CO / 2) + (lane & 15)) * 128;
@@ -164,7 +169,18 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(const ConvParams p, 
             static_for<0, FJ>([&](auto j) { pf0[decltype(j)::value] = lds_read16<decltype(j)::value * 2048>(p0); });
             static_for<0, FI>([&](auto i) { wf1[decltype(i)::value] = lds_read16<decltype(i)::value * 2048>(w1); });
             static_for<0, FJ>([&](auto j) { pf1[decltype(j)::value] = lds_read16<decltype(j)::value * 2048>(p1); });
-            if constexpr (is_split<T>::value) {      // fp32 operands as three bf16 pieces each, six MFMAs per fragment pair (common.h)
+            if constexpr (is_hsplit<T>::value) {     // fp32 operands as two scaled fp16 pieces each, three MFMAs per fragment pair (common.h)
+                wait_lgkmcnt<0>();
+                split2h_t sw[FI], sp[FJ];
+#pragma unroll
+                for (int i = 0; i < FI; ++i) { sw[i].h = __builtin_bit_cast(f16x8_t, wf0[i]); sw[i].l = __builtin_bit_cast(f16x8_t, wf1[i]); }   // planes (fb_weight_prep)
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) sp[j] = split_h2x8(pf0[j], pf1[j], hs_src);
+#pragma unroll
+                for (int i = 0; i < FI; ++i)
+#pragma unroll
+                    for (int j = 0; j < FJ; ++j) acc[i][j] = mma_split3h(sw[i], sp[j], acc[i][j], hs_inv);
+            } else if constexpr (is_split<T>::value) {      // fp32 operands as three bf16 pieces each, six MFMAs per fragment pair (common.h)
                 wait_lgkmcnt<0>();
                 split3_t sw[FI], sp[FJ];
 #pragma unroll
@@ -285,7 +301,11 @@ int fb_launch_igemm_glds(const ConvParams& p, int classes, int dtype, hipStream_
     const int EB = dtype == FB_F32 ? 4 : 2;
     const long long bytesA = (long long)p.n_img * p.Hs * p.Ws * p.Cs * EB, bytesW = (long long)p.Cd * p.R * p.S * p.Cs * EB;
     if (bytesA >= (1LL << 31) || bytesW >= (1LL << 31)) return 0;
-    if (dtype == FB_F32) { if (fb_f32_split_enabled()) launch<f32s_tag>(p, classes, st); else launch<float>(p, classes, st); }
+    if (dtype == FB_F32) {
+        if (p.amax_src && p.amax_wgt) launch<f32h_tag>(p, classes, st);
+        else if (fb_f32_split_enabled()) launch<f32s_tag>(p, classes, st);
+        else launch<float>(p, classes, st);
+    }
     else launch<bf16_tag>(p, classes, st);
     return 1;
 }

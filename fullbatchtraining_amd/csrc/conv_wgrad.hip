@@ -18,12 +18,14 @@ struct WgradParams {
     int R, S, stride, pad;
     int imgs_per_group, split_k, px_per_group, px_per_split;
     long long group_stride;                                 // floats between the slabs of consecutive groups
+    const float* amax_x; const float* amax_dy;              // f32h (fp16x2 split): largest magnitudes of the two operand tensors
 };
 
 template <typename T> struct WG;
 template <> struct WG<bf16_tag> { static constexpr int PAD = 16; };
 template <> struct WG<float> { static constexpr int PAD = 64; };
 template <> struct WG<f32s_tag> : WG<float> {};
+template <> struct WG<f32h_tag> : WG<float> {};
 
 // transposed fragment: for channels c0..c0+15 (lane&15) and pixels pb + 8*(lane>>4) .. +7 (bf16) -> one 16-byte chunk
 template <typename T> __device__ __forceinline__ void load_frag_t(const char* tile, int row_bytes, int pb, int c0, int lane, uint4 (&out)[2]);
@@ -61,15 +63,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     // split path (fp32 storage, bf16x6 arithmetic): a tile is stored to LDS as THREE bf16 planes (h, m, l: every loaded element is
     // split once, 22 VALU per 16-byte chunk) and the fragments come from the transposed bf16 reads of the bf16 kernel -- no per-fragment
     // split (44 VALU per fragment and wave before), 6 ds_read_b64_tr_b16 instead of 8 ds_read_b32 per fragment
-    constexpr bool SPLIT = is_split<T>::value;
-    constexpr int PROW_A = TM * 2 + WG<bf16_tag>::PAD, PROW_B = TN * 2 + WG<bf16_tag>::PAD;      // plane rows (bf16)
+    // f32h: TWO scaled fp16 planes and three MFMAs per fragment pair (common.h); the accumulators hold the scaled sums, the epilogue
+    // multiplies by 2^-(e_x + e_dy)
+    constexpr bool HSPLIT = is_hsplit<T>::value;
+    constexpr bool SPLIT = is_split<T>::value || HSPLIT;
+    constexpr int NPL = HSPLIT ? 2 : 3;
+    constexpr int PROW_A = TM * 2 + WG<bf16_tag>::PAD, PROW_B = TN * 2 + WG<bf16_tag>::PAD;      // plane rows (bf16 / fp16)
     constexpr int PLANE_A = KPX * PROW_A, PLANE_B = KPX * PROW_B;
-    constexpr int TILE_BYTES = SPLIT ? 3 * (PLANE_A + PLANE_B) : KPX * (ROW_A + ROW_B);
+    constexpr int TILE_BYTES = SPLIT ? NPL * (PLANE_A + PLANE_B) : KPX * (ROW_A + ROW_B);
     constexpr int RED_BYTES = (WK > 1) ? WK * 64 * 16 * NJ * 4 : 0;
     constexpr int LDS_BYTES = TILE_BYTES > RED_BYTES ? TILE_BYTES : RED_BYTES;
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     char* tileA = lds;
-    char* tileB = lds + (SPLIT ? 3 * PLANE_A : KPX * ROW_A);
+    char* tileB = lds + (SPLIT ? NPL * PLANE_A : KPX * ROW_A);
+    float hs_a = 1.f, hs_b = 1.f;
+    if constexpr (HSPLIT) { hs_a = fb_pow2_scale(*p.amax_dy); hs_b = fb_pow2_scale(*p.amax_x); }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
@@ -117,17 +125,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
             for (int i = 0; i < LD_A; ++i) {
                 const int id = tid + 256 * i, row = id / CH_A, ch = id % CH_A;
                 uint2 h, m, l;
-                split_f32x4(ra[i], h, m, l);
                 char* d = tileA + row * PROW_A + ch * 8;
-                *(uint2*)d = h; *(uint2*)(d + PLANE_A) = m; *(uint2*)(d + 2 * PLANE_A) = l;
+                if constexpr (HSPLIT) { split_h2x4(ra[i], hs_a, h, l); *(uint2*)d = h; *(uint2*)(d + PLANE_A) = l; }
+                else { split_f32x4(ra[i], h, m, l); *(uint2*)d = h; *(uint2*)(d + PLANE_A) = m; *(uint2*)(d + 2 * PLANE_A) = l; }
             }
 #pragma unroll
             for (int i = 0; i < LD_B; ++i) {
                 const int id = tid + 256 * i, row = id / CH_B, ch = id % CH_B;
                 uint2 h, m, l;
-                split_f32x4(rb[i], h, m, l);
                 char* d = tileB + row * PROW_B + ch * 8;
-                *(uint2*)d = h; *(uint2*)(d + PLANE_B) = m; *(uint2*)(d + 2 * PLANE_B) = l;
+                if constexpr (HSPLIT) { split_h2x4(rb[i], hs_b, h, l); *(uint2*)d = h; *(uint2*)(d + PLANE_B) = l; }
+                else { split_f32x4(rb[i], h, m, l); *(uint2*)d = h; *(uint2*)(d + PLANE_B) = m; *(uint2*)(d + 2 * PLANE_B) = l; }
             }
         } else {
 #pragma unroll
@@ -147,19 +155,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         for (int rep = 0; rep < KREP; ++rep) {
             const int pb = (wk * KREP + rep) * 32;
             if constexpr (SPLIT) {
-                uint4 ap[4][3], bp[NJ][3], tmp[2];
+                uint4 ap[4][NPL], bp[NJ][NPL], tmp[2];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) { load_frag_t<bf16_tag>(tileA + pl * PLANE_A, PROW_A, pb, wm * 64 + i * 16, lane, tmp); ap[i][pl] = tmp[0]; }
+                    for (int pl = 0; pl < NPL; ++pl) { load_frag_t<bf16_tag>(tileA + pl * PLANE_A, PROW_A, pb, wm * 64 + i * 16, lane, tmp); ap[i][pl] = tmp[0]; }
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) { load_frag_t<bf16_tag>(tileB + pl * PLANE_B, PROW_B, pb, wn * 16 * NJ + j * 16, lane, tmp); bp[j][pl] = tmp[0]; }
+                    for (int pl = 0; pl < NPL; ++pl) { load_frag_t<bf16_tag>(tileB + pl * PLANE_B, PROW_B, pb, wn * 16 * NJ + j * 16, lane, tmp); bp[j][pl] = tmp[0]; }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) acc[i][j] = mma_planes6(ap[i], bp[j], acc[i][j]);
+                    for (int j = 0; j < NJ; ++j) {
+                        if constexpr (HSPLIT) acc[i][j] = mma_planes3h_acc(ap[i], bp[j], acc[i][j]);
+                        else acc[i][j] = mma_planes6(ap[i], bp[j], acc[i][j]);
+                    }
             } else {
             uint4 af[4][2], bf[NJ][2];
 #pragma unroll
@@ -177,6 +188,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         }
     }
 
+    if constexpr (HSPLIT) {                                  // the accumulators hold sums of (2^e_dy dy) * (2^e_x x)
+        const float inv = 1.f / (hs_a * hs_b);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[i][j][q] *= inv;
+    }
     // ---- output: [group][split][co][tap][ci] -------------------------------------------------------------------------
     const int taps = p.R * p.S;
     float* out = p.out + group * p.group_stride + ((long long)split * p.Cd) * taps * p.Cs;
@@ -227,6 +247,9 @@ extern "C" int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream) {
     p.imgs_per_group = a->imgs_per_group; p.split_k = a->split_k;
     p.group_stride = a->group_stride ? a->group_stride : (long long)a->split_k * a->Cd * a->R * a->S * a->Cs;
     p.px_per_group = a->imgs_per_group * a->Hd * a->Wd;
+    p.amax_x = a->dtype == FB_F32 ? a->amax_x : nullptr; p.amax_dy = a->dtype == FB_F32 ? a->amax_dy : nullptr;
+    if ((p.amax_x == nullptr) != (p.amax_dy == nullptr)) FB_FAIL(FB_ERR_ARG, "fb_conv2d_wgrad: amax_x and amax_dy go together");
+    const bool hsplit = p.amax_x != nullptr;
     const int n_groups = a->n_img / a->imgs_per_group;
     hipStream_t st = (hipStream_t)stream;
     const bool big = (a->Cs % 128 == 0) && (a->Cd % 128 == 0) && (a->Cs >= 256 || a->Cd >= 256);
@@ -238,17 +261,20 @@ extern "C" int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream) {
     if (fb_try_wgrad3x3_v2(a, st) || fb_try_wgrad3x3(a, st)) {
     } else if (big) {
         dim3 grid((a->Cd / 128) * (a->Cs / 128), taps, n_groups * a->split_k);
-        if (a->dtype == FB_F32 && split) hipLaunchKernelGGL((conv_wgrad_kernel<f32s_tag, 2, 2, 1, 1, 4>), grid, dim3(256), 0, st, p);
+        if (hsplit) hipLaunchKernelGGL((conv_wgrad_kernel<f32h_tag, 2, 2, 1, 1, 4>), grid, dim3(256), 0, st, p);
+        else if (a->dtype == FB_F32 && split) hipLaunchKernelGGL((conv_wgrad_kernel<f32s_tag, 2, 2, 1, 1, 4>), grid, dim3(256), 0, st, p);
         else if (a->dtype == FB_F32) hipLaunchKernelGGL((conv_wgrad_kernel<float, 2, 2, 1, 1, 4>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_tag, 2, 2, 1, 2, 4>), grid, dim3(256), 0, st, p);
     } else if (a->Cs % 64 == 0) {
         dim3 grid((a->Cd / 64) * (a->Cs / 64), taps, n_groups * a->split_k);
-        if (a->dtype == FB_F32 && split) hipLaunchKernelGGL((conv_wgrad_kernel<f32s_tag, 1, 1, 4, 1, 4>), grid, dim3(256), 0, st, p);
+        if (hsplit) hipLaunchKernelGGL((conv_wgrad_kernel<f32h_tag, 1, 1, 4, 1, 4>), grid, dim3(256), 0, st, p);
+        else if (a->dtype == FB_F32 && split) hipLaunchKernelGGL((conv_wgrad_kernel<f32s_tag, 1, 1, 4, 1, 4>), grid, dim3(256), 0, st, p);
         else if (a->dtype == FB_F32) hipLaunchKernelGGL((conv_wgrad_kernel<float, 1, 1, 4, 1, 4>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_tag, 1, 1, 4, 1, 4>), grid, dim3(256), 0, st, p);
     } else {   // Cs multiple of 32 only (pre-gathered stem patches): 64 x 32 tiles
         dim3 grid((a->Cd / 64) * (a->Cs / 32), taps, n_groups * a->split_k);
-        if (a->dtype == FB_F32 && split) hipLaunchKernelGGL((conv_wgrad_kernel<f32s_tag, 1, 1, 4, 1, 2>), grid, dim3(256), 0, st, p);
+        if (hsplit) hipLaunchKernelGGL((conv_wgrad_kernel<f32h_tag, 1, 1, 4, 1, 2>), grid, dim3(256), 0, st, p);
+        else if (a->dtype == FB_F32 && split) hipLaunchKernelGGL((conv_wgrad_kernel<f32s_tag, 1, 1, 4, 1, 2>), grid, dim3(256), 0, st, p);
         else if (a->dtype == FB_F32) hipLaunchKernelGGL((conv_wgrad_kernel<float, 1, 1, 4, 1, 2>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_tag, 1, 1, 4, 1, 2>), grid, dim3(256), 0, st, p);
     }
@@ -298,11 +324,46 @@ __global__ void weight_prep_kernel(const float* __restrict__ master, long long w
     if (w_dgrad) w_dgrad[(long long)ws * wset_stride_out + ((long long)ci * taps + t) * Cout + co] = o;
 }
 
+// fp16x2 planes (common.h, f32h_tag): every 128-byte group of 32 fp32 values becomes [32 fp16 high pieces | 32 fp16 low pieces] of the
+// values scaled by the layer's power of two, in the K-slot order of the convolution kernels' fragment reads: the lane group g of an MFMA
+// step reads 16-byte chunk g (its high pieces) and chunk g + 4 (its low pieces), and the fp32 activations it splits on the fly are the
+// values {4g..4g+3, 16+4g..16+4g+3} of the group -- so value j sits at slot 8*(j%16/4) + 4*(j/16) + j%4.
+__device__ __forceinline__ long long planes_slot(long long inner) {
+    const int j = (int)(inner & 31);
+    return (inner & ~31LL) * 2 + 8 * ((j & 15) >> 2) + 4 * (j >> 4) + (j & 3);        // in 2-byte units from the row start
+}
+__global__ void weight_prep_planes_kernel(const float* __restrict__ master, long long wset_stride_in, long long wset_stride_out, int Cout, int taps,
+                                          int Cin_real, int Cin_pad, _Float16* __restrict__ w_fwd, _Float16* __restrict__ w_dgrad,
+                                          const float* __restrict__ amax) {
+    const long long per_set = (long long)Cout * taps * Cin_pad;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ws = blockIdx.y;
+    if (idx >= per_set) return;
+    const int ci = (int)(idx % Cin_pad); const long long rt = idx / Cin_pad; const int t = (int)(rt % taps); const int co = (int)(rt / taps);
+    float v = 0.f;
+    if (ci < Cin_real) v = master[(long long)ws * wset_stride_in + ((long long)co * taps + t) * Cin_real + ci];
+    v *= fb_pow2_scale(*amax);
+    const _Float16 h = (_Float16)v, l = (_Float16)(v - (float)h);
+    _Float16* f = w_fwd + ((long long)ws * wset_stride_out + rt * Cin_pad) * 2 + planes_slot(ci);
+    f[0] = h; f[32] = l;
+    if (w_dgrad) {
+        _Float16* d = w_dgrad + ((long long)ws * wset_stride_out + ((long long)ci * taps + t) * Cout) * 2 + planes_slot(co);
+        d[0] = h; d[32] = l;
+    }
+}
+
 extern "C" int fb_weight_prep(const float* master, int64_t wset_stride_in, int64_t wset_stride_out, int32_t n_wsets, int32_t Cout, int32_t taps,
-                              int32_t Cin_real, int32_t Cin_pad, void* w_fwd, void* w_dgrad, int32_t dtype, void* stream) {
+                              int32_t Cin_real, int32_t Cin_pad, void* w_fwd, void* w_dgrad, int32_t dtype, const float* amax, void* stream) {
     if (!master || !w_fwd) FB_FAIL(FB_ERR_ARG, "fb_weight_prep: null pointer");
     const long long per_set = (long long)Cout * taps * Cin_pad;
     dim3 grid((unsigned)ceil_div64(per_set, 256), n_wsets);
+    if (amax) {
+        if (dtype != FB_F32 || Cin_pad % 32 != 0 || Cout % 32 != 0) FB_FAIL(FB_ERR_ARG, "fb_weight_prep: fp16x2 planes need fp32 copies and channels in multiples of 32");
+        hipLaunchKernelGGL(weight_prep_planes_kernel, grid, dim3(256), 0, (hipStream_t)stream, master, (long long)wset_stride_in, (long long)wset_stride_out,
+                           Cout, taps, Cin_real, Cin_pad, (_Float16*)w_fwd, (_Float16*)w_dgrad, amax);
+        FB_CHECK_LAUNCH("fb_weight_prep");
+        return FB_OK;
+    }
     if (dtype == FB_F32)
         hipLaunchKernelGGL((weight_prep_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, master, (long long)wset_stride_in,
                            (long long)wset_stride_out, Cout, taps, Cin_real, Cin_pad, (float*)w_fwd, (float*)w_dgrad);

@@ -16,12 +16,14 @@ struct Wgrad3Params {
     int n_img, H, Cs, Cd;
     int imgs_per_group, imgs_per_block, split_k;
     long long group_stride;
+    const float* amax_x; const float* amax_dy;              // f32h (fp16x2 split): largest magnitudes of the two operand tensors
 };
 
 template <typename T> struct W3 { };
 template <> struct W3<bf16_tag> { static constexpr int PAD = 16; };
 template <> struct W3<float> { static constexpr int PAD = 64; };
 template <> struct W3<f32s_tag> : W3<float> {};
+template <> struct W3<f32h_tag> : W3<float> {};
 
 // A operand: dY tile rows are the step's pixels in order
 template <typename T> __device__ __forceinline__ void frag_plain(const char* tile, int row_bytes, int pb, int c0, int lane, uint4 (&out)[2]);
@@ -93,12 +95,17 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p
     constexpr int LD_B = (HROWS * CH + 255) / 256;   // halo chunks per thread
     // split path (fp32 storage, bf16x6 arithmetic): both tiles are stored as THREE bf16 planes (every loaded element split once, at
     // the LDS store) and read with the transposed bf16 fragment reads -- no per-fragment split in the tap loop
-    constexpr bool SPLIT = is_split<T>::value;
-    constexpr int PROW = 64 * 2 + W3<bf16_tag>::PAD; // plane row (bf16)
+    // f32h: TWO scaled fp16 planes, three MFMAs per fragment pair; the accumulators hold the scaled sums, unscaled at the output
+    constexpr bool HSPLIT = is_hsplit<T>::value;
+    constexpr bool SPLIT = is_split<T>::value || HSPLIT;
+    constexpr int NPL = HSPLIT ? 2 : 3;
+    constexpr int PROW = 64 * 2 + W3<bf16_tag>::PAD; // plane row (bf16 / fp16)
     constexpr int PLANE_A = 64 * PROW, PLANE_B = HROWS * PROW;
-    __shared__ __attribute__((aligned(16))) char lds[SPLIT ? 3 * (PLANE_A + PLANE_B) : (64 + HROWS) * ROW];
+    __shared__ __attribute__((aligned(16))) char lds[SPLIT ? NPL * (PLANE_A + PLANE_B) : (64 + HROWS) * ROW];
     char* tileA = lds;
-    char* tileB = lds + (SPLIT ? 3 * PLANE_A : 64 * ROW);
+    char* tileB = lds + (SPLIT ? NPL * PLANE_A : 64 * ROW);
+    float hs_a = 1.f, hs_b = 1.f;
+    if constexpr (HSPLIT) { hs_a = fb_pow2_scale(*p.amax_dy); hs_b = fb_pow2_scale(*p.amax_x); }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_n = p.Cs / 64;
@@ -143,18 +150,18 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p
             for (int i = 0; i < LD_A; ++i) {
                 const int id = tid + 256 * i, row = id / CH, ch = id % CH;
                 uint2 h, m, l;
-                split_f32x4(ra[i], h, m, l);
                 char* d = tileA + row * PROW + ch * 8;
-                *(uint2*)d = h; *(uint2*)(d + PLANE_A) = m; *(uint2*)(d + 2 * PLANE_A) = l;
+                if constexpr (HSPLIT) { split_h2x4(ra[i], hs_a, h, l); *(uint2*)d = h; *(uint2*)(d + PLANE_A) = l; }
+                else { split_f32x4(ra[i], h, m, l); *(uint2*)d = h; *(uint2*)(d + PLANE_A) = m; *(uint2*)(d + 2 * PLANE_A) = l; }
             }
 #pragma unroll
             for (int i = 0; i < LD_B; ++i) {
                 const int id = tid + 256 * i, row = id / CH, ch = id % CH;
                 if (row < HROWS) {
                     uint2 h, m, l;
-                    split_f32x4(rb[i], h, m, l);
                     char* d = tileB + row * PROW + ch * 8;
-                    *(uint2*)d = h; *(uint2*)(d + PLANE_B) = m; *(uint2*)(d + 2 * PLANE_B) = l;
+                    if constexpr (HSPLIT) { split_h2x4(rb[i], hs_b, h, l); *(uint2*)d = h; *(uint2*)(d + PLANE_B) = l; }
+                    else { split_f32x4(rb[i], h, m, l); *(uint2*)d = h; *(uint2*)(d + PLANE_B) = m; *(uint2*)(d + 2 * PLANE_B) = l; }
                 }
             }
         } else {
@@ -175,18 +182,21 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p
         for (int blk = 0; blk < 2; ++blk) {
             const int pb = blk * 32;
             if constexpr (SPLIT) {
-                uint4 ap[4][3], tmp[2];
+                uint4 ap[4][NPL], tmp[2];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) { frag_plain<bf16_tag>(tileA + pl * PLANE_A, PROW, pb, i * 16, lane, tmp); ap[i][pl] = tmp[0]; }
+                    for (int pl = 0; pl < NPL; ++pl) { frag_plain<bf16_tag>(tileA + pl * PLANE_A, PROW, pb, i * 16, lane, tmp); ap[i][pl] = tmp[0]; }
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
-                    uint4 bp[3];
+                    uint4 bp[NPL];
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) { frag_halo<bf16_tag, W>(tileB + pl * PLANE_B, PROW, pb, t / 3, t % 3, wave * 16, lane, tmp); bp[pl] = tmp[0]; }
+                    for (int pl = 0; pl < NPL; ++pl) { frag_halo<bf16_tag, W>(tileB + pl * PLANE_B, PROW, pb, t / 3, t % 3, wave * 16, lane, tmp); bp[pl] = tmp[0]; }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[t][i] = mma_planes6(ap[i], bp, acc[t][i]);
+                    for (int i = 0; i < 4; ++i) {
+                        if constexpr (HSPLIT) acc[t][i] = mma_planes3h_acc(ap[i], bp, acc[t][i]);
+                        else acc[t][i] = mma_planes6(ap[i], bp, acc[t][i]);
+                    }
                 }
             } else {
             uint4 af[4][2];
@@ -207,6 +217,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p
     }
 
     float* out = p.out + group * p.group_stride + ((long long)split * p.Cd) * 9 * p.Cs;
+    const float inv = HSPLIT ? 1.f / (hs_a * hs_b) : 1.f;    // f32h: the accumulators hold sums of (2^e_dy dy) * (2^e_x x)
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p
             for (int q = 0; q < 4; ++q) {
                 const int co = tile_m * 64 + i * 16 + (lane >> 4) * 4 + q;
                 const int ci = tile_n * 64 + wave * 16 + (lane & 15);
-                out[((long long)co * 9 + t) * p.Cs + ci] = acc[t][i][q];
+                out[((long long)co * 9 + t) * p.Cs + ci] = HSPLIT ? acc[t][i][q] * inv : acc[t][i][q];
             }
 }
 
@@ -233,9 +244,13 @@ int fb_try_wgrad3x3(const fb_wgrad_args* a, hipStream_t st) {
     p.group_stride = a->group_stride ? a->group_stride : (long long)a->split_k * a->Cd * 9 * a->Cs;
     p.n_img = a->n_img; p.H = a->Hs; p.Cs = a->Cs; p.Cd = a->Cd;
     p.imgs_per_group = a->imgs_per_group; p.split_k = a->split_k; p.imgs_per_block = (a->imgs_per_group + a->split_k - 1) / a->split_k;   // ragged last K slice allowed
+    p.amax_x = a->amax_x; p.amax_dy = a->amax_dy;
     const int n_groups = a->n_img / a->imgs_per_group;
     dim3 grid((a->Cd / 64) * (a->Cs / 64), n_groups * a->split_k);
-    if (a->dtype == FB_F32 && fb_f32_split_enabled()) {
+    if (a->dtype == FB_F32 && a->amax_x && a->amax_dy) {
+        if (W == 32) hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32h_tag, 32>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32h_tag, 16>), grid, dim3(256), 0, st, p);
+    } else if (a->dtype == FB_F32 && fb_f32_split_enabled()) {
         if (W == 32) hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32s_tag, 32>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32s_tag, 16>), grid, dim3(256), 0, st, p);
     } else if (a->dtype == FB_F32) {

@@ -474,3 +474,44 @@ extern "C" int fb_mt_pnorm2(const float* a, int64_t n, float p, float* out, floa
     FB_CHECK_LAUNCH("fb_mt_pnorm2");
     return FB_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Largest magnitude of an fp32 tensor (scale source of the fp16x2 split, common.h): |x| as a bit pattern is monotone, so the maximum is an
+// integer atomic; 16-byte loads, one atomic per workgroup.  n_sets slices of n values, set_stride floats apart (the per-chunk weight sets
+// of one layer), share one result.
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x0, long long n, long long set_stride, unsigned* __restrict__ out) {
+    const float* xs = x0 + (long long)blockIdx.y * set_stride;
+    const uint4* x = (const uint4*)xs;
+    const long long n_vec = (((unsigned long long)xs & 15) == 0) ? n / 4 : 0;     // an unaligned slice takes the scalar path below
+    unsigned m = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (long long)gridDim.x * 256) {
+        const uint4 v = x[i];
+        const unsigned a = v.x & 0x7fffffffu, b = v.y & 0x7fffffffu, c = v.z & 0x7fffffffu, d = v.w & 0x7fffffffu;
+        const unsigned ab = a > b ? a : b, cd = c > d ? c : d, q = ab > cd ? ab : cd;
+        m = m > q ? m : q;
+    }
+    for (long long i = n_vec * 4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const unsigned a = __float_as_uint(xs[i]) & 0x7fffffffu;
+        m = m > a ? m : a;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)m, off); m = m > o ? m : o; }
+    __shared__ unsigned red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned a = red[0] > red[1] ? red[0] : red[1], b = red[2] > red[3] ? red[2] : red[3];
+        atomicMax(out, a > b ? a : b);
+    }
+}
+
+extern "C" int fb_absmax(const float* x, int64_t n, int32_t n_sets, int64_t set_stride, float* out, void* stream) {
+    if (!x || !out || n < 0 || n_sets < 1) FB_FAIL(FB_ERR_ARG, "fb_absmax: bad arguments");
+    if (((uintptr_t)x & 3) != 0) FB_FAIL(FB_ERR_ARG, "fb_absmax: x must be 4-byte aligned");
+    if (hipMemsetAsync(out, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) FB_FAIL(FB_ERR_LAUNCH, "fb_absmax: memset failed");
+    long long blocks = (n / 4 + 256 * 8 - 1) / (256 * 8);
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks, (unsigned)n_sets), dim3(256), 0, (hipStream_t)stream, x, (long long)n, (long long)set_stride, (unsigned*)out);
+    FB_CHECK_LAUNCH("fb_absmax");
+    return FB_OK;
+}

@@ -171,8 +171,8 @@ class _Pool:
     """Stream-ordered scratch reuse keyed by element count.  A buffer may be returned together with an event of another
     stream that still reads it (the weight-gradient stream): the next user waits for that event before writing."""
 
-    def __init__(self, device, dtype):
-        self.device, self.dtype, self.free = device, dtype, {}
+    def __init__(self, device, dtype, on_reuse=None):
+        self.device, self.dtype, self.free, self.on_reuse = device, dtype, {}, on_reuse
 
     def get(self, shape):
         numel = math.prod(shape)
@@ -181,6 +181,8 @@ class _Pool:
             t, ev = lst.pop(0)                       # oldest first: its reader has most likely finished
             if ev is not None:
                 torch.cuda.current_stream().wait_event(ev)
+            if self.on_reuse is not None:
+                self.on_reuse(t)
             return t.view(shape)
         return torch.empty(shape, device=self.device, dtype=self.dtype)
 
@@ -244,8 +246,19 @@ class Engine:
         self.vnorm2 = torch.zeros(self.G, **f32)
         self.eps_n = torch.zeros(self.G, **f32)
         self.norms2 = torch.zeros(2, **f32)
-        self.pool = _Pool(self.device, self.dt)
+        # fp32 convolutions: "f16x2" (two scaled fp16 pieces per operand, three MFMAs per product; needs the largest magnitude of every
+        # operand tensor: fb_absmax, cached per tensor below), "bf16x6" (three bf16 pieces, six MFMAs); FB_F32_EXACT=1 in the library: exact f32
+        self.f32_split = os.environ.get("FB_F32_SPLIT", "f16x2") if compute_dtype == torch.float32 else None
+        self.amax_buf = torch.zeros(1024, device=self.device, dtype=torch.float32)
+        self.amax_map, self.amax_next = {}, 0
+        for li, L in enumerate(self.plan.layers):
+            L.li = li
+        self.w_amax = [torch.zeros(len(self.plan.layers), device=self.device, dtype=torch.float32) for _ in range(2)]
+        self.pool = _Pool(self.device, self.dt, on_reuse=lambda t: self.amax_map.pop(t.data_ptr(), None))
         self.masks = {}
+        self.fuse_bwd_stat = os.environ.get("FB_FUSED_BWD_STAT", "0") != "0"     # BN-backward reduction in the input-gradient epilogues: built, parity-tested,
+        # measured SLOWER at step level (profiles/r2_notes.md: the separate HBM-bound reduction overlaps the weight-gradient stream) -> off
+        self.bst_done = False
         # weight gradients depend on nothing downstream in the backward chain: they run on their own stream, overlapping the
         # HBM-bound BN backward kernels and the dgrad convolutions of the main stream (FB_WGRAD_STREAM=0: same stream)
         self.wstream = torch.cuda.Stream(device=self.device) if os.environ.get("FB_WGRAD_STREAM", "1") != "0" else None
@@ -415,19 +428,42 @@ class Engine:
         slot = 1 if per_chunk else 0
         wf, wd = self.w_fwd[slot], self.w_dgrad[slot]
         es = wf.element_size()
-        for L in self.plan.layers:
+        for li, L in enumerate(self.plan.layers):
             dst_d = wd.data_ptr() + es * L.wc_off if L is not self.plan.stem else None
+            am = None
+            if self.f32_split == "f16x2":            # one scale per layer, shared by its forward and transposed copies and by all chunks' sets;
+                am = self.w_amax[slot].data_ptr() + 4 * li                      # the copies are then written as fp16x2 planes
+                call("fb_absmax", theta.data_ptr() + 4 * L.w_off, L.cout * L.taps * L.cin_real, nsets, self.plan.P, am)
             call("fb_weight_prep", theta.data_ptr() + 4 * L.w_off, self.plan.P, self.plan.wc_total, nsets, L.cout, L.taps, L.cin_real,
-                 L.cin_pad, wf.data_ptr() + es * L.wc_off, dst_d, self.dtc)
+                 L.cin_pad, wf.data_ptr() + es * L.wc_off, dst_d, self.dtc, am)
+
+    def _amax(self, t, numel):
+        """Device pointer of the largest magnitude of the first ``numel`` values of ``t`` (fp16x2 split scale), computed once per
+        content: the cache is dropped when a forward pass starts and when the pool hands the buffer out again."""
+        key = t.data_ptr()
+        hit = self.amax_map.get(key)
+        if hit is not None and hit[1] == numel:
+            return hit[0]
+        slot = self.amax_buf.data_ptr() + 4 * self.amax_next
+        self.amax_next = (self.amax_next + 1) % self.amax_buf.numel()
+        call("fb_absmax", t.data_ptr(), numel, 1, 0, slot)
+        self.amax_map[key] = (slot, numel)
+        return slot
+
+    def _amax_pair(self, L, src, numel, wsets):
+        if self.f32_split != "f16x2":
+            return None, None
+        return self._amax(src, numel), self.w_amax[1 if wsets > 1 else 0].data_ptr() + 4 * L.li
 
     def _conv_bn_fwd(self, L, src, G, wsets, theta, pidx):
         n = G * self.chunk
         wf = self.w_fwd[1 if wsets > 1 else 0]
         wptr = wf.data_ptr() + wf.element_size() * L.wc_off
         evalm = getattr(self, "_eval", False)
+        am_s, am_w = self._amax_pair(L, src, n * L.hin * L.win * L.cin_pad, wsets)
         a = lib.ConvArgs(src.data_ptr(), wptr, L.x.data_ptr(), None, None if evalm else self.stat_ws.data_ptr(), n, L.hin, L.win, L.cin_pad, L.hout, L.wout,
                          L.cout, L.R, L.S, L.stride, L.pad, 0, self.chunk if wsets > 1 else n, self.plan.wc_total if wsets > 1 else 0,
-                         0, self.dtc)
+                         0, self.dtc, None, None, None, am_s, am_w)
         call("fb_conv2d", lib.C.byref(a))
         if evalm:
             return
@@ -467,6 +503,7 @@ class Engine:
     def forward(self, patches, labels, G, wsets, theta, pidx):
         """patches: [G*chunk, H, W, cin_pad] stem patches; labels int64 [G*chunk].  Fills loss/correct/dlogits."""
         plan = self.plan
+        self.amax_map.clear()                        # every activation is about to be rewritten
         self._conv_bn_fwd(plan.stem, patches, G, wsets, theta, pidx)
         self._bn_apply(plan.stem, self.stem_out, G)
         a = self.stem_out
@@ -509,19 +546,24 @@ class Engine:
         return a
 
     # ----------------------------------------------------------------------------------------------------- backward --
-    def _bn_bwd(self, L, dout, mask, G, gout, pidx, want_dy):
-        """BN (+ReLU mask) backward.  Returns (dx, dy_or_None); dgamma/dbeta go to gout[g] at the layer's arena offsets."""
+    def _bn_bwd(self, L, dout, mask, G, gout, pidx, want_dy, reduced=False):
+        """BN (+ReLU mask) backward.  Returns (dx, dy_or_None); dgamma/dbeta go to gout[g] at the layer's arena offsets.  ``reduced``: the
+        input-gradient convolution that produced ``dout`` has already left the 128-pixel-block sums of dy and dy*x in ``self.stat_ws`` (its
+        fused epilogue, ``_dgrad(bst=...)``), the reduction pass is skipped."""
         n = G * self.chunk
         px = n * L.hout * L.wout
         ppg = self.chunk * L.hout * L.wout
-        n_mblocks = lib.load().fb_bn_bwd_reduce_rows(px, ppg)
         bits = self.masks.get(mask.data_ptr()) if mask is not None else None      # bitmask written by the forward bn_apply
         y = None if bits is not None else mask
-        call("fb_bn_bwd_reduce", dout.data_ptr(), _ptr(y), _ptr(bits), L.x.data_ptr(), self.mean_tab[pidx].data_ptr(), L.invstd.data_ptr(),
-             self.plan.ch_total, L.ch_off, self.stat_ws.data_ptr(), px, L.cout, ppg, self.dtc)
+        if reduced:
+            n_mblocks = px // 128
+        else:
+            n_mblocks = lib.load().fb_bn_bwd_reduce_rows(px, ppg)
+            call("fb_bn_bwd_reduce", dout.data_ptr(), _ptr(y), _ptr(bits), L.x.data_ptr(), self.mean_tab[pidx].data_ptr(), L.invstd.data_ptr(),
+                 self.plan.ch_total, L.ch_off, self.stat_ws.data_ptr(), px, L.cout, ppg, self.dtc)
         call("fb_bn_bwd_finalize", self.stat_ws.data_ptr(), n_mblocks, G, L.cout, float(self.valid * L.hout * L.wout), L.scale.data_ptr(),
              self.mean_tab[pidx].data_ptr(), L.invstd.data_ptr(), self.plan.ch_total, L.ch_off,
-             gout.data_ptr() + 4 * L.g_off, gout.data_ptr() + 4 * L.b_off, self.plan.P, L.coef.data_ptr())
+             gout.data_ptr() + 4 * L.g_off, gout.data_ptr() + 4 * L.b_off, self.plan.P, L.coef.data_ptr(), 1 if reduced else 0)
         dx = self.pool.get((n, L.hout, L.wout, L.cout))
         dy = self.pool.get((n, L.hout, L.wout, L.cout)) if want_dy else None
         call("fb_bn_bwd_apply", dout.data_ptr(), _ptr(y), _ptr(bits), L.x.data_ptr(), L.coef.data_ptr(), dx.data_ptr(), _ptr(dy), px, L.cout, ppg,
@@ -534,9 +576,12 @@ class Engine:
         n = G * self.chunk
         # one K slice and no channel padding: the kernel writes the per-chunk gradients straight into the arena rows
         direct = L.split_k == 1 and L.cin_pad == L.cin_real
+        am_x = am_dy = None
+        if self.f32_split == "f16x2":                # (computed on the main stream, before the event the weight-gradient stream waits for)
+            am_x, am_dy = self._amax(src, n * L.hin * L.win * L.cin_pad), self._amax(dx, n * L.hout * L.wout * L.cout)
         a = lib.WgradArgs(src.data_ptr(), dx.data_ptr(), gout.data_ptr() + 4 * L.w_off if direct else self.slab_ws.data_ptr(), n, L.hin, L.win,
                           L.cin_pad, L.hout, L.wout, L.cout, L.R, L.S, L.stride, L.pad, self.chunk, L.split_k, self.dtc,
-                          self.plan.P if direct else 0)
+                          self.plan.P if direct else 0, am_x, am_dy)
 
         def launch():
             call("fb_conv2d_wgrad", lib.C.byref(a))
@@ -553,18 +598,31 @@ class Engine:
             launch()
             self._wgrad_event = self.wstream.record_event()
 
-    def _dgrad_args(self, L, src, wptr, dst, addend, G, wsets, addend_mode, addend_mask=None):
+    def _dgrad_args(self, L, src, wptr, dst, addend, G, wsets, addend_mode, addend_mask=None, stat=None, bst_x=None, bst_mask=None, amax=(None, None)):
         n = G * self.chunk
-        return lib.ConvArgs(src, wptr, dst, addend, None, n, L.hout, L.wout, L.cout, L.hin, L.win, L.cin_pad,
+        return lib.ConvArgs(src, wptr, dst, addend, stat, n, L.hout, L.wout, L.cout, L.hin, L.win, L.cin_pad,
                             L.R, L.S, L.stride, L.pad, 1, self.chunk if wsets > 1 else n, self.plan.wc_total if wsets > 1 else 0,
-                            addend_mode, self.dtc, addend_mask)
+                            addend_mode, self.dtc, addend_mask, bst_x, bst_mask, amax[0], amax[1])
 
-    def _dgrad(self, L, dx, G, wsets, addend=None, addend_mode=0, addend_mask=None):
+    def _dgrad(self, L, dx, G, wsets, addend=None, addend_mode=0, addend_mask=None, bst=None):
+        """Input gradient of layer L.  ``bst = (Lbn, out)``: the BatchNorm (layer ``Lbn``, output tensor ``out``) whose backward consumes the
+        result; where the kernel can (fb_conv_bwd_stat_supported) it also leaves that BatchNorm's reduction sums in ``self.stat_ws`` and
+        ``self.bst_done`` is set for the following ``_bn_bwd(reduced=...)``: one pass over (dout, x) less."""
         n = G * self.chunk
         out = self.pool.get((n, L.hin, L.win, L.cin_pad))
         wd = self.w_dgrad[1 if wsets > 1 else 0]
         wptr = wd.data_ptr() + wd.element_size() * L.wc_off
-        a = self._dgrad_args(L, dx.data_ptr(), wptr, out.data_ptr(), _ptr(addend), G, wsets, addend_mode, _ptr(addend_mask))
+        self.bst_done = False
+        a = None
+        if bst is not None and self.fuse_bwd_stat:
+            bits = self.masks.get(bst[1].data_ptr())
+            if bits is not None and bst[0].cout == L.cin_pad:
+                a = self._dgrad_args(L, dx.data_ptr(), wptr, out.data_ptr(), _ptr(addend), G, wsets, addend_mode, _ptr(addend_mask),
+                                     self.stat_ws.data_ptr(), bst[0].x.data_ptr(), bits.data_ptr())
+                self.bst_done = bool(lib.load().fb_conv_bwd_stat_supported(lib.C.byref(a)))
+        if not self.bst_done:
+            a = self._dgrad_args(L, dx.data_ptr(), wptr, out.data_ptr(), _ptr(addend), G, wsets, addend_mode, _ptr(addend_mask),
+                                 amax=self._amax_pair(L, dx, n * L.hout * L.wout * L.cout, wsets))
         call("fb_conv2d", lib.C.byref(a))
         return out
 
@@ -588,6 +646,7 @@ class Engine:
         call("fb_head_bwd", self.feat.data_ptr(), self.dlogits.data_ptr(), theta.data_ptr() + 4 * plan.fcw_off, pstride,
              gout.data_ptr() + 4 * plan.fcw_off, gout.data_ptr() + 4 * plan.fcb_off, plan.P, d.data_ptr(), G, self.chunk, hw, plan.feat,
              plan.classes, self.dtc)
+        d_reduced = False                                # has the producer of ``d`` already reduced it for the BatchNorm that consumes it?
         for bi in range(len(plan.blocks) - 1, -1, -1):
             b = plan.blocks[bi]
             a0 = plan.blocks[bi - 1].out if bi > 0 else (self.stem_pooled if plan.stem_pool else self.stem_out)
@@ -598,7 +657,12 @@ class Engine:
             # convolution where fb_conv_masked_addend_supported says so.
             out_bits = self.masks.get(b.out.data_ptr())
             lazy = out_bits is not None and (b.shortcut is not None or self._masked_addend_ok(first, G, wsets))
-            dx, dy = self._bn_bwd(last, d, b.out, G, gout, pidx, want_dy=not lazy)
+            dx, dy = self._bn_bwd(last, d, b.out, G, gout, pidx, want_dy=not lazy, reduced=d_reduced)
+            # the BatchNorm that consumes this block's input gradient: the last one of the previous block, or the stem's
+            if bi > 0:
+                consumer = (plan.blocks[bi - 1].convs[-1], plan.blocks[bi - 1].out)
+            else:
+                consumer = None if plan.stem_pool else (plan.stem, self.stem_out)
             if not lazy:
                 pool.put(d)
             srcs = [a0] + b.mids
@@ -608,9 +672,9 @@ class Engine:
                 self._wgrad(L, srcs[i], cur_dx, G, gout)
                 ev_cur = self._wgrad_event
                 if i > 0:
-                    d_mid = self._dgrad(L, cur_dx, G, wsets)
+                    d_mid = self._dgrad(L, cur_dx, G, wsets, bst=(b.convs[i - 1], b.mids[i - 1]))
                     pool.put(cur_dx, event=ev_cur)
-                    cur_dx, _ = self._bn_bwd(b.convs[i - 1], d_mid, b.mids[i - 1], G, gout, pidx, want_dy=False)
+                    cur_dx, _ = self._bn_bwd(b.convs[i - 1], d_mid, b.mids[i - 1], G, gout, pidx, want_dy=False, reduced=self.bst_done)
                     pool.put(d_mid)
             if b.shortcut is not None:
                 S = b.shortcut
@@ -619,12 +683,13 @@ class Engine:
                 self._wgrad(S, src, dxs, G, gout)
                 d_p = self._dgrad(S, dxs, G, wsets)
                 pool.put(dxs, event=self._wgrad_event)
-                d_in = self._dgrad(first, cur_dx, G, wsets, addend=d_p, addend_mode=2 if b.pooled is not None else 1)
+                d_in = self._dgrad(first, cur_dx, G, wsets, addend=d_p, addend_mode=2 if b.pooled is not None else 1, bst=consumer)
                 pool.put(d_p)
             elif lazy:
-                d_in = self._dgrad(first, cur_dx, G, wsets, addend=d, addend_mode=1, addend_mask=out_bits)
+                d_in = self._dgrad(first, cur_dx, G, wsets, addend=d, addend_mode=1, addend_mask=out_bits, bst=consumer)
             else:
-                d_in = self._dgrad(first, cur_dx, G, wsets, addend=dy, addend_mode=1)
+                d_in = self._dgrad(first, cur_dx, G, wsets, addend=dy, addend_mode=1, bst=consumer)
+            d_reduced = self.bst_done
             pool.put(cur_dx, event=ev_cur)
             pool.put(d if lazy else dy)
             d = d_in
@@ -636,7 +701,7 @@ class Engine:
             call("fb_maxpool3s2_bwd", self.stem_out.data_ptr(), d.data_ptr(), d_r.data_ptr(), n, S.hout, S.wout, 64, self.dtc)
             pool.put(d)
             d = d_r
-        dx, _ = self._bn_bwd(S, d, self.stem_out, G, gout, pidx, want_dy=False)
+        dx, _ = self._bn_bwd(S, d, self.stem_out, G, gout, pidx, want_dy=False, reduced=d_reduced and not plan.stem_pool)
         pool.put(d)
         self._wgrad(S, patches, dx, G, gout)
         pool.put(dx, event=self._wgrad_event)

@@ -9,7 +9,7 @@ import os
 import torch
 
 FB_F32, FB_BF16 = 0, 1
-EXPECTED_ABI = 8          # fb_abi_version() the ctypes structs / signatures below were written for
+EXPECTED_ABI = 9          # fb_abi_version() the ctypes structs / signatures below were written for
 MT_BLOCKS = 1024
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libfbengine.so")
 
@@ -20,21 +20,23 @@ class ConvArgs(C.Structure):
     _fields_ = [("src", c_void_p), ("wgt", c_void_p), ("dst", c_void_p), ("addend", c_void_p), ("stat_partial", c_void_p),
                 ("n_img", c_int), ("Hs", c_int), ("Ws", c_int), ("Cs", c_int), ("Hd", c_int), ("Wd", c_int), ("Cd", c_int),
                 ("R", c_int), ("S", c_int), ("stride", c_int), ("pad", c_int), ("mode", c_int),
-                ("imgs_per_wset", c_int), ("wset_stride", c_i64), ("addend_mode", c_int), ("dtype", c_int), ("addend_mask", c_void_p)]
+                ("imgs_per_wset", c_int), ("wset_stride", c_i64), ("addend_mode", c_int), ("dtype", c_int), ("addend_mask", c_void_p),
+                ("bst_x", c_void_p), ("bst_mask", c_void_p), ("amax_src", c_void_p), ("amax_wgt", c_void_p)]
 
 
 class WgradArgs(C.Structure):
     _fields_ = [("x", c_void_p), ("dy", c_void_p), ("dw_partial", c_void_p),
                 ("n_img", c_int), ("Hs", c_int), ("Ws", c_int), ("Cs", c_int), ("Hd", c_int), ("Wd", c_int), ("Cd", c_int),
                 ("R", c_int), ("S", c_int), ("stride", c_int), ("pad", c_int),
-                ("imgs_per_group", c_int), ("split_k", c_int), ("dtype", c_int), ("group_stride", c_i64)]
+                ("imgs_per_group", c_int), ("split_k", c_int), ("dtype", c_int), ("group_stride", c_i64), ("amax_x", c_void_p), ("amax_dy", c_void_p)]
 
 
 _SIGS = {
     "fb_conv2d": [C.POINTER(ConvArgs), c_void_p],
     "fb_conv2d_wgrad": [C.POINTER(WgradArgs), c_void_p],
+    "fb_absmax": [c_void_p, c_i64, c_int, c_i64, c_void_p, c_void_p],
     "fb_wgrad_reduce": [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
-    "fb_weight_prep": [c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
+    "fb_weight_prep": [c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "fb_bn_fwd_finalize": [c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_i64, c_float, c_void_p, c_void_p, c_int,
                            c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "fb_bn_apply": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_i64, c_int, c_void_p, c_void_p, c_int,
@@ -42,7 +44,7 @@ _SIGS = {
     "fb_bn_running_update": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_void_p, c_int, c_int, c_float, c_void_p],
     "fb_bn_bwd_reduce": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_i64, c_int, c_i64, c_int, c_void_p],
     "fb_bn_bwd_finalize": [c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
-                           c_i64, c_void_p, c_void_p],
+                           c_i64, c_void_p, c_int, c_void_p],
     "fb_bn_bwd_apply": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_void_p],
     "fb_stem_patches": [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                         C.POINTER(c_float), c_int, c_void_p],
@@ -76,7 +78,7 @@ _SIGS = {
     "fb_mt_grad_noise": [c_void_p, c_void_p, c_i64, c_float, c_int, c_void_p],
 }
 EXPORTS = tuple(_SIGS) + ("fb_last_error_string", "fb_abi_version", "fb_profile_enable", "fb_profile_read", "fb_ws_conv_stat_floats",
-                          "fb_ws_wgrad_slab_floats", "fb_ws_bn_partial_floats", "fb_ws_mt_floats", "fb_bn_bwd_reduce_rows", "fb_conv_masked_addend_supported",
+                          "fb_ws_wgrad_slab_floats", "fb_ws_bn_partial_floats", "fb_ws_mt_floats", "fb_bn_bwd_reduce_rows", "fb_conv_masked_addend_supported", "fb_conv_bwd_stat_supported",
                           "fb_bn_apply_can_pool")
 PROF_CLASSES = ("igemm_fwd", "igemm_dgrad", "wgrad")
 
@@ -126,6 +128,7 @@ def load():
         lib.fb_ws_mt_floats.argtypes, lib.fb_ws_mt_floats.restype = [c_int], c_i64
         lib.fb_bn_bwd_reduce_rows.argtypes, lib.fb_bn_bwd_reduce_rows.restype = [c_i64, c_i64], c_int
         lib.fb_conv_masked_addend_supported.argtypes, lib.fb_conv_masked_addend_supported.restype = [C.POINTER(ConvArgs)], c_int
+        lib.fb_conv_bwd_stat_supported.argtypes, lib.fb_conv_bwd_stat_supported.restype = [C.POINTER(ConvArgs)], c_int
         lib.fb_bn_apply_can_pool.argtypes, lib.fb_bn_apply_can_pool.restype = [c_int, c_int, c_i64, c_int], c_int
         _lib = lib
     return _lib
@@ -163,19 +166,21 @@ def dtype_code(dtype):
 # thin tensor-level wrappers (shapes are read from the tensors; NHWC activations)
 # ---------------------------------------------------------------------------------------------------------------------
 def conv2d(src, wgt, dst, R, S, stride, pad, mode, addend=None, addend_mode=0, stat_partial=None, imgs_per_wset=0, wset_stride=0,
-           addend_mask=None):
+           addend_mask=None, bst_x=None, bst_mask=None, amax_src=None, amax_wgt=None):
     n, hs, ws, cs = src.shape
     _, hd, wd, cd = dst.shape
     a = ConvArgs(_ptr(src), _ptr(wgt), _ptr(dst), _ptr(addend), _ptr(stat_partial), n, hs, ws, cs, hd, wd, cd, R, S, stride, pad, mode,
-                 imgs_per_wset, wset_stride, addend_mode, dtype_code(src.dtype), _ptr(addend_mask))
+                 imgs_per_wset, wset_stride, addend_mode, dtype_code(src.dtype), _ptr(addend_mask), _ptr(bst_x), _ptr(bst_mask), _ptr(amax_src), _ptr(amax_wgt))
+    if bst_x is not None and not load().fb_conv_bwd_stat_supported(C.byref(a)):
+        raise EngineError("fb_conv2d: fused BatchNorm-backward reduction not supported for these arguments")
     call("fb_conv2d", C.byref(a))
 
 
-def conv2d_wgrad(x, dy, dw_partial, R, S, stride, pad, imgs_per_group, split_k, group_stride=0):
+def conv2d_wgrad(x, dy, dw_partial, R, S, stride, pad, imgs_per_group, split_k, group_stride=0, amax_x=None, amax_dy=None):
     n, hs, ws, cs = x.shape
     _, hd, wd, cd = dy.shape
     a = WgradArgs(_ptr(x), _ptr(dy), _ptr(dw_partial), n, hs, ws, cs, hd, wd, cd, R, S, stride, pad, imgs_per_group, split_k,
-                  dtype_code(x.dtype), group_stride)
+                  dtype_code(x.dtype), group_stride, _ptr(amax_x), _ptr(amax_dy))
     call("fb_conv2d_wgrad", C.byref(a))
 
 
@@ -183,6 +188,6 @@ def wgrad_reduce(dw_partial, out, out_group_stride, n_groups, split_k, Cd, taps,
     call("fb_wgrad_reduce", _ptr(dw_partial), _ptr(out), out_group_stride, n_groups, split_k, Cd, taps, Cs_pad, Cs_real)
 
 
-def weight_prep(master, wset_stride_in, wset_stride_out, n_wsets, Cout, taps, Cin_real, Cin_pad, w_fwd, w_dgrad, dtype):
+def weight_prep(master, wset_stride_in, wset_stride_out, n_wsets, Cout, taps, Cin_real, Cin_pad, w_fwd, w_dgrad, dtype, amax=None):
     call("fb_weight_prep", _ptr(master), wset_stride_in, wset_stride_out, n_wsets, Cout, taps, Cin_real, Cin_pad, _ptr(w_fwd),
-         _ptr(w_dgrad), dtype_code(dtype))
+         _ptr(w_dgrad), dtype_code(dtype), _ptr(amax))

@@ -52,7 +52,12 @@ int fb_profile_read(double* ms, int64_t* launches, int64_t* dropped);
  * addend (optional, mode 1): dst += addend            (addend_mode 1: same shape)
  *                            dst += 0.25*addend[y/2][x/2] (addend_mode 2: gradient of AvgPool2d(2,2), resnets.py:149)
  * stat_partial (optional, mode 0): [2][ceil(M/128)][Cd] per-128-pixel-block channel sums / sums of squares of the fp32
- *   accumulators, consumed by fb_bn_fwd_finalize (training-mode BatchNorm statistics, resnets.py:71). */
+ *   accumulators, consumed by fb_bn_fwd_finalize (training-mode BatchNorm statistics, resnets.py:71).
+ * bst_x + bst_mask + stat_partial (optional, mode 1): the reduction pass of the BatchNorm backward that CONSUMES dst (autograd's
+ *   native_batch_norm_backward sums behind resnets.py:71,118-121), fused into the epilogue: with g = dst * relu_mask (bst_mask: the bitmask
+ *   fb_bn_apply wrote for that BatchNorm's output, 1 byte per 8 channels) and x = bst_x (that BatchNorm's input, shape of dst),
+ *   stat_partial receives [2][M/128][Cd] per-128-pixel-block sums of g and of g*x (RAW x: fb_bn_bwd_finalize with raw_x = 1
+ *   turns them into dbeta / dgamma).  Ask fb_conv_bwd_stat_supported first; otherwise call fb_bn_bwd_reduce. */
 typedef struct {
     const void* src; const void* wgt; void* dst; const void* addend; float* stat_partial;
     int32_t n_img, Hs, Ws, Cs, Hd, Wd, Cd;
@@ -62,11 +67,22 @@ typedef struct {
     const void* addend_mask;   /* optional (addend_mode 1): ReLU bitmask of the addend as written by fb_bn_apply (1 byte per 16-byte
                                 * vector): dst += addend only where the bit is set, i.e. the masked residual gradient d * (out > 0) of
                                 * reference resnets.py:118-121 / autograd's threshold_backward without a materialised copy */
+    const void* bst_x; const void* bst_mask;   /* optional (mode 1): fused BatchNorm-backward reduction, see above */
+    const float* amax_src; const float* amax_wgt;   /* optional (FB_F32): device scalars holding the largest magnitudes of src and of wgt
+                                * (fb_absmax).  Both set: every fp32 operand enters as two scaled fp16 pieces and a product takes three fp16
+                                * MFMAs (22 significand bits per operand, fp32 accumulation); src is split inside the kernel, wgt must be the
+                                * fp16x2 planes fb_weight_prep(amax) wrote.  Unset: three bf16 pieces, six MFMAs (exact fp32 operands), or
+                                * the exact-f32 MFMA with FB_F32_EXACT=1 */
 } fb_conv_args;
 int fb_conv2d(const fb_conv_args* a, void* stream);
 /* 1 if fb_conv2d implements addend_mask for these arguments (otherwise it fails with FB_ERR_UNSUPPORTED and the caller masks the
  * addend itself: fb_bn_bwd_apply's dy_out) */
 int32_t fb_conv_masked_addend_supported(const fb_conv_args* a);
+/* 1 if fb_conv2d implements the fused BatchNorm-backward reduction (bst_x / bst_mask / stat_partial in mode 1) for these arguments */
+int32_t fb_conv_bwd_stat_supported(const fb_conv_args* a);
+/* out[0] = max |x[s*set_stride + i]| over n_sets slices of n fp32 values (device scalar; one streaming pass, atomic maximum of the bit
+ * patterns): the per-tensor scale source of the fp16x2 split (amax_* above); slices = the per-chunk weight sets of one layer */
+int fb_absmax(const float* x, int64_t n, int32_t n_sets, int64_t set_stride, float* out, void* stream);
 
 /* wgrad: dw[g][split][Cd][R*S][Cs] (fp32 partial slabs) = sum over the pixels of chunk g (split-K slice `split`) of
  * dy[p][Cd] (x) x[src(p,tap)][Cs]        (ATen convolution_backward, weight part).  Deterministic: no atomics.
@@ -79,6 +95,7 @@ typedef struct {
     int32_t R, S, stride, pad;
     int32_t imgs_per_group; int32_t split_k; int32_t dtype;
     int64_t group_stride;
+    const float* amax_x; const float* amax_dy;   /* optional (FB_F32): largest magnitudes of x and dy (fb_absmax): fp16x2 split as in fb_conv_args */
 } fb_wgrad_args;
 int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream);
 
@@ -97,9 +114,12 @@ int64_t fb_ws_mt_floats(int32_t n_groups);
 int fb_wgrad_reduce(const float* dw_partial, float* out, int64_t out_group_stride, int32_t n_groups, int32_t split_k,
                     int32_t Cd, int32_t taps, int32_t Cs_pad, int32_t Cs_real, void* stream);
 /* master fp32 KRSC weights [Cout][taps][Cin_real] of n_wsets sets (wset_stride_in floats apart) ->
- * w_fwd [Cout][taps][Cin_pad] and (optional) w_dgrad [Cin_pad][taps][Cout] in `dtype`, sets wset_stride_out elements apart */
+ * w_fwd [Cout][taps][Cin_pad] and (optional) w_dgrad [Cin_pad][taps][Cout] in `dtype`, sets wset_stride_out elements apart.
+ * amax (optional, FB_F32): device scalar = largest magnitude of these master weights over all sets (fb_absmax): the copies are written
+ * as fp16x2 planes (per 32 values: 32 scaled fp16 high pieces, then 32 low pieces; same size as fp32) -- the weight format fb_conv2d
+ * expects whenever fb_conv_args.amax_wgt is set (to this same scalar) */
 int fb_weight_prep(const float* master, int64_t wset_stride_in, int64_t wset_stride_out, int32_t n_wsets, int32_t Cout, int32_t taps,
-                   int32_t Cin_real, int32_t Cin_pad, void* w_fwd, void* w_dgrad, int32_t dtype, void* stream);
+                   int32_t Cin_real, int32_t Cin_pad, void* w_fwd, void* w_dgrad, int32_t dtype, const float* amax, void* stream);
 
 /* ---------------------------------------------------------------- batch norm ------------------------------------- */
 /* Per (group, channel): mean, biased var from the partial sums; writes mean/var rows into the [n_groups][ch_total]
@@ -134,10 +154,12 @@ int32_t fb_bn_bwd_reduce_rows(int64_t n_pixels, int64_t pixels_per_group);
 int fb_bn_bwd_reduce(const void* dout, const void* y, const void* mask, const void* x, const float* mean_tab, const float* invstd,
                      int32_t ch_total, int32_t ch_off, float* partial, int64_t n_pixels, int32_t C,
                      int64_t pixels_per_group, int32_t dtype, void* stream);
-/* dgamma/dbeta -> gradient arena (per group), coefficients for fb_bn_bwd_apply */
+/* dgamma/dbeta -> gradient arena (per group), coefficients for fb_bn_bwd_apply.  raw_x = 0: partial holds sums of dy and of dy*xhat
+ * (fb_bn_bwd_reduce); raw_x = 1: sums of dy and of dy*x (the fused reduction of fb_conv2d): sum dy*xhat = invstd*(sum dy*x - mean*sum dy),
+ * evaluated in double */
 int fb_bn_bwd_finalize(const float* partial, int32_t n_mblocks, int32_t n_groups, int32_t C, double count,
                        const float* scale, const float* mean_tab, const float* invstd, int32_t ch_total, int32_t ch_off,
-                       float* dgamma, float* dbeta, int64_t grad_group_stride, float* coef, void* stream);
+                       float* dgamma, float* dbeta, int64_t grad_group_stride, float* coef, int32_t raw_x, void* stream);
 /* dx = c_dy*dy + c_x*x + c_0 ; optionally also stores dy (masked gradient, used by the shortcut branch) */
 int fb_bn_bwd_apply(const void* dout, const void* y, const void* mask, const void* x, const float* coef, void* dx, void* dy_out,
                     int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t dtype, void* stream);

@@ -111,6 +111,47 @@ def test_conv_dgrad(dtype, cin, cout, k, stride, hw, n, amode, monkeypatch):
     assert rel(nchw(out.float().cpu()), ref) < tol(dtype)
 
 
+@pytest.mark.parametrize("magnitude", [1.0, 3e-6, 4e4])
+@pytest.mark.parametrize("cin,cout,k,stride,hw,n", [(64, 64, 3, 1, 8, 8), (64, 128, 3, 2, 8, 8), (128, 256, 1, 1, 4, 16), (64, 64, 3, 1, 32, 2),
+                                                   (128, 128, 3, 1, 16, 3), (256, 128, 3, 1, 8, 4), (512, 512, 3, 1, 4, 32), (96, 64, 3, 1, 6, 3)])
+def test_conv_f32_fp16x2_split(cin, cout, k, stride, hw, n, magnitude):
+    """fp32 convolutions on the fp16 matrix pipe (fb_conv_args.amax_src / amax_wgt: two scaled fp16 pieces per operand, three MFMAs per
+    product): forward and input gradient against float64, for activations / gradients of very different magnitudes (the
+    per-tensor power-of-two scales come from fb_absmax; the weights are the fp16x2 planes fb_weight_prep writes).  22 significand bits per
+    operand: the error stays within a small multiple of the six-product bf16 path's, and fb_absmax itself is exact."""
+    lib = _lib()
+    torch.manual_seed(3)
+    pad = k // 2
+    x = (torch.randn(n, cin, hw, hw) * torch.exp(torch.randn(n, cin, hw, hw))) * magnitude     # heavy-tailed, like gradients
+    w = torch.randn(cout, cin, k, k) * 0.1
+    am = torch.zeros(4, device="cuda")
+    xd, master = nhwc(x).cuda(), krsc(w).cuda()
+    lib.call("fb_absmax", xd.data_ptr(), xd.numel(), 1, 0, am.data_ptr())
+    lib.call("fb_absmax", master.data_ptr(), master.numel() // 2, 2, master.numel() // 2, am.data_ptr() + 4)     # two slices = the two halves
+    assert float(am[0]) == float(x.abs().max()) and float(am[1]) == float(w.abs().max())
+    w_plain, wt_plain, w_pl, wt_pl = (torch.zeros(cout * k * k * cin, device="cuda") for _ in range(4))
+    lib.weight_prep(master, 0, 0, 1, cout, k * k, cin, cin, w_plain, wt_plain, torch.float32)
+    lib.weight_prep(master, 0, 0, 1, cout, k * k, cin, cin, w_pl, wt_pl, torch.float32, amax=am[1:])
+    ref = F.conv2d(x.double(), w.double(), None, stride, pad)
+    ho = ref.shape[2]
+    out_h, out_s = (torch.empty(n, ho, ho, cout, device="cuda") for _ in range(2))
+    lib.conv2d(xd, w_pl, out_h, k, k, stride, pad, 0, amax_src=am[0:], amax_wgt=am[1:])
+    lib.conv2d(xd, w_plain, out_s, k, k, stride, pad, 0)
+    eh, es = rel(nchw(out_h.cpu()).double(), ref), rel(nchw(out_s.cpu()).double(), ref)
+    assert eh < 1.5e-6 and eh < 8 * es + 2e-7, (eh, es)
+    if cin % 64 != 0:                               # (input gradients need Cd = cin in multiples of 64)
+        return
+    dy = (torch.randn(n, cout, ho, ho) * torch.exp(torch.randn(n, cout, ho, ho))) * magnitude
+    refd = torch.nn.grad.conv2d_input((n, cin, hw, hw), w.double(), dy.double(), stride, pad)
+    dyd = nhwc(dy).cuda()
+    lib.call("fb_absmax", dyd.data_ptr(), dyd.numel(), 1, 0, am.data_ptr() + 8)
+    dh, ds = (torch.empty(n, hw, hw, cin, device="cuda") for _ in range(2))
+    lib.conv2d(dyd, wt_pl, dh, k, k, stride, pad, 1, amax_src=am[2:], amax_wgt=am[1:])
+    lib.conv2d(dyd, wt_plain, ds, k, k, stride, pad, 1)
+    eh, es = rel(nchw(dh.cpu()).double(), refd), rel(nchw(ds.cpu()).double(), refd)
+    assert eh < 1.5e-6 and eh < 8 * es + 2e-7, (eh, es)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cin,cout,k,stride,hw,ipg,groups,split", [(64, 64, 3, 1, 8, 8, 2, 1), (64, 64, 3, 1, 8, 8, 2, 3),
                                                                   (64, 128, 3, 2, 8, 8, 1, 2), (256, 256, 3, 1, 4, 16, 2, 1),
@@ -148,6 +189,39 @@ def test_conv_wgrad(dtype, cin, cout, k, stride, hw, ipg, groups, split):
         assert bool(torch.isnan(arena[:, :8]).all()) and bool(torch.isnan(arena[:, 8 + cout * k * k * cin:]).all())
 
 
+@pytest.mark.parametrize("magnitude", [1.0, 2e-6])
+@pytest.mark.parametrize("cin,cout,k,stride,hw,ipg,groups,split", [(64, 64, 3, 1, 8, 8, 2, 3), (64, 128, 3, 2, 8, 8, 1, 2), (256, 256, 3, 1, 4, 16, 2, 1),
+                                                                  (128, 256, 1, 1, 4, 16, 1, 2), (32, 64, 1, 1, 8, 4, 2, 1), (64, 64, 3, 1, 32, 4, 2, 2),
+                                                                  (128, 64, 3, 1, 16, 4, 2, 4), (64, 64, 3, 1, 16, 10, 2, 3)])
+def test_conv_wgrad_f32_fp16x2_split(cin, cout, k, stride, hw, ipg, groups, split, magnitude):
+    """Weight gradients of fp32 tensors on the fp16 matrix pipe (fb_wgrad_args.amax_x / amax_dy): two scaled fp16 planes per operand, three
+    MFMAs per product; against float64, with gradients of realistic (tiny) magnitude, next to the six-product bf16 path."""
+    lib = _lib()
+    torch.manual_seed(4)
+    pad = k // 2
+    n = ipg * groups
+    ho = (hw + 2 * pad - k) // stride + 1
+    x = torch.randn(n, cin, hw, hw) * torch.exp(0.5 * torch.randn(n, cin, hw, hw))
+    dy = torch.randn(n, cout, ho, ho) * torch.exp(torch.randn(n, cout, ho, ho)) * magnitude
+    xd, dyd = nhwc(x).cuda(), nhwc(dy).cuda()
+    am = torch.zeros(2, device="cuda")
+    lib.call("fb_absmax", xd.data_ptr(), xd.numel(), 1, 0, am.data_ptr())
+    lib.call("fb_absmax", dyd.data_ptr(), dyd.numel(), 1, 0, am.data_ptr() + 4)
+    errs = []
+    for amax in ((am[0:], am[1:]), (None, None)):
+        slab = torch.full((groups, split, cout, k * k, cin), float("nan"), device="cuda")
+        lib.conv2d_wgrad(xd, dyd, slab, k, k, stride, pad, ipg, split, amax_x=amax[0], amax_dy=amax[1])
+        out = torch.zeros(groups, cout * k * k * cin, device="cuda")
+        lib.wgrad_reduce(slab, out, out.shape[1], groups, split, cout, k * k, cin, cin)
+        e = 0.0
+        for g in range(groups):
+            sl = slice(g * ipg, (g + 1) * ipg)
+            ref = torch.nn.grad.conv2d_weight(x[sl].double(), (cout, cin, k, k), dy[sl].double(), stride, pad)
+            e = max(e, rel(out[g].view(cout, k, k, cin).permute(0, 3, 1, 2).cpu().double(), ref))
+        errs.append(e)
+    assert errs[0] < 1.5e-6 and errs[0] < 8 * errs[1] + 2e-7, errs
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_weight_prep(dtype):
     lib = _lib()
@@ -157,7 +231,7 @@ def test_weight_prep(dtype):
     wf = torch.zeros(sets, co * taps * cip + 64, dtype=dtype, device="cuda")
     wd = torch.zeros_like(wf)
     lib.call("fb_weight_prep", master.data_ptr() + 4 * 100, master.shape[1], wf.shape[1], sets, co, taps, ci, cip, wf.data_ptr(),
-             wd.data_ptr(), lib.dtype_code(dtype))
+             wd.data_ptr(), lib.dtype_code(dtype), None)
     for s in range(sets):
         m = master[s, 100:100 + co * taps * ci].view(co, taps, ci).cpu()
         ref = torch.zeros(co, taps, cip)
@@ -228,7 +302,7 @@ def test_batchnorm_fwd_bwd(dtype, C, hw, ipg, groups):
     gout = torch.zeros(groups, 2 * C + 64, device="cuda")
     coef = torch.zeros(groups, C, 3, device="cuda")
     lib.call("fb_bn_bwd_finalize", part2.data_ptr(), lib.load().fb_bn_bwd_reduce_rows(px, ppg), groups, C, float(ppg), scale.data_ptr(), mean_tab.data_ptr(), invstd.data_ptr(),
-             ch_total, ch_off, gout.data_ptr(), gout.data_ptr() + 4 * C, gout.shape[1], coef.data_ptr())
+             ch_total, ch_off, gout.data_ptr(), gout.data_ptr() + 4 * C, gout.shape[1], coef.data_ptr(), 0)
     dx = torch.empty_like(xd)
     dy_out = torch.empty_like(xd)
     lib.call("fb_bn_bwd_apply", doutd.data_ptr(), yd.data_ptr(), None, xd.data_ptr(), coef.data_ptr(), dx.data_ptr(), dy_out.data_ptr(), px, C, ppg,
@@ -503,6 +577,52 @@ def test_conv_masked_addend_equals_materialised_mask():
     d2 = torch.randn(n, 16, 16, 128, device="cuda").bfloat16()
     with pytest.raises(lib.EngineError):                                       # 128 channels: not implemented, and loudly so
         lib.conv2d(dy2, w2, torch.empty_like(d2), 3, 3, 1, 1, 1, addend=d2, addend_mode=1, addend_mask=bits)
+
+
+@pytest.mark.parametrize("C,hw,amode", [(64, 32, 0), (64, 32, 1), (64, 32, 3), (128, 16, 0), (128, 16, 1), (256, 8, 0), (256, 8, 1), (512, 4, 0),
+                                         (512, 4, 1)])
+def test_conv_dgrad_fused_bn_backward_reduction(C, hw, amode):
+    """The BatchNorm-backward reduction fused into the input-gradient epilogues (fb_conv_args.bst_x / bst_mask): the gradient
+    itself is bit-identical to the plain launch, and dgamma / dbeta / the fb_bn_bwd_apply coefficients obtained from the fused 128-pixel
+    sums of (g, g*x) equal those of the separate fb_bn_bwd_reduce pass over the stored gradient (amode 1: + addend, 3: + masked addend)."""
+    lib = _lib()
+    torch.manual_seed(C + hw + amode)
+    ipg, groups = 128, 3
+    n = ipg * groups
+    dt = torch.bfloat16
+    dy = torch.randn(n, hw, hw, C, device="cuda").to(dt)
+    wt = (torch.randn(C, 9, C, device="cuda") * 0.05).to(dt)
+    x = (torch.randn(n, hw, hw, C, device="cuda") * 1.5 + 0.7).to(dt)                      # input of the consuming BatchNorm
+    bits = torch.randint(0, 256, (n * hw * hw * C // 8,), device="cuda", dtype=torch.uint8)  # its ReLU bitmask
+    addend = torch.randn(n, hw, hw, C, device="cuda").to(dt) if amode else None
+    amask = torch.randint(0, 256, (n * hw * hw * C // 8,), device="cuda", dtype=torch.uint8) if amode == 3 else None
+    px, ppg = n * hw * hw, ipg * hw * hw
+    plain, fused = torch.empty_like(dy), torch.empty_like(dy)
+    part_f = torch.zeros(2, px // 128, C, device="cuda")
+    lib.conv2d(dy, wt, plain, 3, 3, 1, 1, 1, addend=addend, addend_mode=1 if amode else 0, addend_mask=amask)
+    lib.conv2d(dy, wt, fused, 3, 3, 1, 1, 1, addend=addend, addend_mode=1 if amode else 0, addend_mask=amask, stat_partial=part_f, bst_x=x, bst_mask=bits)
+    assert torch.equal(plain, fused)
+    mean_tab = x.float().reshape(groups, -1, C).mean(1).contiguous()
+    invstd = (1.0 / (x.float().reshape(groups, -1, C).var(1, unbiased=False) + 1e-5).sqrt()).contiguous()
+    scale = torch.rand(groups, C, device="cuda") + 0.5
+    rows = lib.load().fb_bn_bwd_reduce_rows(px, ppg)
+    part_s = torch.zeros(2, rows, C, device="cuda")
+    lib.call("fb_bn_bwd_reduce", plain.data_ptr(), None, bits.data_ptr(), x.data_ptr(), mean_tab.data_ptr(), invstd.data_ptr(), C, 0, part_s.data_ptr(), px, C,
+             ppg, lib.dtype_code(dt))
+    outs = []
+    for part, nrows, raw in ((part_s, rows, 0), (part_f, px // 128, 1)):
+        gout = torch.zeros(groups, 2 * C, device="cuda")
+        coef = torch.zeros(groups, C, 3, device="cuda")
+        lib.call("fb_bn_bwd_finalize", part.data_ptr(), nrows, groups, C, float(ppg), scale.data_ptr(), mean_tab.data_ptr(), invstd.data_ptr(), C, 0,
+                 gout.data_ptr(), gout.data_ptr() + 4 * C, 2 * C, coef.data_ptr(), raw)
+        outs.append((gout.double().cpu(), coef.double().cpu()))
+    # float64 reference of the sums from the stored gradient
+    g = plain.double() * ((bits.view(-1, 1).to(torch.int32) >> torch.arange(8, device="cuda")) & 1).reshape(plain.shape).double()
+    xhat = (x.double().reshape(groups, -1, C) - mean_tab.double()[:, None]) * invstd.double()[:, None]
+    dbeta, dgamma = g.reshape(groups, -1, C).sum(1).cpu(), (g.reshape(groups, -1, C) * xhat).sum(1).cpu()
+    for gout, coef in outs:
+        assert rel(gout[:, :C], dgamma) < 2e-5 and rel(gout[:, C:], dbeta) < 2e-5
+    assert rel(outs[1][1], outs[0][1]) < 2e-5
 
 
 def test_engine_per_tensor_weight_decay_matches_torch_sgd():

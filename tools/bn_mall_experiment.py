@@ -46,7 +46,7 @@ def main():
                          invstd.data_ptr() + 4 * g0 * C, C, 0, part.data_ptr(), p, C, ppg, dt)
                 lib.call("fb_bn_bwd_finalize", part.data_ptr(), rows, g, C, float(ppg), scale.data_ptr() + 4 * g0 * C, mean.data_ptr() + 4 * g0 * C,
                          invstd.data_ptr() + 4 * g0 * C, C, 0, gout.data_ptr() + 4 * g0 * 2 * C, gout.data_ptr() + 4 * (g0 * 2 * C + C), 2 * C,
-                         coef.data_ptr() + 4 * g0 * C * 3)
+                         coef.data_ptr() + 4 * g0 * C * 3, 0)
                 lib.call("fb_bn_bwd_apply", dout.data_ptr() + o, None, mask.data_ptr() + o // 16, x.data_ptr() + o, coef.data_ptr() + 4 * g0 * C * 3,
                          dx.data_ptr() + o, None, p, C, ppg, dt)
 
