@@ -125,13 +125,44 @@ __device__ __forceinline__ void st_stream(uint4* p, const uint4& v) {
     __builtin_nontemporal_store((bn_u32x4_t){v.x, v.y, v.z, v.w}, (bn_u32x4_t*)p);
 }
 
+// Largest magnitude of what a streaming kernel wrote (scale source of the fp16x2 convolutions, fb_absmax semantics; the caller zeroes the
+// slot): wave maximum, then one atomic per wave ONLY if it would raise the value -- after the first few workgroups almost none does
+// Two levels, no atomics: every workgroup stores the maximum of its run to ws[group][run] (an atomic on one address per workgroup -- or
+// even an agent-scope load of it -- serialises on this multi-die part: 2.3x the kernel time measured), amax_finish_kernel folds the
+// runs of a group.
+__device__ __forceinline__ void amax_commit(float* ws, float am) {
+    __shared__ float red[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = am;
+    __syncthreads();
+    if (threadIdx.x == 0) ws[(long long)blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__global__ __launch_bounds__(256) void amax_finish_kernel(const float* __restrict__ ws, int runs, float* __restrict__ out) {
+    float m = 0.f;
+    for (int i = threadIdx.x; i < runs; i += 256) m = fmaxf(m, ws[(long long)blockIdx.x * runs + i]);
+    __shared__ float red[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+// floats of scratch fb_bn_apply / fb_bn_bwd_apply need for amax_out
+extern "C" int64_t fb_ws_bn_amax_floats(int64_t n_pixels, int32_t C, int64_t pixels_per_group) {
+    const long long vpg = pixels_per_group * (C / 4);
+    const long long groups = (n_pixels + pixels_per_group - 1) / pixels_per_group;
+    return ((vpg + 511) / 512) * groups;
+}
+
 template <typename T, int RES>
 __global__ __launch_bounds__(256) void bn_apply_span_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, const uint4* __restrict__ res,
                                                             const float* __restrict__ rscale, const float* __restrict__ rshift, long long n_vec,
                                                             int cvec, long long vec_per_group, int C, int relu, unsigned char* __restrict__ mask_out,
-                                                            int span, long long valid_vec, uint4* __restrict__ pool_out) {
+                                                            int span, long long valid_vec, uint4* __restrict__ pool_out, float* __restrict__ amax) {
     constexpr int V = ET<T>::VEC;
+    float am = 0.f;
     const long long g = blockIdx.y, base = g * vec_per_group;
     const long long lim = n_vec - base < vec_per_group ? n_vec - base : vec_per_group;
     const long long lo = (long long)blockIdx.x * span;
@@ -158,6 +189,10 @@ __global__ __launch_bounds__(256) void bn_apply_span_kernel(const uint4* __restr
         }
         uint4 packed = ET<T>::pack(o);
         if (i >= valid_vec) { packed = make_uint4(0, 0, 0, 0); m = 0; }      // padding pixels of a ragged statistics group
+        else if (amax) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) am = fmaxf(am, fabsf(o[k]));
+        }
         st_stream(y + i, packed);
         if (mask_out) mask_out[i] = (unsigned char)m;
         return packed;
@@ -187,6 +222,7 @@ __global__ __launch_bounds__(256) void bn_apply_span_kernel(const uint4* __restr
         }
     }
     for (; i < hi; i += 256) { uint4 rr = make_uint4(0, 0, 0, 0); if (RES) rr = res[i]; one(x[i], rr, i); }
+    if (amax) amax_commit(amax, am);                          // (uniform branch) one value per run; folded per statistics group afterwards
 }
 
 // run length of a span kernel: 512 vectors (one trip of two vectors per thread).  Alone on the device longer runs are a little faster
@@ -195,24 +231,26 @@ __global__ __launch_bounds__(256) void bn_apply_span_kernel(const uint4* __restr
 static inline int bn_span(long long) { return 512; }
 
 template <typename T>
-static void launch_bn_apply(const void* x, void* y, const float* scale, const float* shift, const void* res, const float* rscale,
+static bool launch_bn_apply(const void* x, void* y, const float* scale, const float* shift, const void* res, const float* rscale,
                             const float* rshift, int64_t n_pixels, int C, int64_t ppg, int64_t valid_ppg, int relu, unsigned char* mask_out, uint4* pool_out,
-                            hipStream_t st) {
+                            float* amax_out, float* amax_ws, hipStream_t st) {
     const int cvec = C / ET<T>::VEC;
     const long long n_vec = n_pixels * cvec, vpg = ppg * cvec;
     const long long valid_vec = (valid_ppg > 0 && valid_ppg < ppg ? valid_ppg : ppg) * cvec;
     if (256 % cvec == 0 && vpg > 0) {
         const int span = bn_span(n_vec);
         const dim3 grid((unsigned)((vpg + span - 1) / span), (unsigned)((n_vec + vpg - 1) / vpg));
-        if (!res) hipLaunchKernelGGL((bn_apply_span_kernel<T, 0>), grid, dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, nullptr, nullptr, nullptr, n_vec, cvec, vpg, C, relu, mask_out, span, valid_vec, pool_out);
-        else if (!rscale) hipLaunchKernelGGL((bn_apply_span_kernel<T, 1>), grid, dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, nullptr, nullptr, n_vec, cvec, vpg, C, relu, mask_out, span, valid_vec, pool_out);
-        else hipLaunchKernelGGL((bn_apply_span_kernel<T, 2>), grid, dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, rscale, rshift, n_vec, cvec, vpg, C, relu, mask_out, span, valid_vec, pool_out);
-        return;
+        if (!res) hipLaunchKernelGGL((bn_apply_span_kernel<T, 0>), grid, dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, nullptr, nullptr, nullptr, n_vec, cvec, vpg, C, relu, mask_out, span, valid_vec, pool_out, amax_out ? amax_ws : nullptr);
+        else if (!rscale) hipLaunchKernelGGL((bn_apply_span_kernel<T, 1>), grid, dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, nullptr, nullptr, n_vec, cvec, vpg, C, relu, mask_out, span, valid_vec, pool_out, amax_out ? amax_ws : nullptr);
+        else hipLaunchKernelGGL((bn_apply_span_kernel<T, 2>), grid, dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, rscale, rshift, n_vec, cvec, vpg, C, relu, mask_out, span, valid_vec, pool_out, amax_out ? amax_ws : nullptr);
+        if (amax_out) hipLaunchKernelGGL(amax_finish_kernel, dim3(grid.y), dim3(256), 0, st, amax_ws, (int)grid.x, amax_out);
+        return true;
     }
     const int blocks = (int)((n_vec + 255) / 256 < 8192 ? (n_vec + 255) / 256 : 8192);
     if (!res) hipLaunchKernelGGL((bn_apply_kernel<T, 0>), dim3(blocks), dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, nullptr, nullptr, nullptr, n_vec, cvec, vpg, C, relu, mask_out, valid_vec);
     else if (!rscale) hipLaunchKernelGGL((bn_apply_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, nullptr, nullptr, n_vec, cvec, vpg, C, relu, mask_out, valid_vec);
     else hipLaunchKernelGGL((bn_apply_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, (const uint4*)x, (uint4*)y, scale, shift, (const uint4*)res, rscale, rshift, n_vec, cvec, vpg, C, relu, mask_out, valid_vec);
+    return false;                                           // (the grid-stride form does not track the largest magnitude)
 }
 
 // fused AvgPool2d(2,2) output of fb_bn_apply: a 512-vector run of the span kernel must be exactly two image rows
@@ -222,14 +260,18 @@ extern "C" int32_t fb_bn_apply_can_pool(int32_t C, int32_t W, int64_t pixels_per
 
 extern "C" int fb_bn_apply(const void* x, void* y, const float* scale, const float* shift, const void* res, const float* rscale,
                            const float* rshift, int64_t n_pixels, int32_t C, int64_t pixels_per_group, int64_t valid_pixels_per_group,
-                           int32_t relu, void* mask_out, void* pool_out, int32_t pool_W, int32_t dtype, void* stream) {
+                           int32_t relu, void* mask_out, void* pool_out, int32_t pool_W, int32_t dtype, float* amax_out, float* amax_ws, void* stream) {
     if (!x || !y || !scale || !shift) FB_FAIL(FB_ERR_ARG, "fb_bn_apply: null pointer");
+    if (amax_out && (dtype != FB_F32 || !amax_ws)) FB_FAIL(FB_ERR_ARG, "fb_bn_apply: amax_out is for fp32 tensors and needs amax_ws (fb_ws_bn_amax_floats)");
+    const int64_t n_groups = (n_pixels + pixels_per_group - 1) / pixels_per_group;
     if (C % 8 != 0) FB_FAIL(FB_ERR_SHAPE, "fb_bn_apply: C=%d must be a multiple of 8", C);
     if (pool_out && !fb_bn_apply_can_pool(C, pool_W, pixels_per_group, dtype))
         FB_FAIL(FB_ERR_UNSUPPORTED, "fb_bn_apply: fused 2x2 average pooling needs bf16, W * C == 2048 and whole row pairs per group (C=%d W=%d)", C, pool_W);
-    if (dtype == FB_F32) launch_bn_apply<float>(x, y, scale, shift, res, rscale, rshift, n_pixels, C, pixels_per_group, valid_pixels_per_group, relu, (unsigned char*)mask_out, (uint4*)pool_out, (hipStream_t)stream);
-    else launch_bn_apply<bf16_tag>(x, y, scale, shift, res, rscale, rshift, n_pixels, C, pixels_per_group, valid_pixels_per_group, relu, (unsigned char*)mask_out, (uint4*)pool_out, (hipStream_t)stream);
+    bool tracked = false;
+    if (dtype == FB_F32) tracked = launch_bn_apply<float>(x, y, scale, shift, res, rscale, rshift, n_pixels, C, pixels_per_group, valid_pixels_per_group, relu, (unsigned char*)mask_out, (uint4*)pool_out, amax_out, amax_ws, (hipStream_t)stream);
+    else launch_bn_apply<bf16_tag>(x, y, scale, shift, res, rscale, rshift, n_pixels, C, pixels_per_group, valid_pixels_per_group, relu, (unsigned char*)mask_out, (uint4*)pool_out, nullptr, nullptr, (hipStream_t)stream);
     FB_CHECK_LAUNCH("fb_bn_apply");
+    if (amax_out && !tracked) return fb_absmax((const float*)y, pixels_per_group * C, (int32_t)n_groups, pixels_per_group * C, 1, amax_out, stream);
     return FB_OK;
 }
 
@@ -450,8 +492,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_span_kernel(const uint4* __restrict__ dout, const uint4* __restrict__ y,
                                                                 const unsigned char* __restrict__ mask, const uint4* __restrict__ x,
                                                                 const float* __restrict__ coef, uint4* __restrict__ dx, uint4* __restrict__ dy_out,
-                                                                long long n_vec, int cvec, long long vec_per_group, int C, int span) {
+                                                                long long n_vec, int cvec, long long vec_per_group, int C, int span, float* __restrict__ amax) {
     constexpr int V = ET<T>::VEC;
+    float am = 0.f;
     const long long g = blockIdx.y, base = g * vec_per_group;
     const long long lim = n_vec - base < vec_per_group ? n_vec - base : vec_per_group;
     const long long lo = (long long)blockIdx.x * span;
@@ -471,6 +514,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_span_kernel(const uint4* __r
             const float dy = ((mk >> k) & 1u) ? d[k] : 0.f;
             dyv[k] = dy;
             o[k] = cf[3 * k] * dy + cf[3 * k + 1] * xv[k] + cf[3 * k + 2];
+        }
+        if (amax) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) am = fmaxf(am, fabsf(o[k]));
         }
         st_stream(dx + i, ET<T>::pack(o));
         if (dy_out) st_stream(dy_out + i, ET<T>::pack(dyv));
@@ -495,11 +542,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_span_kernel(const uint4* __r
         for (int u = 0; u < BN_SPAN_U; ++u) one(dr[u], xr[u], mk[u], i + u * 256);
     }
     for (; i < hi; i += 256) one(dout[i], x[i], mask_at(i), i);
+    if (amax) amax_commit(amax, am);                          // (uniform branch) one value per run; folded per statistics group afterwards
 }
 
 extern "C" int fb_bn_bwd_apply(const void* dout, const void* y, const void* mask, const void* x, const float* coef, void* dx, void* dy_out,
-                               int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t dtype, void* stream) {
+                               int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t dtype, float* amax_out, float* amax_ws, void* stream) {
     if (!dout || !x || !coef || !dx) FB_FAIL(FB_ERR_ARG, "fb_bn_bwd_apply: null pointer");
+    if (amax_out && (dtype != FB_F32 || !amax_ws)) FB_FAIL(FB_ERR_ARG, "fb_bn_bwd_apply: amax_out is for fp32 tensors and needs amax_ws (fb_ws_bn_amax_floats)");
+    const int64_t n_groups = (n_pixels + pixels_per_group - 1) / pixels_per_group;
     const int V = dtype == FB_F32 ? 4 : 8;
     const int cvec = C / V;
     const long long n_vec = n_pixels * cvec, vpg = pixels_per_group * cvec;
@@ -508,10 +558,11 @@ extern "C" int fb_bn_bwd_apply(const void* dout, const void* y, const void* mask
         const dim3 grid((unsigned)((vpg + span - 1) / span), (unsigned)((n_vec + vpg - 1) / vpg));
         if (dtype == FB_F32)
             hipLaunchKernelGGL((bn_bwd_apply_span_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const uint4*)dout, (const uint4*)y,
-                               (const unsigned char*)mask, (const uint4*)x, coef, (uint4*)dx, (uint4*)dy_out, n_vec, cvec, vpg, C, span);
+                               (const unsigned char*)mask, (const uint4*)x, coef, (uint4*)dx, (uint4*)dy_out, n_vec, cvec, vpg, C, span, amax_out ? amax_ws : nullptr);
         else
             hipLaunchKernelGGL((bn_bwd_apply_span_kernel<bf16_tag>), grid, dim3(256), 0, (hipStream_t)stream, (const uint4*)dout, (const uint4*)y,
-                               (const unsigned char*)mask, (const uint4*)x, coef, (uint4*)dx, (uint4*)dy_out, n_vec, cvec, vpg, C, span);
+                               (const unsigned char*)mask, (const uint4*)x, coef, (uint4*)dx, (uint4*)dy_out, n_vec, cvec, vpg, C, span, nullptr);
+        if (amax_out) hipLaunchKernelGGL(amax_finish_kernel, dim3(grid.y), dim3(256), 0, (hipStream_t)stream, amax_ws, (int)grid.x, amax_out);
         FB_CHECK_LAUNCH("fb_bn_bwd_apply");
         return FB_OK;
     }
@@ -523,5 +574,6 @@ extern "C" int fb_bn_bwd_apply(const void* dout, const void* y, const void* mask
         hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_tag>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)dout, (const uint4*)y,
                            (const unsigned char*)mask, (const uint4*)x, coef, (uint4*)dx, (uint4*)dy_out, n_vec, cvec, vpg, C);
     FB_CHECK_LAUNCH("fb_bn_bwd_apply");
+    if (amax_out) return fb_absmax((const float*)dx, pixels_per_group * C, (int32_t)n_groups, pixels_per_group * C, 1, amax_out, stream);
     return FB_OK;
 }

@@ -23,7 +23,8 @@
 struct Halo4Params {
     const char* src; const char* wgt; char* dst; const char* addend; float* stat;
     const char* bst_x; const unsigned char* bst_mask;       // BST: input and ReLU bitmask of the BatchNorm whose backward consumes dst
-    const float* amax_src; const float* amax_wgt;           // f32h (fp16x2 split): largest magnitudes of the operand tensors
+    const float* amax_src; const float* amax_wgt;           // f32h (fp16x2 split): largest magnitudes per chunk of src / per weight set
+    int amax_imgs;
     int n_img, H, Cs, Cd, mode;
     int imgs_per_wset; long long wset_stride_bytes;
     int addend_mode, n_mblocks, n_ct, n_tiles;
@@ -203,11 +204,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
     // set by the per-CU load/store pipeline, not by idle workgroups.)
     int L = h4_xcd_remap(blockIdx.x, NB);
     if (L >= p.n_tiles) return;
-    float hs_src = 1.f, hs_wgt = 1.f, hs_inv = 1.f;         // f32h: per-tensor power-of-two scales
-    if constexpr (is_hsplit<T>::value) {
-        hs_src = fb_pow2_scale(*p.amax_src); hs_wgt = fb_pow2_scale(*p.amax_wgt);
-        hs_inv = 1.f / (hs_src * hs_wgt);
-    }
+    float hs_src = 1.f, hs_inv = 1.f;                       // f32h: power-of-two scales of the tile's chunk and weight set
+    auto scales_of = [&](const H4Tile& t) {
+        if constexpr (is_hsplit<T>::value) {
+            hs_src = fb_pow2_scale(p.amax_src[t.n0 / p.amax_imgs]);
+            hs_inv = 1.f / (hs_src * fb_pow2_scale(p.amax_wgt[h4_div(t.n0, p.magic_wset)]));
+        }
+    };
     H4Tile cur = decode(L);
     halo_issue(cur, 0);
     wt_issue(0, cur, 0, tap_of(0));
@@ -222,6 +225,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
         const bool has_next = Ln < p.n_tiles;
         H4Tile nxt = cur;
         if (has_next) nxt = decode(Ln);
+        scales_of(cur);
         h4_wait_vmcnt<0>();                                // halo slice 0 + weight taps 0, 1 (and the previous tile's stores)
         __builtin_amdgcn_s_barrier();
         H4_STAMP(2);
@@ -493,7 +497,7 @@ int fb_try_conv3x3_halo4(const fb_conv_args* a, hipStream_t st) {
     p.src = (const char*)a->src; p.wgt = (const char*)a->wgt; p.dst = (char*)a->dst; p.addend = (const char*)a->addend;
     p.stat = a->stat_partial;
     p.bst_x = (const char*)a->bst_x; p.bst_mask = (const unsigned char*)a->bst_mask;
-    p.amax_src = a->amax_src; p.amax_wgt = a->amax_wgt;
+    p.amax_src = a->amax_src; p.amax_wgt = a->amax_wgt; p.amax_imgs = a->amax_imgs > 0 ? a->amax_imgs : a->n_img;
     p.n_img = a->n_img; p.H = a->Hs; p.Cs = a->Cs; p.Cd = a->Cd; p.mode = a->mode;
     p.imgs_per_wset = imgs_per_wset;
     p.wset_stride_bytes = a->wset_stride * EB;

@@ -254,6 +254,7 @@ extern "C" int fb_conv2d(const fb_conv_args* a, void* stream) {
     p.addend_mode = a->addend ? a->addend_mode : 0;
     p.amax_src = a->dtype == FB_F32 ? a->amax_src : nullptr; p.amax_wgt = a->dtype == FB_F32 ? a->amax_wgt : nullptr;
     if ((p.amax_src == nullptr) != (p.amax_wgt == nullptr)) FB_FAIL(FB_ERR_ARG, "fb_conv2d: amax_src and amax_wgt go together");
+    p.amax_imgs = a->amax_imgs > 0 ? a->amax_imgs : a->n_img;
     int classes = 1;
     if (a->mode == 0) {
         if (a->Hd != (a->Hs + 2 * a->pad - a->R) / a->stride + 1 || a->Wd != (a->Ws + 2 * a->pad - a->S) / a->stride + 1)

@@ -147,7 +147,8 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(const ConvParams p, 
         for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     float hs_src = 1.f, hs_wgt = 1.f, hs_inv = 1.f;         // f32h: per-tensor power-of-two scales
     if constexpr (is_hsplit<T>::value) {
-        hs_src = fb_pow2_scale(*p.amax_src); hs_wgt = fb_pow2_scale(*p.amax_wgt);
+        const int img0 = (mblk * 128) / qHW;                 // (a 128-pixel block never straddles two chunks)
+        hs_src = fb_pow2_scale(p.amax_src[img0 / p.amax_imgs]); hs_wgt = fb_pow2_scale(p.amax_wgt[wset]);
         hs_inv = 1.f / (hs_src * hs_wgt);
     }
 

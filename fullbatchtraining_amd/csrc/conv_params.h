@@ -8,7 +8,8 @@ struct ConvParams {
     int imgs_per_wset; long long wset_stride_bytes;
     int addend_mode, n_mblocks;
     const char* zeros;   // >= 128 bytes of zeros in device memory (source of padding rows for LDS-direct loads)
-    const float* amax_src; const float* amax_wgt;   // f32h (fp16x2 split): largest magnitudes of the two operand tensors (fb_absmax)
+    const float* amax_src; const float* amax_wgt;   // f32h (fp16x2 split): largest magnitudes per chunk of src / per weight set (fb_absmax)
+    int amax_imgs;                                   // images per entry of amax_src
 };
 const void* fb_zero_page();                                                   // runtime.cpp
 int fb_launch_igemm_glds(const ConvParams& p, int classes, int dtype, hipStream_t st);   // conv_igemm_glds.hip

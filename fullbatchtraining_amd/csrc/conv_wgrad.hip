@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     char* tileA = lds;
     char* tileB = lds + (SPLIT ? NPL * PLANE_A : KPX * ROW_A);
     float hs_a = 1.f, hs_b = 1.f;
-    if constexpr (HSPLIT) { hs_a = fb_pow2_scale(*p.amax_dy); hs_b = fb_pow2_scale(*p.amax_x); }
+    if constexpr (HSPLIT) { hs_a = fb_pow2_scale(p.amax_dy[blockIdx.z / p.split_k]); hs_b = fb_pow2_scale(p.amax_x[blockIdx.z / p.split_k]); }   // per chunk
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
@@ -342,7 +342,7 @@ __global__ void weight_prep_planes_kernel(const float* __restrict__ master, long
     const int ci = (int)(idx % Cin_pad); const long long rt = idx / Cin_pad; const int t = (int)(rt % taps); const int co = (int)(rt / taps);
     float v = 0.f;
     if (ci < Cin_real) v = master[(long long)ws * wset_stride_in + ((long long)co * taps + t) * Cin_real + ci];
-    v *= fb_pow2_scale(*amax);
+    v *= fb_pow2_scale(amax[ws]);
     const _Float16 h = (_Float16)v, l = (_Float16)(v - (float)h);
     _Float16* f = w_fwd + ((long long)ws * wset_stride_out + rt * Cin_pad) * 2 + planes_slot(ci);
     f[0] = h; f[32] = l;

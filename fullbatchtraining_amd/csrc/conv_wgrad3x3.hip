@@ -70,6 +70,17 @@ template <> __device__ __forceinline__ void frag_halo<bf16_tag, 16>(const char* 
                         ((unsigned)(unsigned short)hi[0]) | ((unsigned)(unsigned short)hi[1] << 16),
                         ((unsigned)(unsigned short)hi[2]) | ((unsigned)(unsigned short)hi[3] << 16));
 }
+template <> __device__ __forceinline__ void frag_halo<bf16_tag, 8>(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) {
+    const int t = lane & 15, g = lane >> 4;
+    const int p = pb + g * 8 + (t >> 2);                      // a lane group's 8 pixels = one whole row of an 8x8 image
+    const char* a0 = tile + ((p / 8 + r) * 10 + (p % 8) + s) * row_bytes + (c0 + (t & 3) * 4) * 2;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0 + 4 * row_bytes));
+    out[0] = make_uint4(((unsigned)(unsigned short)lo[0]) | ((unsigned)(unsigned short)lo[1] << 16),
+                        ((unsigned)(unsigned short)lo[2]) | ((unsigned)(unsigned short)lo[3] << 16),
+                        ((unsigned)(unsigned short)hi[0]) | ((unsigned)(unsigned short)hi[1] << 16),
+                        ((unsigned)(unsigned short)hi[2]) | ((unsigned)(unsigned short)hi[3] << 16));
+}
 template <int W> __device__ __forceinline__ void frag_halo_f32(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) {
     const int t = lane & 15, g = lane >> 4;
     unsigned v[8];
@@ -83,6 +94,7 @@ template <int W> __device__ __forceinline__ void frag_halo_f32(const char* tile,
 }
 template <> __device__ __forceinline__ void frag_halo<float, 32>(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) { frag_halo_f32<32>(tile, row_bytes, pb, r, s, c0, lane, out); }
 template <> __device__ __forceinline__ void frag_halo<float, 16>(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) { frag_halo_f32<16>(tile, row_bytes, pb, r, s, c0, lane, out); }
+template <> __device__ __forceinline__ void frag_halo<float, 8>(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) { frag_halo_f32<8>(tile, row_bytes, pb, r, s, c0, lane, out); }
 
 template <typename T, int W>
 __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p) {
@@ -105,7 +117,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p
     char* tileA = lds;
     char* tileB = lds + (SPLIT ? NPL * PLANE_A : 64 * ROW);
     float hs_a = 1.f, hs_b = 1.f;
-    if constexpr (HSPLIT) { hs_a = fb_pow2_scale(*p.amax_dy); hs_b = fb_pow2_scale(*p.amax_x); }
+    if constexpr (HSPLIT) { hs_a = fb_pow2_scale(p.amax_dy[blockIdx.y / p.split_k]); hs_b = fb_pow2_scale(p.amax_x[blockIdx.y / p.split_k]); }   // per chunk
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_n = p.Cs / 64;
@@ -237,7 +249,7 @@ int fb_try_wgrad3x3(const fb_wgrad_args* a, hipStream_t st) {
     if (a->R != 3 || a->S != 3 || a->stride != 1 || a->pad != 1) return 0;
     if (a->Hs != a->Hd || a->Ws != a->Wd || a->Hs != a->Ws) return 0;
     const int W = a->Ws;
-    if (W != 32 && W != 16) return 0;
+    if (W != 32 && W != 16 && W != 8) return 0;               // (8x8: one whole image per 64-pixel K-step)
     if (a->Cs % 64 != 0 || a->Cd % 64 != 0) return 0;
     Wgrad3Params p;
     p.x = (const char*)a->x; p.dy = (const char*)a->dy; p.out = a->dw_partial;
@@ -249,16 +261,20 @@ int fb_try_wgrad3x3(const fb_wgrad_args* a, hipStream_t st) {
     dim3 grid((a->Cd / 64) * (a->Cs / 64), n_groups * a->split_k);
     if (a->dtype == FB_F32 && a->amax_x && a->amax_dy) {
         if (W == 32) hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32h_tag, 32>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32h_tag, 16>), grid, dim3(256), 0, st, p);
+        else if (W == 16) hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32h_tag, 16>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32h_tag, 8>), grid, dim3(256), 0, st, p);
     } else if (a->dtype == FB_F32 && fb_f32_split_enabled()) {
         if (W == 32) hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32s_tag, 32>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32s_tag, 16>), grid, dim3(256), 0, st, p);
+        else if (W == 16) hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32s_tag, 16>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32s_tag, 8>), grid, dim3(256), 0, st, p);
     } else if (a->dtype == FB_F32) {
         if (W == 32) hipLaunchKernelGGL((conv_wgrad3x3_kernel<float, 32>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv_wgrad3x3_kernel<float, 16>), grid, dim3(256), 0, st, p);
+        else if (W == 16) hipLaunchKernelGGL((conv_wgrad3x3_kernel<float, 16>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wgrad3x3_kernel<float, 8>), grid, dim3(256), 0, st, p);
     } else {
         if (W == 32) hipLaunchKernelGGL((conv_wgrad3x3_kernel<bf16_tag, 32>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv_wgrad3x3_kernel<bf16_tag, 16>), grid, dim3(256), 0, st, p);
+        else if (W == 16) hipLaunchKernelGGL((conv_wgrad3x3_kernel<bf16_tag, 16>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wgrad3x3_kernel<bf16_tag, 8>), grid, dim3(256), 0, st, p);
     }
     return 1;
 }

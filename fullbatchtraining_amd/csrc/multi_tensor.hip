@@ -479,7 +479,9 @@ extern "C" int fb_mt_pnorm2(const float* a, int64_t n, float p, float* out, floa
 // Largest magnitude of an fp32 tensor (scale source of the fp16x2 split, common.h): |x| as a bit pattern is monotone, so the maximum is an
 // integer atomic; 16-byte loads, one atomic per workgroup.  n_sets slices of n values, set_stride floats apart (the per-chunk weight sets
 // of one layer), share one result.
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x0, long long n, long long set_stride, unsigned* __restrict__ out) {
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x0, long long n, long long set_stride, unsigned* __restrict__ out0,
+                                                     int per_set) {
+    unsigned* out = out0 + (per_set ? blockIdx.y : 0);
     const float* xs = x0 + (long long)blockIdx.y * set_stride;
     const uint4* x = (const uint4*)xs;
     const long long n_vec = (((unsigned long long)xs & 15) == 0) ? n / 4 : 0;     // an unaligned slice takes the scalar path below
@@ -505,13 +507,15 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     }
 }
 
-extern "C" int fb_absmax(const float* x, int64_t n, int32_t n_sets, int64_t set_stride, float* out, void* stream) {
+extern "C" int fb_absmax(const float* x, int64_t n, int32_t n_sets, int64_t set_stride, int32_t per_set, float* out, void* stream) {
     if (!x || !out || n < 0 || n_sets < 1) FB_FAIL(FB_ERR_ARG, "fb_absmax: bad arguments");
     if (((uintptr_t)x & 3) != 0) FB_FAIL(FB_ERR_ARG, "fb_absmax: x must be 4-byte aligned");
-    if (hipMemsetAsync(out, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) FB_FAIL(FB_ERR_LAUNCH, "fb_absmax: memset failed");
+    if (hipMemsetAsync(out, 0, sizeof(float) * (per_set ? n_sets : 1), (hipStream_t)stream) != hipSuccess) FB_FAIL(FB_ERR_LAUNCH, "fb_absmax: memset failed");
     long long blocks = (n / 4 + 256 * 8 - 1) / (256 * 8);
     blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks, (unsigned)n_sets), dim3(256), 0, (hipStream_t)stream, x, (long long)n, (long long)set_stride, (unsigned*)out);
+    if (per_set && blocks * n_sets > 8192) blocks = (8192 + n_sets - 1) / n_sets;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks, (unsigned)n_sets), dim3(256), 0, (hipStream_t)stream, x, (long long)n, (long long)set_stride, (unsigned*)out,
+                       (int)per_set);
     FB_CHECK_LAUNCH("fb_absmax");
     return FB_OK;
 }

@@ -248,12 +248,20 @@ class Engine:
         self.norms2 = torch.zeros(2, **f32)
         # fp32 convolutions: "f16x2" (two scaled fp16 pieces per operand, three MFMAs per product; needs the largest magnitude of every
         # operand tensor: fb_absmax, cached per tensor below), "bf16x6" (three bf16 pieces, six MFMAs); FB_F32_EXACT=1 in the library: exact f32
-        self.f32_split = os.environ.get("FB_F32_SPLIT", "f16x2") if compute_dtype == torch.float32 else None
-        self.amax_buf = torch.zeros(1024, device=self.device, dtype=torch.float32)
+        # Default: f16x2 for the finite-difference regulariser (its own truncation error, 3.5e-2 in fp32, hides the 2^-22 operand rounding:
+        # the float64 oracle with 22-bit operands gives 3.7e-2), bf16x6 for plain fp32 training (held to the tighter fp32-vs-float64 traces)
+        self.f32_split = os.environ.get("FB_F32_SPLIT", "f16x2" if fd_sets else "bf16x6") if compute_dtype == torch.float32 else None
+        # one scale per CHUNK and tensor (a chunk's arithmetic must not depend on how chunks are batched or sharded): slots of G floats
+        self.amax_buf = torch.zeros(256, self.G, device=self.device, dtype=torch.float32)
         self.amax_map, self.amax_next = {}, 0
         for li, L in enumerate(self.plan.layers):
             L.li = li
-        self.w_amax = [torch.zeros(len(self.plan.layers), device=self.device, dtype=torch.float32) for _ in range(2)]
+        self.w_amax = [torch.zeros(len(self.plan.layers), self.G if k else 1, device=self.device, dtype=torch.float32) for k in range(2)]
+        self.amax_ws = None
+        if self.f32_split == "f16x2":                # scratch of the apply passes that track the magnitudes of their own output
+            n_max = self.G * chunk
+            need = max(lib.load().fb_ws_bn_amax_floats(n_max * L.hout * L.wout, L.cout, chunk * L.hout * L.wout) for L in self.plan.layers)
+            self.amax_ws = torch.zeros(int(need), device=self.device, dtype=torch.float32)
         self.pool = _Pool(self.device, self.dt, on_reuse=lambda t: self.amax_map.pop(t.data_ptr(), None))
         self.masks = {}
         self.fuse_bwd_stat = os.environ.get("FB_FUSED_BWD_STAT", "0") != "0"     # BN-backward reduction in the input-gradient epilogues: built, parity-tested,
@@ -317,7 +325,7 @@ class Engine:
     def _choose_split(self, L):
         """Split the pixel reduction of wgrad so that >= ~1000 workgroups exist; slices are multiples of the K-step."""
         bf16 = self.dt == torch.bfloat16
-        widths = ((4, 8, 16, 32) if bf16 else (16, 32)) if L.stride == 1 else ((4, 8, 16) if bf16 else ())
+        widths = ((4, 8, 16, 32) if bf16 else (8, 16, 32)) if L.stride == 1 else ((4, 8, 16) if bf16 else ())
         if (L.R == 3 and L.stride in (1, 2) and L.pad == 1 and L.hout == L.wout and L.hin == L.stride * L.hout and L.wout in widths
                 and L.cin_pad % 64 == 0 and L.cout % 64 == 0 and not (L.wout == 4 and self.chunk % 2)):
             # all-taps halo wgrad kernel: split-K over whole images (pairs for 4x4 maps); any split works (ragged last slice).
@@ -431,39 +439,44 @@ class Engine:
         for li, L in enumerate(self.plan.layers):
             dst_d = wd.data_ptr() + es * L.wc_off if L is not self.plan.stem else None
             am = None
-            if self.f32_split == "f16x2":            # one scale per layer, shared by its forward and transposed copies and by all chunks' sets;
-                am = self.w_amax[slot].data_ptr() + 4 * li                      # the copies are then written as fp16x2 planes
-                call("fb_absmax", theta.data_ptr() + 4 * L.w_off, L.cout * L.taps * L.cin_real, nsets, self.plan.P, am)
+            if self.f32_split == "f16x2":            # one scale per layer and weight set, shared by its forward and transposed copies;
+                am = self.w_amax[slot][li].data_ptr()                           # the copies are then written as fp16x2 planes
+                call("fb_absmax", theta.data_ptr() + 4 * L.w_off, L.cout * L.taps * L.cin_real, nsets, self.plan.P, 1, am)
             call("fb_weight_prep", theta.data_ptr() + 4 * L.w_off, self.plan.P, self.plan.wc_total, nsets, L.cout, L.taps, L.cin_real,
                  L.cin_pad, wf.data_ptr() + es * L.wc_off, dst_d, self.dtc, am)
 
-    def _amax(self, t, numel):
-        """Device pointer of the largest magnitude of the first ``numel`` values of ``t`` (fp16x2 split scale), computed once per
-        content: the cache is dropped when a forward pass starts and when the pool hands the buffer out again."""
+    def _amax(self, t, numel, G):
+        """Device pointer of the per-chunk largest magnitudes (G floats) of the first ``numel`` values of ``t`` (fp16x2 split scales),
+        computed once per content: the cache is dropped when a forward pass starts and when the pool hands the buffer out again."""
         key = t.data_ptr()
         hit = self.amax_map.get(key)
         if hit is not None and hit[1] == numel:
             return hit[0]
-        slot = self.amax_buf.data_ptr() + 4 * self.amax_next
-        self.amax_next = (self.amax_next + 1) % self.amax_buf.numel()
-        call("fb_absmax", t.data_ptr(), numel, 1, 0, slot)
-        self.amax_map[key] = (slot, numel)
+        slot = self._amax_slot(t, numel)
+        call("fb_absmax", t.data_ptr(), numel // G, G, numel // G, 1, slot)
         return slot
 
-    def _amax_pair(self, L, src, numel, wsets):
+    def _amax_slot(self, t, numel):
+        """Slot (G floats) for a tensor whose PRODUCER tracks the largest magnitudes itself (fb_bn_apply / fb_bn_bwd_apply ``amax_out``)."""
+        slot = self.amax_buf[self.amax_next].data_ptr()
+        self.amax_next = (self.amax_next + 1) % self.amax_buf.shape[0]
+        self.amax_map[t.data_ptr()] = (slot, numel)
+        return slot
+
+    def _amax_pair(self, L, src, numel, wsets, G):
         if self.f32_split != "f16x2":
             return None, None
-        return self._amax(src, numel), self.w_amax[1 if wsets > 1 else 0].data_ptr() + 4 * L.li
+        return self._amax(src, numel, G), self.w_amax[1 if wsets > 1 else 0][L.li].data_ptr()
 
     def _conv_bn_fwd(self, L, src, G, wsets, theta, pidx):
         n = G * self.chunk
         wf = self.w_fwd[1 if wsets > 1 else 0]
         wptr = wf.data_ptr() + wf.element_size() * L.wc_off
         evalm = getattr(self, "_eval", False)
-        am_s, am_w = self._amax_pair(L, src, n * L.hin * L.win * L.cin_pad, wsets)
+        am_s, am_w = self._amax_pair(L, src, n * L.hin * L.win * L.cin_pad, wsets, G)
         a = lib.ConvArgs(src.data_ptr(), wptr, L.x.data_ptr(), None, None if evalm else self.stat_ws.data_ptr(), n, L.hin, L.win, L.cin_pad, L.hout, L.wout,
                          L.cout, L.R, L.S, L.stride, L.pad, 0, self.chunk if wsets > 1 else n, self.plan.wc_total if wsets > 1 else 0,
-                         0, self.dtc, None, None, None, am_s, am_w)
+                         0, self.dtc, None, None, None, am_s, am_w, self.chunk)
         call("fb_conv2d", lib.C.byref(a))
         if evalm:
             return
@@ -484,7 +497,8 @@ class Engine:
         call("fb_bn_apply", L.x.data_ptr(), out.data_ptr(), L.scale.data_ptr(), L.shift.data_ptr(), _ptr(res),
              resL.scale.data_ptr() if resL is not None else None, resL.shift.data_ptr() if resL is not None else None,
              px, L.cout, ppg, self.valid * L.hout * L.wout if self.valid < self.chunk else 0, 1 if relu else 0,
-             _ptr(self._mask_of(out)) if relu else None, _ptr(pool) if fused else None, L.wout, self.dtc)
+             _ptr(self._mask_of(out)) if relu else None, _ptr(pool) if fused else None, L.wout, self.dtc,
+             *((self._amax_slot(out, px * L.cout), self.amax_ws.data_ptr()) if self.f32_split == "f16x2" else (None, None)))
         return fused
 
     def _mask_of(self, act):
@@ -567,7 +581,7 @@ class Engine:
         dx = self.pool.get((n, L.hout, L.wout, L.cout))
         dy = self.pool.get((n, L.hout, L.wout, L.cout)) if want_dy else None
         call("fb_bn_bwd_apply", dout.data_ptr(), _ptr(y), _ptr(bits), L.x.data_ptr(), L.coef.data_ptr(), dx.data_ptr(), _ptr(dy), px, L.cout, ppg,
-             self.dtc)
+             self.dtc, *((self._amax_slot(dx, px * L.cout), self.amax_ws.data_ptr()) if self.f32_split == "f16x2" else (None, None)))
         return dx, dy
 
     def _wgrad(self, L, src, dx, G, gout):
@@ -578,7 +592,7 @@ class Engine:
         direct = L.split_k == 1 and L.cin_pad == L.cin_real
         am_x = am_dy = None
         if self.f32_split == "f16x2":                # (computed on the main stream, before the event the weight-gradient stream waits for)
-            am_x, am_dy = self._amax(src, n * L.hin * L.win * L.cin_pad), self._amax(dx, n * L.hout * L.wout * L.cout)
+            am_x, am_dy = self._amax(src, n * L.hin * L.win * L.cin_pad, G), self._amax(dx, n * L.hout * L.wout * L.cout, G)
         a = lib.WgradArgs(src.data_ptr(), dx.data_ptr(), gout.data_ptr() + 4 * L.w_off if direct else self.slab_ws.data_ptr(), n, L.hin, L.win,
                           L.cin_pad, L.hout, L.wout, L.cout, L.R, L.S, L.stride, L.pad, self.chunk, L.split_k, self.dtc,
                           self.plan.P if direct else 0, am_x, am_dy)
@@ -602,7 +616,7 @@ class Engine:
         n = G * self.chunk
         return lib.ConvArgs(src, wptr, dst, addend, stat, n, L.hout, L.wout, L.cout, L.hin, L.win, L.cin_pad,
                             L.R, L.S, L.stride, L.pad, 1, self.chunk if wsets > 1 else n, self.plan.wc_total if wsets > 1 else 0,
-                            addend_mode, self.dtc, addend_mask, bst_x, bst_mask, amax[0], amax[1])
+                            addend_mode, self.dtc, addend_mask, bst_x, bst_mask, amax[0], amax[1], self.chunk)
 
     def _dgrad(self, L, dx, G, wsets, addend=None, addend_mode=0, addend_mask=None, bst=None):
         """Input gradient of layer L.  ``bst = (Lbn, out)``: the BatchNorm (layer ``Lbn``, output tensor ``out``) whose backward consumes the
@@ -622,7 +636,7 @@ class Engine:
                 self.bst_done = bool(lib.load().fb_conv_bwd_stat_supported(lib.C.byref(a)))
         if not self.bst_done:
             a = self._dgrad_args(L, dx.data_ptr(), wptr, out.data_ptr(), _ptr(addend), G, wsets, addend_mode, _ptr(addend_mask),
-                                 amax=self._amax_pair(L, dx, n * L.hout * L.wout * L.cout, wsets))
+                                 amax=self._amax_pair(L, dx, n * L.hout * L.wout * L.cout, wsets, G))
         call("fb_conv2d", lib.C.byref(a))
         return out
 

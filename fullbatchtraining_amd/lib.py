@@ -21,7 +21,7 @@ class ConvArgs(C.Structure):
                 ("n_img", c_int), ("Hs", c_int), ("Ws", c_int), ("Cs", c_int), ("Hd", c_int), ("Wd", c_int), ("Cd", c_int),
                 ("R", c_int), ("S", c_int), ("stride", c_int), ("pad", c_int), ("mode", c_int),
                 ("imgs_per_wset", c_int), ("wset_stride", c_i64), ("addend_mode", c_int), ("dtype", c_int), ("addend_mask", c_void_p),
-                ("bst_x", c_void_p), ("bst_mask", c_void_p), ("amax_src", c_void_p), ("amax_wgt", c_void_p)]
+                ("bst_x", c_void_p), ("bst_mask", c_void_p), ("amax_src", c_void_p), ("amax_wgt", c_void_p), ("amax_imgs", c_int)]
 
 
 class WgradArgs(C.Structure):
@@ -34,18 +34,18 @@ class WgradArgs(C.Structure):
 _SIGS = {
     "fb_conv2d": [C.POINTER(ConvArgs), c_void_p],
     "fb_conv2d_wgrad": [C.POINTER(WgradArgs), c_void_p],
-    "fb_absmax": [c_void_p, c_i64, c_int, c_i64, c_void_p, c_void_p],
+    "fb_absmax": [c_void_p, c_i64, c_int, c_i64, c_int, c_void_p, c_void_p],
     "fb_wgrad_reduce": [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "fb_weight_prep": [c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "fb_bn_fwd_finalize": [c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_i64, c_float, c_void_p, c_void_p, c_int,
                            c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "fb_bn_apply": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_i64, c_int, c_void_p, c_void_p, c_int,
-                    c_int, c_void_p],
+                    c_int, c_void_p, c_void_p, c_void_p],
     "fb_bn_running_update": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_void_p, c_int, c_int, c_float, c_void_p],
     "fb_bn_bwd_reduce": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_i64, c_int, c_i64, c_int, c_void_p],
     "fb_bn_bwd_finalize": [c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                            c_i64, c_void_p, c_int, c_void_p],
-    "fb_bn_bwd_apply": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_void_p],
+    "fb_bn_bwd_apply": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_void_p, c_void_p, c_void_p],
     "fb_stem_patches": [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                         C.POINTER(c_float), c_int, c_void_p],
     "fb_avgpool2_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
@@ -79,7 +79,7 @@ _SIGS = {
 }
 EXPORTS = tuple(_SIGS) + ("fb_last_error_string", "fb_abi_version", "fb_profile_enable", "fb_profile_read", "fb_ws_conv_stat_floats",
                           "fb_ws_wgrad_slab_floats", "fb_ws_bn_partial_floats", "fb_ws_mt_floats", "fb_bn_bwd_reduce_rows", "fb_conv_masked_addend_supported", "fb_conv_bwd_stat_supported",
-                          "fb_bn_apply_can_pool")
+                          "fb_bn_apply_can_pool", "fb_ws_bn_amax_floats")
 PROF_CLASSES = ("igemm_fwd", "igemm_dgrad", "wgrad")
 
 
@@ -129,6 +129,7 @@ def load():
         lib.fb_bn_bwd_reduce_rows.argtypes, lib.fb_bn_bwd_reduce_rows.restype = [c_i64, c_i64], c_int
         lib.fb_conv_masked_addend_supported.argtypes, lib.fb_conv_masked_addend_supported.restype = [C.POINTER(ConvArgs)], c_int
         lib.fb_conv_bwd_stat_supported.argtypes, lib.fb_conv_bwd_stat_supported.restype = [C.POINTER(ConvArgs)], c_int
+        lib.fb_ws_bn_amax_floats.argtypes, lib.fb_ws_bn_amax_floats.restype = [c_i64, c_int, c_i64], c_i64
         lib.fb_bn_apply_can_pool.argtypes, lib.fb_bn_apply_can_pool.restype = [c_int, c_int, c_i64, c_int], c_int
         _lib = lib
     return _lib
@@ -166,11 +167,11 @@ def dtype_code(dtype):
 # thin tensor-level wrappers (shapes are read from the tensors; NHWC activations)
 # ---------------------------------------------------------------------------------------------------------------------
 def conv2d(src, wgt, dst, R, S, stride, pad, mode, addend=None, addend_mode=0, stat_partial=None, imgs_per_wset=0, wset_stride=0,
-           addend_mask=None, bst_x=None, bst_mask=None, amax_src=None, amax_wgt=None):
+           addend_mask=None, bst_x=None, bst_mask=None, amax_src=None, amax_wgt=None, amax_imgs=0):
     n, hs, ws, cs = src.shape
     _, hd, wd, cd = dst.shape
     a = ConvArgs(_ptr(src), _ptr(wgt), _ptr(dst), _ptr(addend), _ptr(stat_partial), n, hs, ws, cs, hd, wd, cd, R, S, stride, pad, mode,
-                 imgs_per_wset, wset_stride, addend_mode, dtype_code(src.dtype), _ptr(addend_mask), _ptr(bst_x), _ptr(bst_mask), _ptr(amax_src), _ptr(amax_wgt))
+                 imgs_per_wset, wset_stride, addend_mode, dtype_code(src.dtype), _ptr(addend_mask), _ptr(bst_x), _ptr(bst_mask), _ptr(amax_src), _ptr(amax_wgt), amax_imgs)
     if bst_x is not None and not load().fb_conv_bwd_stat_supported(C.byref(a)):
         raise EngineError("fb_conv2d: fused BatchNorm-backward reduction not supported for these arguments")
     call("fb_conv2d", C.byref(a))

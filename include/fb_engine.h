@@ -68,11 +68,13 @@ typedef struct {
                                 * vector): dst += addend only where the bit is set, i.e. the masked residual gradient d * (out > 0) of
                                 * reference resnets.py:118-121 / autograd's threshold_backward without a materialised copy */
     const void* bst_x; const void* bst_mask;   /* optional (mode 1): fused BatchNorm-backward reduction, see above */
-    const float* amax_src; const float* amax_wgt;   /* optional (FB_F32): device scalars holding the largest magnitudes of src and of wgt
+    const float* amax_src; const float* amax_wgt;   /* optional (FB_F32): device arrays holding the largest magnitudes of src and of wgt
                                 * (fb_absmax).  Both set: every fp32 operand enters as two scaled fp16 pieces and a product takes three fp16
                                 * MFMAs (22 significand bits per operand, fp32 accumulation); src is split inside the kernel, wgt must be the
-                                * fp16x2 planes fb_weight_prep(amax) wrote.  Unset: three bf16 pieces, six MFMAs (exact fp32 operands), or
-                                * the exact-f32 MFMA with FB_F32_EXACT=1 */
+                                * fp16x2 planes fb_weight_prep(amax) wrote.  amax_src[k] belongs to images [k*amax_imgs, (k+1)*amax_imgs) (one
+                                * scale per chunk, so that a chunk's result does not depend on how chunks are batched), amax_wgt[w] to weight
+                                * set w.  Unset: three bf16 pieces, six MFMAs (exact fp32 operands), or the exact-f32 MFMA with FB_F32_EXACT=1 */
+    int32_t amax_imgs;
 } fb_conv_args;
 int fb_conv2d(const fb_conv_args* a, void* stream);
 /* 1 if fb_conv2d implements addend_mask for these arguments (otherwise it fails with FB_ERR_UNSUPPORTED and the caller masks the
@@ -80,9 +82,10 @@ int fb_conv2d(const fb_conv_args* a, void* stream);
 int32_t fb_conv_masked_addend_supported(const fb_conv_args* a);
 /* 1 if fb_conv2d implements the fused BatchNorm-backward reduction (bst_x / bst_mask / stat_partial in mode 1) for these arguments */
 int32_t fb_conv_bwd_stat_supported(const fb_conv_args* a);
-/* out[0] = max |x[s*set_stride + i]| over n_sets slices of n fp32 values (device scalar; one streaming pass, atomic maximum of the bit
- * patterns): the per-tensor scale source of the fp16x2 split (amax_* above); slices = the per-chunk weight sets of one layer */
-int fb_absmax(const float* x, int64_t n, int32_t n_sets, int64_t set_stride, float* out, void* stream);
+/* Largest magnitudes of n_sets slices of n fp32 values, set_stride floats apart (one streaming pass, atomic maximum of the bit patterns):
+ * per_set = 1: out[s] = max |x[s*set_stride + i]| (one scale per chunk: the amax_* arrays above); per_set = 0: out[0] = the maximum
+ * over all slices */
+int fb_absmax(const float* x, int64_t n, int32_t n_sets, int64_t set_stride, int32_t per_set, float* out, void* stream);
 
 /* wgrad: dw[g][split][Cd][R*S][Cs] (fp32 partial slabs) = sum over the pixels of chunk g (split-K slice `split`) of
  * dy[p][Cd] (x) x[src(p,tap)][Cs]        (ATen convolution_backward, weight part).  Deterministic: no atomics.
@@ -95,7 +98,8 @@ typedef struct {
     int32_t R, S, stride, pad;
     int32_t imgs_per_group; int32_t split_k; int32_t dtype;
     int64_t group_stride;
-    const float* amax_x; const float* amax_dy;   /* optional (FB_F32): largest magnitudes of x and dy (fb_absmax): fp16x2 split as in fb_conv_args */
+    const float* amax_x; const float* amax_dy;   /* optional (FB_F32): largest magnitudes of x and dy PER GROUP of imgs_per_group images
+                                                  * (fb_absmax, per_set): fp16x2 split as in fb_conv_args */
 } fb_wgrad_args;
 int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream);
 
@@ -115,8 +119,8 @@ int fb_wgrad_reduce(const float* dw_partial, float* out, int64_t out_group_strid
                     int32_t Cd, int32_t taps, int32_t Cs_pad, int32_t Cs_real, void* stream);
 /* master fp32 KRSC weights [Cout][taps][Cin_real] of n_wsets sets (wset_stride_in floats apart) ->
  * w_fwd [Cout][taps][Cin_pad] and (optional) w_dgrad [Cin_pad][taps][Cout] in `dtype`, sets wset_stride_out elements apart.
- * amax (optional, FB_F32): device scalar = largest magnitude of these master weights over all sets (fb_absmax): the copies are written
- * as fp16x2 planes (per 32 values: 32 scaled fp16 high pieces, then 32 low pieces; same size as fp32) -- the weight format fb_conv2d
+ * amax (optional, FB_F32): device array, amax[s] = largest magnitude of the master weights of set s (fb_absmax, per_set): the copies are
+ * written as fp16x2 planes (per 32 values: 32 scaled fp16 high pieces, then 32 low pieces; same size as fp32) -- the weight format fb_conv2d
  * expects whenever fb_conv_args.amax_wgt is set (to this same scalar) */
 int fb_weight_prep(const float* master, int64_t wset_stride_in, int64_t wset_stride_out, int32_t n_wsets, int32_t Cout, int32_t taps,
                    int32_t Cin_real, int32_t Cin_pad, void* w_fwd, void* w_dgrad, int32_t dtype, const float* amax, void* stream);
@@ -129,10 +133,14 @@ int fb_bn_fwd_finalize(const float* stat_partial, int32_t n_mblocks, int32_t n_g
                        float* mean_tab, float* var_tab, int32_t ch_total, int32_t ch_off,
                        float* scale, float* shift, float* invstd, void* stream);
 /* y = relu?(x*scale[g][c] + shift[g][c] + residual)  residual: none | res | res*rscale[g][c]+rshift[g][c]
- * (BatchNorm2d + ReLU(inplace) + `out += identity`, resnets.py:217-228) */
+ * (BatchNorm2d + ReLU(inplace) + `out += identity`, resnets.py:217-228).
+ * amax_out (optional, FB_F32): device array that receives max |y| of every statistics group (fb_absmax per_set semantics, tracked by the
+ * same pass): the scale source of the fp16x2 convolutions that read y */
 int fb_bn_apply(const void* x, void* y, const float* scale, const float* shift, const void* res, const float* rscale,
                 const float* rshift, int64_t n_pixels, int32_t C, int64_t pixels_per_group, int64_t valid_pixels_per_group,
-                int32_t relu, void* mask_out, void* pool_out, int32_t pool_W, int32_t dtype, void* stream);
+                int32_t relu, void* mask_out, void* pool_out, int32_t pool_W, int32_t dtype, float* amax_out, float* amax_ws, void* stream);
+/* floats of scratch (amax_ws) that fb_bn_apply / fb_bn_bwd_apply need when amax_out is set: one per 512-vector run */
+int64_t fb_ws_bn_amax_floats(int64_t n_pixels, int32_t C, int64_t pixels_per_group);
 /* pool_out (optional): AvgPool2d(2,2) of y, [n_img][H/2][W/2][C] (the 'C' downsample shortcut of the NEXT block, resnets.py:149), written
  * by the same pass -- bit-identical to fb_avgpool2_fwd on y, one read of the activation less.  pool_W = image width of y; only where
  * fb_bn_apply_can_pool() says so (bf16, W*C == 2048: the 64@32, 128@16, 256@8 maps of ResNet-18/34). */
@@ -160,9 +168,10 @@ int fb_bn_bwd_reduce(const void* dout, const void* y, const void* mask, const vo
 int fb_bn_bwd_finalize(const float* partial, int32_t n_mblocks, int32_t n_groups, int32_t C, double count,
                        const float* scale, const float* mean_tab, const float* invstd, int32_t ch_total, int32_t ch_off,
                        float* dgamma, float* dbeta, int64_t grad_group_stride, float* coef, int32_t raw_x, void* stream);
-/* dx = c_dy*dy + c_x*x + c_0 ; optionally also stores dy (masked gradient, used by the shortcut branch) */
+/* dx = c_dy*dy + c_x*x + c_0 ; optionally also stores dy (masked gradient, used by the shortcut branch); amax_out (optional, FB_F32):
+ * receives max |dx| as in fb_bn_apply */
 int fb_bn_bwd_apply(const void* dout, const void* y, const void* mask, const void* x, const float* coef, void* dx, void* dy_out,
-                    int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t dtype, void* stream);
+                    int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t dtype, float* amax_out, float* amax_ws, void* stream);
 
 /* ---------------------------------------------------------------- data path --------------------------------------- */
 /* Stem patch gather: images [n_img][C][H][W] fp32 (device) -> patches [n_img][Ho][Wo][cin_pad] in `dtype`, element tap*C + c

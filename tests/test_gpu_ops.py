@@ -126,8 +126,17 @@ def test_conv_f32_fp16x2_split(cin, cout, k, stride, hw, n, magnitude):
     w = torch.randn(cout, cin, k, k) * 0.1
     am = torch.zeros(4, device="cuda")
     xd, master = nhwc(x).cuda(), krsc(w).cuda()
-    lib.call("fb_absmax", xd.data_ptr(), xd.numel(), 1, 0, am.data_ptr())
-    lib.call("fb_absmax", master.data_ptr(), master.numel() // 2, 2, master.numel() // 2, am.data_ptr() + 4)     # two slices = the two halves
+    if n % 2 == 0 and (n // 2) * hw * hw % 128 == 0:         # two "chunks" with a scale each, the second one 64x smaller
+        x[n // 2:] /= 64
+        xd = nhwc(x).cuda()
+        am2 = torch.zeros(2, device="cuda")
+        lib.call("fb_absmax", xd.data_ptr(), xd.numel() // 2, 2, xd.numel() // 2, 1, am2.data_ptr())
+        assert torch.equal(am2.cpu(), x.reshape(2, -1).abs().max(1).values)
+        src_scale = dict(amax_src=am2, amax_imgs=n // 2)
+    else:
+        src_scale = dict(amax_src=am[0:])
+    lib.call("fb_absmax", xd.data_ptr(), xd.numel(), 1, 0, 0, am.data_ptr())
+    lib.call("fb_absmax", master.data_ptr(), master.numel() // 2, 2, master.numel() // 2, 0, am.data_ptr() + 4)   # two slices = the two halves
     assert float(am[0]) == float(x.abs().max()) and float(am[1]) == float(w.abs().max())
     w_plain, wt_plain, w_pl, wt_pl = (torch.zeros(cout * k * k * cin, device="cuda") for _ in range(4))
     lib.weight_prep(master, 0, 0, 1, cout, k * k, cin, cin, w_plain, wt_plain, torch.float32)
@@ -135,7 +144,7 @@ def test_conv_f32_fp16x2_split(cin, cout, k, stride, hw, n, magnitude):
     ref = F.conv2d(x.double(), w.double(), None, stride, pad)
     ho = ref.shape[2]
     out_h, out_s = (torch.empty(n, ho, ho, cout, device="cuda") for _ in range(2))
-    lib.conv2d(xd, w_pl, out_h, k, k, stride, pad, 0, amax_src=am[0:], amax_wgt=am[1:])
+    lib.conv2d(xd, w_pl, out_h, k, k, stride, pad, 0, amax_wgt=am[1:], **src_scale)
     lib.conv2d(xd, w_plain, out_s, k, k, stride, pad, 0)
     eh, es = rel(nchw(out_h.cpu()).double(), ref), rel(nchw(out_s.cpu()).double(), ref)
     assert eh < 1.5e-6 and eh < 8 * es + 2e-7, (eh, es)
@@ -144,7 +153,7 @@ def test_conv_f32_fp16x2_split(cin, cout, k, stride, hw, n, magnitude):
     dy = (torch.randn(n, cout, ho, ho) * torch.exp(torch.randn(n, cout, ho, ho))) * magnitude
     refd = torch.nn.grad.conv2d_input((n, cin, hw, hw), w.double(), dy.double(), stride, pad)
     dyd = nhwc(dy).cuda()
-    lib.call("fb_absmax", dyd.data_ptr(), dyd.numel(), 1, 0, am.data_ptr() + 8)
+    lib.call("fb_absmax", dyd.data_ptr(), dyd.numel(), 1, 0, 0, am.data_ptr() + 8)
     dh, ds = (torch.empty(n, hw, hw, cin, device="cuda") for _ in range(2))
     lib.conv2d(dyd, wt_pl, dh, k, k, stride, pad, 1, amax_src=am[2:], amax_wgt=am[1:])
     lib.conv2d(dyd, wt_plain, ds, k, k, stride, pad, 1)
@@ -192,7 +201,7 @@ def test_conv_wgrad(dtype, cin, cout, k, stride, hw, ipg, groups, split):
 @pytest.mark.parametrize("magnitude", [1.0, 2e-6])
 @pytest.mark.parametrize("cin,cout,k,stride,hw,ipg,groups,split", [(64, 64, 3, 1, 8, 8, 2, 3), (64, 128, 3, 2, 8, 8, 1, 2), (256, 256, 3, 1, 4, 16, 2, 1),
                                                                   (128, 256, 1, 1, 4, 16, 1, 2), (32, 64, 1, 1, 8, 4, 2, 1), (64, 64, 3, 1, 32, 4, 2, 2),
-                                                                  (128, 64, 3, 1, 16, 4, 2, 4), (64, 64, 3, 1, 16, 10, 2, 3)])
+                                                                  (128, 64, 3, 1, 16, 4, 2, 4), (64, 64, 3, 1, 16, 10, 2, 3), (128, 64, 3, 1, 8, 6, 2, 2), (256, 256, 3, 1, 8, 16, 1, 1)])
 def test_conv_wgrad_f32_fp16x2_split(cin, cout, k, stride, hw, ipg, groups, split, magnitude):
     """Weight gradients of fp32 tensors on the fp16 matrix pipe (fb_wgrad_args.amax_x / amax_dy): two scaled fp16 planes per operand, three
     MFMAs per product; against float64, with gradients of realistic (tiny) magnitude, next to the six-product bf16 path."""
@@ -204,11 +213,12 @@ def test_conv_wgrad_f32_fp16x2_split(cin, cout, k, stride, hw, ipg, groups, spli
     x = torch.randn(n, cin, hw, hw) * torch.exp(0.5 * torch.randn(n, cin, hw, hw))
     dy = torch.randn(n, cout, ho, ho) * torch.exp(torch.randn(n, cout, ho, ho)) * magnitude
     xd, dyd = nhwc(x).cuda(), nhwc(dy).cuda()
-    am = torch.zeros(2, device="cuda")
-    lib.call("fb_absmax", xd.data_ptr(), xd.numel(), 1, 0, am.data_ptr())
-    lib.call("fb_absmax", dyd.data_ptr(), dyd.numel(), 1, 0, am.data_ptr() + 4)
+    am = torch.zeros(2, groups, device="cuda")                # one scale per chunk (group) and operand
+    lib.call("fb_absmax", xd.data_ptr(), xd.numel() // groups, groups, xd.numel() // groups, 1, am[0].data_ptr())
+    lib.call("fb_absmax", dyd.data_ptr(), dyd.numel() // groups, groups, dyd.numel() // groups, 1, am[1].data_ptr())
+    assert torch.equal(am[0].cpu(), x.reshape(groups, -1).abs().max(1).values) and torch.equal(am[1].cpu(), dy.reshape(groups, -1).abs().max(1).values)
     errs = []
-    for amax in ((am[0:], am[1:]), (None, None)):
+    for amax in ((am[0], am[1]), (None, None)):
         slab = torch.full((groups, split, cout, k * k, cin), float("nan"), device="cuda")
         lib.conv2d_wgrad(xd, dyd, slab, k, k, stride, pad, ipg, split, amax_x=amax[0], amax_dy=amax[1])
         out = torch.zeros(groups, cout * k * k * cin, device="cuda")
@@ -269,8 +279,10 @@ def test_batchnorm_fwd_bwd(dtype, C, hw, ipg, groups):
     xd, resd, doutd = (nhwc(t).to(dtype).cuda() for t in (x, res, dout))
     y = torch.empty_like(xd)
     bits = torch.zeros(xd.numel() * xd.element_size() // 16, dtype=torch.uint8, device="cuda")
+    amax = torch.zeros(2, groups, device="cuda")             # fp32 only: per-group largest magnitudes tracked by the apply passes themselves
+    amax_ws = torch.zeros(int(lib.load().fb_ws_bn_amax_floats(px, C, ppg)), device="cuda")
     lib.call("fb_bn_apply", xd.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), resd.data_ptr(), None, None, px, C, ppg, 0, 1,
-             bits.data_ptr(), None, 0, lib.dtype_code(dtype))
+             bits.data_ptr(), None, 0, lib.dtype_code(dtype), *((amax[0].data_ptr(), amax_ws.data_ptr()) if dtype == torch.float32 else (None, None)))
     # reference, per group
     ys, dxs, dgs, dbs = [], [], [], []
     for g in range(groups):
@@ -306,7 +318,9 @@ def test_batchnorm_fwd_bwd(dtype, C, hw, ipg, groups):
     dx = torch.empty_like(xd)
     dy_out = torch.empty_like(xd)
     lib.call("fb_bn_bwd_apply", doutd.data_ptr(), yd.data_ptr(), None, xd.data_ptr(), coef.data_ptr(), dx.data_ptr(), dy_out.data_ptr(), px, C, ppg,
-             lib.dtype_code(dtype))
+             lib.dtype_code(dtype), *((amax[1].data_ptr(), amax_ws.data_ptr()) if dtype == torch.float32 else (None, None)))
+    if dtype == torch.float32:
+        assert torch.equal(amax[0], y.reshape(groups, -1).abs().max(1).values) and torch.equal(amax[1], dx.reshape(groups, -1).abs().max(1).values)
     assert rel(gout[:, :C].cpu(), torch.stack(dgs)) < 1e-4
     assert rel(gout[:, C:2 * C].cpu(), torch.stack(dbs)) < 1e-4
     assert rel(nchw(dx.float().cpu()), torch.cat(dxs)) < tol(dtype, 0.5)
@@ -734,9 +748,9 @@ def test_bn_apply_fused_avgpool_is_bit_identical(C, W):
     want = torch.empty_like(pooled)
     bits = torch.zeros(x.numel() // 8, dtype=torch.uint8, device="cuda")
     lib.call("fb_bn_apply", x.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), res.data_ptr(), None, None, px, C, ppg, 0, 1,
-             bits.data_ptr(), pooled.data_ptr(), W, dt)
+             bits.data_ptr(), pooled.data_ptr(), W, dt, None, None)
     lib.call("fb_bn_apply", x.data_ptr(), y2.data_ptr(), scale.data_ptr(), shift.data_ptr(), res.data_ptr(), None, None, px, C, ppg, 0, 1,
-             bits.data_ptr(), None, 0, dt)
+             bits.data_ptr(), None, 0, dt, None, None)
     lib.call("fb_avgpool2_fwd", y2.data_ptr(), want.data_ptr(), n, W, W, C, dt)
     torch.cuda.synchronize()
     assert torch.equal(y, y2)

@@ -48,7 +48,7 @@ def main():
                          invstd.data_ptr() + 4 * g0 * C, C, 0, gout.data_ptr() + 4 * g0 * 2 * C, gout.data_ptr() + 4 * (g0 * 2 * C + C), 2 * C,
                          coef.data_ptr() + 4 * g0 * C * 3, 0)
                 lib.call("fb_bn_bwd_apply", dout.data_ptr() + o, None, mask.data_ptr() + o // 16, x.data_ptr() + o, coef.data_ptr() + 4 * g0 * C * 3,
-                         dx.data_ptr() + o, None, p, C, ppg, dt)
+                         dx.data_ptr() + o, None, p, C, ppg, dt, None, None)
 
         base = bench(lambda: run(G))
         line = f"C={C:4d} {hw:2d}x{hw:<2d}  whole group {base:7.0f} us"

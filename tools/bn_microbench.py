@@ -35,16 +35,16 @@ def main():
         nbytes = px * C * 2
         dt = lib.dtype_code(torch.bfloat16)
         t = bench(lambda: lib.call("fb_bn_apply", x.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, None, None, px, C, ppg, 0, 1,
-                                   mask.data_ptr(), None, 0, dt))
+                                   mask.data_ptr(), None, 0, dt, None, None))
         print(f"C={C:4d} {hw:2d}x{hw:<2d} bn_apply        {t*1e6:8.1f} us  {2.0625*nbytes/t/1e12:5.2f} TB/s")
         t = bench(lambda: lib.call("fb_bn_apply", x.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), res.data_ptr(), None, None, px, C, ppg,
-                                   0, 1, mask.data_ptr(), None, 0, dt))
+                                   0, 1, mask.data_ptr(), None, 0, dt, None, None))
         print(f"C={C:4d} {hw:2d}x{hw:<2d} bn_apply+res    {t*1e6:8.1f} us  {3.0625*nbytes/t/1e12:5.2f} TB/s")
         t = bench(lambda: lib.call("fb_bn_bwd_reduce", dout.data_ptr(), None, mask.data_ptr(), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), C, 0,
-                                   part.data_ptr(), px, C, ppg, dt))
+                                   part.data_ptr(), px, C, ppg, dt, None, None))
         print(f"C={C:4d} {hw:2d}x{hw:<2d} bn_bwd_reduce   {t*1e6:8.1f} us  {2.0625*nbytes/t/1e12:5.2f} TB/s")
         t = bench(lambda: lib.call("fb_bn_bwd_apply", dout.data_ptr(), None, mask.data_ptr(), x.data_ptr(), coef.data_ptr(), dx.data_ptr(), None, px, C,
-                                   ppg, dt))
+                                   ppg, dt, None, None))
         print(f"C={C:4d} {hw:2d}x{hw:<2d} bn_bwd_apply    {t*1e6:8.1f} us  {3.0625*nbytes/t/1e12:5.2f} TB/s")
         t = bench(lambda: y.copy_(x))
         print(f"C={C:4d} {hw:2d}x{hw:<2d} torch copy      {t*1e6:8.1f} us  {2*nbytes/t/1e12:5.2f} TB/s")

@@ -32,7 +32,7 @@ def bn_case(C, hw):
     scale, shift = torch.rand(G, C, device="cuda") + 0.5, torch.randn(G, C, device="cuda")
     mask = torch.empty(x.numel() // 8, device="cuda", dtype=torch.uint8)
     return lambda: lib.call("fb_bn_apply", x.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, None, None, px, C, ppg, 0, 1,
-                            mask.data_ptr(), None, hw, lib.dtype_code(dt))
+                            mask.data_ptr(), None, hw, lib.dtype_code(dt), None, None)
 
 
 def region(fns, streams, iters):
