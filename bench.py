@@ -121,13 +121,19 @@ def side_configs(args, device, X, Y, main_trainer):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n_steps
     flop = 2 * 3328997376 * tr.datapoints
+    mode = tr.engine.f32_split                              # "f16x2": two scaled fp16 pieces per operand, three MFMAs per product; "bf16x6": three bf16 pieces, six
+    per_product = 3 if mode == "f16x2" else 6
+    arithmetic = ("convolutions on the fp16 matrix pipe: every fp32 operand as two scaled fp16 pieces (22 significand bits, one power-of-two scale per chunk "
+                  "and tensor), three MFMAs per product (f16x2)" if mode == "f16x2" else
+                  "convolutions on the bf16 matrix pipe with an exact three-way split of every fp32 operand (bf16x6)")
     out = {"configs": {"gradreg": {
         "workload": f"ResNet-18 CIFAR-10 full-batch GD step + GradRegularizer block_strength=0.5 (forward differences, eps 1e-2), {tr.n_chunks} chunks x "
-                    f"{tr.chunk}, fp32 storage; convolutions on the bf16 matrix pipe with an exact three-way split of every fp32 operand (bf16x6)",
+                    f"{tr.chunk}, fp32 storage; {arithmetic}",
         "ms_per_step": round(1000 * dt, 1), "value": round(tr.datapoints / dt, 1), "unit": "images/s", "steps": n_steps, "warmup": warm, "dtype": "f32",
         "tflops": round(flop / dt / 1e12, 1),
-        "roofline": {"bound": "mfma", "peak": PEAK_BF16_TFLOPS / 6, "unit": "TFLOP/s (fp32-equivalent: six bf16 MFMAs per fp32 product)",
-                     "achieved": round(flop / dt / 1e12, 1), "frac": round(flop / dt / 1e12 / (PEAK_BF16_TFLOPS / 6), 4),
+        "roofline": {"bound": "mfma", "peak": round(PEAK_BF16_TFLOPS / per_product, 1),
+                     "unit": f"TFLOP/s (fp32-equivalent: {per_product} 16-bit MFMAs per fp32 product)",
+                     "achieved": round(flop / dt / 1e12, 1), "frac": round(flop / dt / 1e12 / (PEAK_BF16_TFLOPS / per_product), 4),
                      "frac_of_f32_mfma_peak": round(flop / dt / 1e12 / PEAK_F32_TFLOPS, 4)}}}}
     # bf16 vs fp32 on the mean gradient of the first 16 chunks at the benchmark's parameters (tests/test_gpu_bf16_parity.py)
     K = 16
