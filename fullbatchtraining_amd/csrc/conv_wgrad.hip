@@ -328,28 +328,66 @@ __global__ void weight_prep_kernel(const float* __restrict__ master, long long w
 // values scaled by the layer's power of two, in the K-slot order of the convolution kernels' fragment reads: the lane group g of an MFMA
 // step reads 16-byte chunk g (its high pieces) and chunk g + 4 (its low pieces), and the fp32 activations it splits on the fly are the
 // values {4g..4g+3, 16+4g..16+4g+3} of the group -- so value j sits at slot 8*(j%16/4) + 4*(j/16) + j%4.
-__device__ __forceinline__ long long planes_slot(long long inner) {
-    const int j = (int)(inner & 31);
-    return (inner & ~31LL) * 2 + 8 * ((j & 15) >> 2) + 4 * (j >> 4) + (j & 3);        // in 2-byte units from the row start
-}
-__global__ void weight_prep_planes_kernel(const float* __restrict__ master, long long wset_stride_in, long long wset_stride_out, int Cout, int taps,
-                                          int Cin_real, int Cin_pad, _Float16* __restrict__ w_fwd, _Float16* __restrict__ w_dgrad,
-                                          const float* __restrict__ amax) {
-    const long long per_set = (long long)Cout * taps * Cin_pad;
+// forward copy: one thread per (row = (co, tap), 32-channel group): 32 consecutive master values in, 64 + 64 contiguous bytes out
+__global__ __launch_bounds__(256) void weight_prep_planes_fwd_kernel(const float* __restrict__ master, long long wset_stride_in, long long wset_stride_out,
+                                                                     int Cout, int taps, int Cin_real, int Cin_pad, _Float16* __restrict__ w_fwd,
+                                                                     const float* __restrict__ amax) {
+    const int groups = Cin_pad / 32;
+    const long long n = (long long)Cout * taps * groups;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int ws = blockIdx.y;
-    if (idx >= per_set) return;
-    const int ci = (int)(idx % Cin_pad); const long long rt = idx / Cin_pad; const int t = (int)(rt % taps); const int co = (int)(rt / taps);
-    float v = 0.f;
-    if (ci < Cin_real) v = master[(long long)ws * wset_stride_in + ((long long)co * taps + t) * Cin_real + ci];
-    v *= fb_pow2_scale(amax[ws]);
-    const _Float16 h = (_Float16)v, l = (_Float16)(v - (float)h);
-    _Float16* f = w_fwd + ((long long)ws * wset_stride_out + rt * Cin_pad) * 2 + planes_slot(ci);
-    f[0] = h; f[32] = l;
-    if (w_dgrad) {
-        _Float16* d = w_dgrad + ((long long)ws * wset_stride_out + ((long long)ci * taps + t) * Cout) * 2 + planes_slot(co);
-        d[0] = h; d[32] = l;
+    if (idx >= n) return;
+    const int q = (int)(idx % groups);
+    const long long rt = idx / groups;
+    const float sc = fb_pow2_scale(amax[ws]);
+    const float* src = master + (long long)ws * wset_stride_in + rt * Cin_real + q * 32;
+    unsigned hi[16], lo[16];
+#pragma unroll
+    for (int j = 0; j < 32; j += 2) {
+        // slot order of the planes: value j of the group sits at slot 8*(j%16/4) + 4*(j/16) + j%4 -> fill slot pairs (s, s+1)
+        const int s0 = j;                                    // slots s0, s0+1 hold values v(s0), v(s0+1)
+        const int v0 = 4 * (s0 >> 3) + (s0 & 3) + 16 * ((s0 >> 2) & 1), v1 = v0 + 1;
+        const float a = (q * 32 + v0 < Cin_real ? src[v0] : 0.f) * sc, b = (q * 32 + v1 < Cin_real ? src[v1] : 0.f) * sc;
+        hi[j >> 1] = pack_f16x2(a, b);
+        const f16x2_t hv = __builtin_bit_cast(f16x2_t, hi[j >> 1]);
+        lo[j >> 1] = pack_f16x2(a - (float)hv[0], b - (float)hv[1]);
     }
+    uint4* dst = (uint4*)(w_fwd + ((long long)ws * wset_stride_out + rt * Cin_pad + q * 32) * 2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[k] = make_uint4(hi[4 * k], hi[4 * k + 1], hi[4 * k + 2], hi[4 * k + 3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[4 + k] = make_uint4(lo[4 * k], lo[4 * k + 1], lo[4 * k + 2], lo[4 * k + 3]);
+}
+// transposed copy [ci][tap][co]: one thread per (ci, tap, 32-channel group of co); neighbouring threads = neighbouring ci, so the 32 strided
+// master reads of a thread are coalesced across the wave, and the thread writes its own 64 + 64 contiguous bytes
+__global__ __launch_bounds__(256) void weight_prep_planes_dgrad_kernel(const float* __restrict__ master, long long wset_stride_in, long long wset_stride_out,
+                                                                       int Cout, int taps, int Cin_real, int Cin_pad, _Float16* __restrict__ w_dgrad,
+                                                                       const float* __restrict__ amax) {
+    const int groups = Cout / 32;
+    const long long n = (long long)Cin_pad * taps * groups;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ws = blockIdx.y;
+    if (idx >= n) return;
+    const int ci = (int)(idx % Cin_pad);
+    const long long r2 = idx / Cin_pad;
+    const int t = (int)(r2 % taps), q = (int)(r2 / taps);
+    const float sc = fb_pow2_scale(amax[ws]);
+    const float* src = master + (long long)ws * wset_stride_in + ((long long)(q * 32) * taps + t) * Cin_real + ci;
+    const long long cstride = (long long)taps * Cin_real;
+    unsigned hi[16], lo[16];
+#pragma unroll
+    for (int j = 0; j < 32; j += 2) {
+        const int v0 = 4 * (j >> 3) + (j & 3) + 16 * ((j >> 2) & 1), v1 = v0 + 1;
+        const float a = (ci < Cin_real ? src[v0 * cstride] : 0.f) * sc, b = (ci < Cin_real ? src[v1 * cstride] : 0.f) * sc;
+        hi[j >> 1] = pack_f16x2(a, b);
+        const f16x2_t hv = __builtin_bit_cast(f16x2_t, hi[j >> 1]);
+        lo[j >> 1] = pack_f16x2(a - (float)hv[0], b - (float)hv[1]);
+    }
+    uint4* dst = (uint4*)(w_dgrad + ((long long)ws * wset_stride_out + ((long long)ci * taps + t) * Cout + q * 32) * 2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[k] = make_uint4(hi[4 * k], hi[4 * k + 1], hi[4 * k + 2], hi[4 * k + 3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[4 + k] = make_uint4(lo[4 * k], lo[4 * k + 1], lo[4 * k + 2], lo[4 * k + 3]);
 }
 
 extern "C" int fb_weight_prep(const float* master, int64_t wset_stride_in, int64_t wset_stride_out, int32_t n_wsets, int32_t Cout, int32_t taps,
@@ -359,8 +397,14 @@ extern "C" int fb_weight_prep(const float* master, int64_t wset_stride_in, int64
     dim3 grid((unsigned)ceil_div64(per_set, 256), n_wsets);
     if (amax) {
         if (dtype != FB_F32 || Cin_pad % 32 != 0 || Cout % 32 != 0) FB_FAIL(FB_ERR_ARG, "fb_weight_prep: fp16x2 planes need fp32 copies and channels in multiples of 32");
-        hipLaunchKernelGGL(weight_prep_planes_kernel, grid, dim3(256), 0, (hipStream_t)stream, master, (long long)wset_stride_in, (long long)wset_stride_out,
-                           Cout, taps, Cin_real, Cin_pad, (_Float16*)w_fwd, (_Float16*)w_dgrad, amax);
+        const dim3 gf((unsigned)ceil_div64((long long)Cout * taps * (Cin_pad / 32), 256), n_wsets);
+        hipLaunchKernelGGL(weight_prep_planes_fwd_kernel, gf, dim3(256), 0, (hipStream_t)stream, master, (long long)wset_stride_in, (long long)wset_stride_out,
+                           Cout, taps, Cin_real, Cin_pad, (_Float16*)w_fwd, amax);
+        if (w_dgrad) {
+            const dim3 gd((unsigned)ceil_div64((long long)Cin_pad * taps * (Cout / 32), 256), n_wsets);
+            hipLaunchKernelGGL(weight_prep_planes_dgrad_kernel, gd, dim3(256), 0, (hipStream_t)stream, master, (long long)wset_stride_in,
+                               (long long)wset_stride_out, Cout, taps, Cin_real, Cin_pad, (_Float16*)w_dgrad, amax);
+        }
         FB_CHECK_LAUNCH("fb_weight_prep");
         return FB_OK;
     }
