@@ -52,6 +52,10 @@ template <int OFF> __device__ __forceinline__ uint4 h4_read16(unsigned byte_addr
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(OFF));
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
+__device__ __forceinline__ void h4_write16(unsigned byte_addr, const uint4& v) {
+    const h4_u32x4 d = {v.x, v.y, v.z, v.w};
+    asm volatile("ds_write_b128 %0, %1" ::"v"(byte_addr), "v"(d) : "memory");
+}
 template <int I, int N, typename F> __device__ __forceinline__ void h4_static_for(F&& f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); h4_static_for<I + 1, N>(f); }
 }
@@ -148,6 +152,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
 #pragma unroll
     for (int h = 0; h < 2; ++h) wa[h] = lds0 + HALO_BYTES + (lane & 15) * 128 + ((((lane >> 4) + 4 * h) ^ (lane & 7)) * 16);
 
+    // f32h: the halo slice is converted IN PLACE, once, from fp32 to fp16x2 planes (common.h) before its nine taps -- not per fragment and
+    // tap (32 VALU x 4 fragments x 9 taps per wave and slice before).  A 128-byte row holds the 16-byte chunks c = 0..7 of 32 channels at
+    // position c ^ (hx & 7); the lane group g of an MFMA step reads chunk g (channels 4g..4g+3) and chunk g + 4 (16+4g..), so the pair
+    // of positions (p, p + 4) is converted together: the high pieces of its eight values go where chunk g was, the low pieces where
+    // chunk g + 4 was, and the two fragment reads of a lane become its high and low operands.
+    constexpr int KI = is_hsplit<T>::value ? (NGRP * 8 * 4 + 255) / 256 : 1;
+    unsigned cvA[KI];
+    if constexpr (is_hsplit<T>::value) {
+#pragma unroll
+        for (int k = 0; k < KI; ++k) {
+            const int item = tid + 256 * k, row = item >> 2, pp = item & 3;
+            const int rr = row % G::IMG_ROWS, hx = rr % PITCH;
+            cvA[k] = row < G::ROWS ? (lds0 + row * 128 + pp * 16) | (((hx & 7) >> 2) & 1u) : 0xffffffffu;
+        }
+    }
+    float hs_src = 1.f, hs_inv = 1.f;                       // f32h: power-of-two scales of the tile's chunk and weight set
+    auto convert_halo = [&]() {
+        if constexpr (is_hsplit<T>::value) {
+#pragma unroll
+            for (int k = 0; k < KI; ++k) {
+                if (cvA[k] != 0xffffffffu) {
+                    const unsigned a = cvA[k] & ~1u, swap = cvA[k] & 1u;
+                    const uint4 A = h4_read16<0>(a), B = h4_read16<64>(a);
+                    h4_wait_lgkmcnt<0>();
+                    const split2h_t sp = swap ? split_h2x8(B, A, hs_src) : split_h2x8(A, B, hs_src);
+                    const uint4 hv = __builtin_bit_cast(uint4, sp.h), lv = __builtin_bit_cast(uint4, sp.l);
+                    h4_write16(swap ? a + 64 : a, hv);
+                    h4_write16(swap ? a : a + 64, lv);
+                }
+            }
+            h4_wait_lgkmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+        }
+    };
+
     // ---- tile bookkeeping (scalar; descriptors are rebuilt where they are needed to keep SGPR pressure low) ----------------
     auto decode = [&](int L) {
         H4Tile t;
@@ -204,7 +243,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
     // set by the per-CU load/store pipeline, not by idle workgroups.)
     int L = h4_xcd_remap(blockIdx.x, NB);
     if (L >= p.n_tiles) return;
-    float hs_src = 1.f, hs_inv = 1.f;                       // f32h: power-of-two scales of the tile's chunk and weight set
     auto scales_of = [&](const H4Tile& t) {
         if constexpr (is_hsplit<T>::value) {
             hs_src = fb_pow2_scale(p.amax_src[t.n0 / p.amax_imgs]);
@@ -228,6 +266,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
         scales_of(cur);
         h4_wait_vmcnt<0>();                                // halo slice 0 + weight taps 0, 1 (and the previous tile's stores)
         __builtin_amdgcn_s_barrier();
+        convert_halo();
         H4_STAMP(2);
 
         f32x4_t acc[FI][4];
@@ -254,9 +293,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
                 h4_static_for<0, 4>([&](auto j) { pf1[decltype(j)::value] = h4_read16<(A * PITCH + h4_frag_rows<W>(decltype(j)::value)) * 128>(pa[B][1]); });
                 if constexpr (is_hsplit<T>::value) {     // fp32 operands as two scaled fp16 pieces each, three MFMAs per fragment pair (common.h)
                     h4_wait_lgkmcnt<0>();
-                    split2h_t sp[4];
+                    split2h_t sp[4];                       // both reads of a fragment are operands already: the halo was converted in place
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) sp[j] = split_h2x8(pf0[j], pf1[j], hs_src);
+                    for (int j = 0; j < 4; ++j) { sp[j].h = __builtin_bit_cast(f16x8_t, pf0[j]); sp[j].l = __builtin_bit_cast(f16x8_t, pf1[j]); }
 #pragma unroll
                     for (int i = 0; i < FI; ++i) {
                         split2h_t sw;                          // the weights arrive as fp16x2 planes (fb_weight_prep)
@@ -293,6 +332,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
                         halo_issue(cur, cc + 1);
                         h4_wait_vmcnt<0>();
                         __builtin_amdgcn_s_barrier();
+                        convert_halo();
                     } else if (has_next) {
                         halo_issue(nxt, 0);               // lands during the epilogue; the loop top waits for it
                     }
