@@ -87,6 +87,50 @@ def test_resnet18_chunk_gradients_vs_oracle(dtype, gtol, ltol):
     assert rel_err(mean0.numpy(), xs.mean((0, 2, 3)).numpy()) < (1e-4 if dtype == torch.float32 else 3e-2)
 
 
+@pytest.mark.parametrize("split", ["bf16x6", "f16x2"])
+def test_f32_split_modes_regularised_mean_gradient_vs_oracle(split, monkeypatch):
+    """Both arithmetic modes of the fp32 convolutions (three bf16 pieces / six MFMAs, two scaled fp16 pieces / three MFMAs)
+    through the whole engine: raw chunk gradients and the finite-difference regularised MEAN gradient of three chunks (both passes in the
+    same arithmetic, per-chunk scales) against the float64 oracle.  The regulariser's own truncation error (a few 1e-2 even in fp32)
+    hides the 2^-22 operand rounding of f16x2; a raw chunk gradient of the freshly initialised net is a cancelling sum on the fp32 noise
+    floor in either mode (the reference's own fp32 run: 3e-3 from its float64 run)."""
+    from oracle import fb_oracle as orc
+    monkeypatch.setenv("FB_F32_SPLIT", split)
+    pixels, chunk, G = 16, 32, 3
+    cfg, model, eng, stem_patches = _build(18, pixels, chunk, G, torch.float32, fd_sets=1)
+    assert eng.f32_split == split
+    x, y = make_data(chunk * G, pixels)
+    truth, _, _ = _oracle_chunk_grads(model, x, y, chunk)
+    patches = stem_patches(x.cuda(), eng.plan.stem, torch.float32)
+    eng.prep_weights(eng.theta, 1)
+    eng.group_gradient(patches, y.cuda(), G, eng.g)
+    got = _engine_grads_as_lists(eng, G)
+    for g in range(G):
+        a = torch.cat([t.reshape(-1).double() for t in got[g]])
+        t = torch.cat([r.reshape(-1).double() for r in truth[g][0]])
+        err = float((a - t).norm() / t.norm())
+        print(f"[{split}] raw chunk {g}: engine-vs-f64 {err:.3e}")
+        assert err < 1e-2 and float((a * t).sum() / (a.norm() * t.norm())) > 0.99999      # (the reference's own fp32 run: 3e-3)
+    # regularised mean gradient (forward differences, block_strength 0.5, lr 0.1)
+    spec = orc.Spec(18)
+    state = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+    params, buffers = orc.split_state(state)
+    mean = None
+    for k in range(G):
+        xk, yk = x[k * chunk:(k + 1) * chunk].double(), y[k * chunk:(k + 1) * chunk]
+        raw, _, _ = orc.chunk_gradient(spec, params, buffers, xk, yk)
+        reg = orc.gradreg(spec, params, buffers, [g.clone() for g in raw], xk, yk, 0.1, 0.5, 1e-2, "forward-differences")
+        flat = torch.cat([t.reshape(-1) for t in reg])
+        mean = flat / G if mean is None else mean + flat / G
+    eng.full_gradient(patches, y.cuda(), 0.1, block_strength=0.5, eps=1e-2, implementation="forward-differences")
+    torch.cuda.synchronize()
+    names = eng.plan.param_names
+    avg = torch.cat([eng._unflatten(eng.avg.cpu(), n).reshape(-1).double() for n in names])
+    err = float((avg - mean).norm() / mean.norm())
+    print(f"[{split}] regularised mean gradient of {G} chunks: engine-vs-f64 oracle {err:.3e}")
+    assert err < 5e-2
+
+
 def test_golden_reference_chunk_gradient_f32(golden):
     """Engine (f32) vs vectors of the REAL reference: fb_plain chunk 0 (128 images, 32x32) raw gradient sample + scalars."""
     data, meta = golden
