@@ -81,13 +81,26 @@ template <> __device__ __forceinline__ void frag_halo<bf16_tag, 8>(const char* t
                         ((unsigned)(unsigned short)hi[0]) | ((unsigned)(unsigned short)hi[1] << 16),
                         ((unsigned)(unsigned short)hi[2]) | ((unsigned)(unsigned short)hi[3] << 16));
 }
+// 4x4 maps: a K-step holds four whole images (6x6 halo each); a lane group's 8 pixels are two image rows of one image
+template <> __device__ __forceinline__ void frag_halo<bf16_tag, 4>(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) {
+    const int t = lane & 15, g = lane >> 4;
+    const int p = pb + g * 8 + (t >> 2), q = p & 15;
+    const char* a0 = tile + ((p >> 4) * 36 + ((q >> 2) + r) * 6 + (q & 3) + s) * row_bytes + (c0 + (t & 3) * 4) * 2;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0 + 6 * row_bytes));
+    out[0] = make_uint4(((unsigned)(unsigned short)lo[0]) | ((unsigned)(unsigned short)lo[1] << 16),
+                        ((unsigned)(unsigned short)lo[2]) | ((unsigned)(unsigned short)lo[3] << 16),
+                        ((unsigned)(unsigned short)hi[0]) | ((unsigned)(unsigned short)hi[1] << 16),
+                        ((unsigned)(unsigned short)hi[2]) | ((unsigned)(unsigned short)hi[3] << 16));
+}
 template <int W> __device__ __forceinline__ void frag_halo_f32(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) {
     const int t = lane & 15, g = lane >> 4;
     unsigned v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int p = pb + g + 4 * e;
-        v[e] = *(const unsigned*)(tile + ((p / W + r) * (W + 2) + (p % W) + s) * row_bytes + (c0 + t) * 4);
+        if constexpr (W == 4) v[e] = *(const unsigned*)(tile + ((p >> 4) * 36 + (((p & 15) >> 2) + r) * 6 + (p & 3) + s) * row_bytes + (c0 + t) * 4);
+        else v[e] = *(const unsigned*)(tile + ((p / W + r) * (W + 2) + (p % W) + s) * row_bytes + (c0 + t) * 4);
     }
     out[0] = make_uint4(v[0], v[1], v[2], v[3]);
     out[1] = make_uint4(v[4], v[5], v[6], v[7]);
@@ -95,12 +108,15 @@ template <int W> __device__ __forceinline__ void frag_halo_f32(const char* tile,
 template <> __device__ __forceinline__ void frag_halo<float, 32>(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) { frag_halo_f32<32>(tile, row_bytes, pb, r, s, c0, lane, out); }
 template <> __device__ __forceinline__ void frag_halo<float, 16>(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) { frag_halo_f32<16>(tile, row_bytes, pb, r, s, c0, lane, out); }
 template <> __device__ __forceinline__ void frag_halo<float, 8>(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) { frag_halo_f32<8>(tile, row_bytes, pb, r, s, c0, lane, out); }
+template <> __device__ __forceinline__ void frag_halo<float, 4>(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) { frag_halo_f32<4>(tile, row_bytes, pb, r, s, c0, lane, out); }
 
 template <typename T, int W>
 __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p) {
     constexpr int EB = ET<T>::EB;
-    constexpr int RS = 64 / W;                       // image rows per K-step (64 pixels)
-    constexpr int HROWS = (RS + 2) * (W + 2);        // halo pixels per K-step
+    constexpr int IMGS = W == 4 ? 4 : 1;             // whole images per K-step (4x4 maps: four)
+    constexpr int RS = 64 / (W * IMGS);              // image rows per K-step and image (64 pixels)
+    constexpr int IMG_ROWS = (RS + 2) * (W + 2);     // halo pixels of one image part
+    constexpr int HROWS = IMGS * IMG_ROWS;           // halo pixels per K-step
     constexpr int ROW = 64 * EB + W3<T>::PAD;        // LDS row: 64 channels + pad
     constexpr int CH = 64 * EB / 16;                 // 16-byte chunks per row
     constexpr int LD_A = 64 * CH / 256;              // dY chunks per thread
@@ -126,7 +142,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p
     const int img0 = group * p.imgs_per_group + split * p.imgs_per_block;
     const int img_end = min(img0 + p.imgs_per_block, (group + 1) * p.imgs_per_group);
     const int steps_per_img = p.H / RS;
-    const int n_steps = (img_end - img0) * steps_per_img;
+    const int n_steps = IMGS > 1 ? (img_end - img0 + IMGS - 1) / IMGS : (img_end - img0) * steps_per_img;   // (a ragged last step reads zeros)
 
     f32x4_t acc[9][4];
 #pragma unroll
@@ -136,12 +152,13 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p
 
     uint4 ra[LD_A], rb[LD_B];
     auto gload = [&](int step) {
-        const int img = img0 + step / steps_per_img, y0 = (step % steps_per_img) * RS;
+        const int img = IMGS > 1 ? img0 + step * IMGS : img0 + step / steps_per_img, y0 = IMGS > 1 ? 0 : (step % steps_per_img) * RS;
         const char* dyb = p.dy + (((long long)img * p.H + y0) * W * p.Cd + tile_m * 64) * EB;
 #pragma unroll
         for (int i = 0; i < LD_A; ++i) {
             const int id = tid + 256 * i, row = id / CH, ch = id % CH;
-            ra[i] = *(const uint4*)(dyb + (long long)row * p.Cd * EB + ch * 16);
+            ra[i] = make_uint4(0, 0, 0, 0);
+            if (IMGS == 1 || img + row / (W * W) < img_end) ra[i] = *(const uint4*)(dyb + (long long)row * p.Cd * EB + ch * 16);
         }
         const char* xb = p.x + ((long long)img * p.H * W * p.Cs + tile_n * 64) * EB;
 #pragma unroll
@@ -149,10 +166,11 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p
             const int id = tid + 256 * i, row = id / CH, ch = id % CH;
             rb[i] = make_uint4(0, 0, 0, 0);
             if (row < HROWS) {
-                const int hy = row / (W + 2), hx = row - hy * (W + 2);
+                const int img_l = row / IMG_ROWS, rr = row - img_l * IMG_ROWS;
+                const int hy = rr / (W + 2), hx = rr - hy * (W + 2);
                 const int sy = y0 + hy - 1, sx = hx - 1;
-                if ((unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)W)
-                    rb[i] = *(const uint4*)(xb + (long long)(sy * W + sx) * p.Cs * EB + ch * 16);
+                if ((unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)W && img + img_l < img_end)
+                    rb[i] = *(const uint4*)(xb + ((long long)img_l * p.H * W + sy * W + sx) * p.Cs * EB + ch * 16);
             }
         }
     };
@@ -249,7 +267,7 @@ int fb_try_wgrad3x3(const fb_wgrad_args* a, hipStream_t st) {
     if (a->R != 3 || a->S != 3 || a->stride != 1 || a->pad != 1) return 0;
     if (a->Hs != a->Hd || a->Ws != a->Wd || a->Hs != a->Ws) return 0;
     const int W = a->Ws;
-    if (W != 32 && W != 16 && W != 8) return 0;               // (8x8: one whole image per 64-pixel K-step)
+    if (W != 32 && W != 16 && W != 8 && W != 4) return 0;     // (8x8: one whole image per 64-pixel K-step, 4x4: four)
     if (a->Cs % 64 != 0 || a->Cd % 64 != 0) return 0;
     Wgrad3Params p;
     p.x = (const char*)a->x; p.dy = (const char*)a->dy; p.out = a->dw_partial;
@@ -262,19 +280,23 @@ int fb_try_wgrad3x3(const fb_wgrad_args* a, hipStream_t st) {
     if (a->dtype == FB_F32 && a->amax_x && a->amax_dy) {
         if (W == 32) hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32h_tag, 32>), grid, dim3(256), 0, st, p);
         else if (W == 16) hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32h_tag, 16>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32h_tag, 8>), grid, dim3(256), 0, st, p);
+        else if (W == 8) hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32h_tag, 8>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32h_tag, 4>), grid, dim3(256), 0, st, p);
     } else if (a->dtype == FB_F32 && fb_f32_split_enabled()) {
         if (W == 32) hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32s_tag, 32>), grid, dim3(256), 0, st, p);
         else if (W == 16) hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32s_tag, 16>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32s_tag, 8>), grid, dim3(256), 0, st, p);
+        else if (W == 8) hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32s_tag, 8>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32s_tag, 4>), grid, dim3(256), 0, st, p);
     } else if (a->dtype == FB_F32) {
         if (W == 32) hipLaunchKernelGGL((conv_wgrad3x3_kernel<float, 32>), grid, dim3(256), 0, st, p);
         else if (W == 16) hipLaunchKernelGGL((conv_wgrad3x3_kernel<float, 16>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv_wgrad3x3_kernel<float, 8>), grid, dim3(256), 0, st, p);
+        else if (W == 8) hipLaunchKernelGGL((conv_wgrad3x3_kernel<float, 8>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wgrad3x3_kernel<float, 4>), grid, dim3(256), 0, st, p);
     } else {
         if (W == 32) hipLaunchKernelGGL((conv_wgrad3x3_kernel<bf16_tag, 32>), grid, dim3(256), 0, st, p);
         else if (W == 16) hipLaunchKernelGGL((conv_wgrad3x3_kernel<bf16_tag, 16>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv_wgrad3x3_kernel<bf16_tag, 8>), grid, dim3(256), 0, st, p);
+        else if (W == 8) hipLaunchKernelGGL((conv_wgrad3x3_kernel<bf16_tag, 8>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wgrad3x3_kernel<bf16_tag, 4>), grid, dim3(256), 0, st, p);
     }
     return 1;
 }
