@@ -93,6 +93,21 @@ template <> __device__ __forceinline__ void frag_halo<bf16_tag, 4>(const char* t
                         ((unsigned)(unsigned short)hi[0]) | ((unsigned)(unsigned short)hi[1] << 16),
                         ((unsigned)(unsigned short)hi[2]) | ((unsigned)(unsigned short)hi[3] << 16));
 }
+// stride 2 (fp16x2 planes only): output pixel (py, px) of the step reads halo row (2 py + r) * (2 W + 1) + 2 px + s; the 8 pixels of a lane
+// group are one output row segment (W >= 8: +4 pixels = +8 halo columns) or two output rows of a 4x4 map
+template <int W> __device__ __forceinline__ void frag_halo_s2(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) {
+    constexpr int PW = 2 * W + 1, RS = W == 4 ? 4 : 64 / W, IMG_ROWS = (2 * RS + 1) * PW;
+    const int t = lane & 15, g = lane >> 4;
+    const int p = pb + g * 8 + (t >> 2);
+    const int img_l = W == 4 ? p >> 4 : 0, q = W == 4 ? p & 15 : p;
+    const char* a0 = tile + (img_l * IMG_ROWS + (2 * (q / W) + r) * PW + 2 * (q % W) + s) * row_bytes + (c0 + (t & 3) * 4) * 2;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0 + (W == 4 ? 2 * PW : 8) * row_bytes));
+    out[0] = make_uint4(((unsigned)(unsigned short)lo[0]) | ((unsigned)(unsigned short)lo[1] << 16),
+                        ((unsigned)(unsigned short)lo[2]) | ((unsigned)(unsigned short)lo[3] << 16),
+                        ((unsigned)(unsigned short)hi[0]) | ((unsigned)(unsigned short)hi[1] << 16),
+                        ((unsigned)(unsigned short)hi[2]) | ((unsigned)(unsigned short)hi[3] << 16));
+}
 template <int W> __device__ __forceinline__ void frag_halo_f32(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) {
     const int t = lane & 15, g = lane >> 4;
     unsigned v[8];
@@ -110,13 +125,17 @@ template <> __device__ __forceinline__ void frag_halo<float, 16>(const char* til
 template <> __device__ __forceinline__ void frag_halo<float, 8>(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) { frag_halo_f32<8>(tile, row_bytes, pb, r, s, c0, lane, out); }
 template <> __device__ __forceinline__ void frag_halo<float, 4>(const char* tile, int row_bytes, int pb, int r, int s, int c0, int lane, uint4 (&out)[2]) { frag_halo_f32<4>(tile, row_bytes, pb, r, s, c0, lane, out); }
 
-template <typename T, int W>
+// W = OUTPUT map width (p.H = output height); SD = 2 (fp16x2 planes only): stride-2 layers, the halo holds the 2 RS + 1 input rows and
+// 2 W + 1 input columns the step's 64 output pixels touch (the per-tap kernel re-read dY nine times there: 111-217 fp32-TFLOP/s)
+template <typename T, int W, int SD = 1>
 __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p) {
     constexpr int EB = ET<T>::EB;
     constexpr int IMGS = W == 4 ? 4 : 1;             // whole images per K-step (4x4 maps: four)
-    constexpr int RS = 64 / (W * IMGS);              // image rows per K-step and image (64 pixels)
-    constexpr int IMG_ROWS = (RS + 2) * (W + 2);     // halo pixels of one image part
+    constexpr int RS = 64 / (W * IMGS);              // output rows per K-step and image (64 pixels)
+    constexpr int PW = SD == 1 ? W + 2 : 2 * W + 1, PH = SD == 1 ? RS + 2 : 2 * RS + 1;   // halo columns / rows of one image part
+    constexpr int IMG_ROWS = PH * PW;                // halo pixels of one image part
     constexpr int HROWS = IMGS * IMG_ROWS;           // halo pixels per K-step
+    static_assert(SD == 1 || is_hsplit<T>::value, "stride 2 is built for the fp16x2 planes only");
     constexpr int ROW = 64 * EB + W3<T>::PAD;        // LDS row: 64 channels + pad
     constexpr int CH = 64 * EB / 16;                 // 16-byte chunks per row
     constexpr int LD_A = 64 * CH / 256;              // dY chunks per thread
@@ -160,17 +179,19 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p
             ra[i] = make_uint4(0, 0, 0, 0);
             if (IMGS == 1 || img + row / (W * W) < img_end) ra[i] = *(const uint4*)(dyb + (long long)row * p.Cd * EB + ch * 16);
         }
-        const char* xb = p.x + ((long long)img * p.H * W * p.Cs + tile_n * 64) * EB;
+        const int Hi = SD * p.H;                                  // input map: Hi x WI
+        constexpr int WI = SD * W;
+        const char* xb = p.x + ((long long)img * Hi * WI * p.Cs + tile_n * 64) * EB;
 #pragma unroll
         for (int i = 0; i < LD_B; ++i) {
             const int id = tid + 256 * i, row = id / CH, ch = id % CH;
             rb[i] = make_uint4(0, 0, 0, 0);
             if (row < HROWS) {
                 const int img_l = row / IMG_ROWS, rr = row - img_l * IMG_ROWS;
-                const int hy = rr / (W + 2), hx = rr - hy * (W + 2);
-                const int sy = y0 + hy - 1, sx = hx - 1;
-                if ((unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)W && img + img_l < img_end)
-                    rb[i] = *(const uint4*)(xb + ((long long)img_l * p.H * W + sy * W + sx) * p.Cs * EB + ch * 16);
+                const int hy = rr / PW, hx = rr - hy * PW;
+                const int sy = SD * y0 + hy - 1, sx = hx - 1;
+                if ((unsigned)sy < (unsigned)Hi && (unsigned)sx < (unsigned)WI && img + img_l < img_end)
+                    rb[i] = *(const uint4*)(xb + ((long long)img_l * Hi * WI + sy * WI + sx) * p.Cs * EB + ch * 16);
             }
         }
     };
@@ -221,7 +242,11 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p
                 for (int t = 0; t < 9; ++t) {
                     uint4 bp[NPL];
 #pragma unroll
-                    for (int pl = 0; pl < NPL; ++pl) { frag_halo<bf16_tag, W>(tileB + pl * PLANE_B, PROW, pb, t / 3, t % 3, wave * 16, lane, tmp); bp[pl] = tmp[0]; }
+                    for (int pl = 0; pl < NPL; ++pl) {
+                        if constexpr (SD == 2) frag_halo_s2<W>(tileB + pl * PLANE_B, PROW, pb, t / 3, t % 3, wave * 16, lane, tmp);
+                        else frag_halo<bf16_tag, W>(tileB + pl * PLANE_B, PROW, pb, t / 3, t % 3, wave * 16, lane, tmp);
+                        bp[pl] = tmp[0];
+                    }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         if constexpr (HSPLIT) acc[t][i] = mma_planes3h_acc(ap[i], bp, acc[t][i]);
@@ -229,6 +254,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p
                     }
                 }
             } else {
+            if constexpr (SD == 1) {
             uint4 af[4][2];
 #pragma unroll
             for (int i = 0; i < 4; ++i) frag_plain<T>(tileA, ROW, pb, i * 16, lane, af[i]);
@@ -241,6 +267,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p
                     acc[t][i] = mma_chunk<T>(af[i][0], bf[0], acc[t][i]);
                     if constexpr (EB == 4) acc[t][i] = mma_chunk<T>(af[i][1], bf[1], acc[t][i]);
                 }
+            }
             }
             }
         }
@@ -264,19 +291,26 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_kernel(const Wgrad3Params p
 int fb_try_wgrad3x3(const fb_wgrad_args* a, hipStream_t st) {
     static const bool disabled = getenv("FB_DISABLE_WGRAD3") != nullptr;
     if (disabled) return 0;
-    if (a->R != 3 || a->S != 3 || a->stride != 1 || a->pad != 1) return 0;
-    if (a->Hs != a->Hd || a->Ws != a->Wd || a->Hs != a->Ws) return 0;
-    const int W = a->Ws;
+    if (a->R != 3 || a->S != 3 || (a->stride != 1 && a->stride != 2) || a->pad != 1) return 0;
+    if (a->Hs != a->stride * a->Hd || a->Ws != a->stride * a->Wd || a->Hd != a->Wd) return 0;
+    const int W = a->Wd;                                      // OUTPUT map width
+    if (a->stride == 2 && !(a->dtype == FB_F32 && a->amax_x && a->amax_dy && (W == 16 || W == 8 || W == 4))) return 0;   // stride 2: fp16x2 planes only
     if (W != 32 && W != 16 && W != 8 && W != 4) return 0;     // (8x8: one whole image per 64-pixel K-step, 4x4: four)
     if (a->Cs % 64 != 0 || a->Cd % 64 != 0) return 0;
     Wgrad3Params p;
     p.x = (const char*)a->x; p.dy = (const char*)a->dy; p.out = a->dw_partial;
     p.group_stride = a->group_stride ? a->group_stride : (long long)a->split_k * a->Cd * 9 * a->Cs;
-    p.n_img = a->n_img; p.H = a->Hs; p.Cs = a->Cs; p.Cd = a->Cd;
+    p.n_img = a->n_img; p.H = a->Hd; p.Cs = a->Cs; p.Cd = a->Cd;
     p.imgs_per_group = a->imgs_per_group; p.split_k = a->split_k; p.imgs_per_block = (a->imgs_per_group + a->split_k - 1) / a->split_k;   // ragged last K slice allowed
     p.amax_x = a->amax_x; p.amax_dy = a->amax_dy;
     const int n_groups = a->n_img / a->imgs_per_group;
     dim3 grid((a->Cd / 64) * (a->Cs / 64), n_groups * a->split_k);
+    if (a->stride == 2) {
+        if (W == 16) hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32h_tag, 16, 2>), grid, dim3(256), 0, st, p);
+        else if (W == 8) hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32h_tag, 8, 2>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32h_tag, 4, 2>), grid, dim3(256), 0, st, p);
+        return 1;
+    }
     if (a->dtype == FB_F32 && a->amax_x && a->amax_dy) {
         if (W == 32) hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32h_tag, 32>), grid, dim3(256), 0, st, p);
         else if (W == 16) hipLaunchKernelGGL((conv_wgrad3x3_kernel<f32h_tag, 16>), grid, dim3(256), 0, st, p);

@@ -240,17 +240,17 @@ class Engine:
         self.var_tab = torch.zeros(self.n_passes, self.G, self.plan.ch_total, **f32)
         self._unbias_tabs = {}
         self.unbias = self._unbias_for(self.valid)
+        # fp32 convolutions: "f16x2" (two scaled fp16 pieces per operand, three MFMAs per product; needs the largest magnitude of every
+        # operand tensor: fb_absmax, cached per tensor below), "bf16x6" (three bf16 pieces, six MFMAs); FB_F32_EXACT=1 in the library: exact f32
+        # Default: f16x2 for the finite-difference regulariser (its own truncation error, 3.5e-2 in fp32, hides the 2^-22 operand rounding:
+        # the float64 oracle with 22-bit operands gives 3.7e-2), bf16x6 for plain fp32 training (held to the tighter fp32-vs-float64 traces)
+        self.f32_split = os.environ.get("FB_F32_SPLIT", "f16x2" if fd_sets else "bf16x6") if compute_dtype == torch.float32 else None
         self._alloc_activations()
         self.mt_ws = torch.zeros(lib.load().fb_ws_mt_floats(self.G), **f32)
         self.sq = torch.zeros(self.G, **f32)
         self.vnorm2 = torch.zeros(self.G, **f32)
         self.eps_n = torch.zeros(self.G, **f32)
         self.norms2 = torch.zeros(2, **f32)
-        # fp32 convolutions: "f16x2" (two scaled fp16 pieces per operand, three MFMAs per product; needs the largest magnitude of every
-        # operand tensor: fb_absmax, cached per tensor below), "bf16x6" (three bf16 pieces, six MFMAs); FB_F32_EXACT=1 in the library: exact f32
-        # Default: f16x2 for the finite-difference regulariser (its own truncation error, 3.5e-2 in fp32, hides the 2^-22 operand rounding:
-        # the float64 oracle with 22-bit operands gives 3.7e-2), bf16x6 for plain fp32 training (held to the tighter fp32-vs-float64 traces)
-        self.f32_split = os.environ.get("FB_F32_SPLIT", "f16x2" if fd_sets else "bf16x6") if compute_dtype == torch.float32 else None
         # one scale per CHUNK and tensor (a chunk's arithmetic must not depend on how chunks are batched or sharded): slots of G floats
         self.amax_buf = torch.zeros(256, self.G, device=self.device, dtype=torch.float32)
         self.amax_map, self.amax_next = {}, 0
@@ -325,7 +325,7 @@ class Engine:
     def _choose_split(self, L):
         """Split the pixel reduction of wgrad so that >= ~1000 workgroups exist; slices are multiples of the K-step."""
         bf16 = self.dt == torch.bfloat16
-        widths = (4, 8, 16, 32) if L.stride == 1 else ((4, 8, 16) if bf16 else ())
+        widths = (4, 8, 16, 32) if L.stride == 1 else ((4, 8, 16) if (bf16 or self.f32_split == "f16x2") else ())
         if (L.R == 3 and L.stride in (1, 2) and L.pad == 1 and L.hout == L.wout and L.hin == L.stride * L.hout and L.wout in widths
                 and L.cin_pad % 64 == 0 and L.cout % 64 == 0 and not (L.wout == 4 and self.chunk % 2)):
             # all-taps halo wgrad kernel: split-K over whole images (pairs for 4x4 maps); any split works (ragged last slice).

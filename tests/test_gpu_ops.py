@@ -201,7 +201,8 @@ def test_conv_wgrad(dtype, cin, cout, k, stride, hw, ipg, groups, split):
 @pytest.mark.parametrize("magnitude", [1.0, 2e-6])
 @pytest.mark.parametrize("cin,cout,k,stride,hw,ipg,groups,split", [(64, 64, 3, 1, 8, 8, 2, 3), (64, 128, 3, 2, 8, 8, 1, 2), (256, 256, 3, 1, 4, 16, 2, 1),
                                                                   (128, 256, 1, 1, 4, 16, 1, 2), (32, 64, 1, 1, 8, 4, 2, 1), (64, 64, 3, 1, 32, 4, 2, 2),
-                                                                  (128, 64, 3, 1, 16, 4, 2, 4), (64, 64, 3, 1, 16, 10, 2, 3), (128, 64, 3, 1, 8, 6, 2, 2), (256, 256, 3, 1, 8, 16, 1, 1), (64, 128, 3, 1, 4, 8, 2, 2), (64, 64, 3, 1, 4, 6, 1, 3), (512, 512, 3, 1, 4, 16, 2, 1)])
+                                                                  (128, 64, 3, 1, 16, 4, 2, 4), (64, 64, 3, 1, 16, 10, 2, 3), (128, 64, 3, 1, 8, 6, 2, 2), (256, 256, 3, 1, 8, 16, 1, 1), (64, 128, 3, 1, 4, 8, 2, 2), (64, 64, 3, 1, 4, 6, 1, 3), (512, 512, 3, 1, 4, 16, 2, 1),
+                                                                  (64, 128, 3, 2, 32, 4, 2, 2), (128, 64, 3, 2, 16, 6, 1, 3), (64, 64, 3, 2, 8, 8, 2, 2), (128, 128, 3, 2, 16, 5, 1, 1)])   # stride 2, all taps
 def test_conv_wgrad_f32_fp16x2_split(cin, cout, k, stride, hw, ipg, groups, split, magnitude):
     """Weight gradients of fp32 tensors on the fp16 matrix pipe (fb_wgrad_args.amax_x / amax_dy): two scaled fp16 planes per operand, three
     MFMAs per product; against float64, with gradients of realistic (tiny) magnitude, next to the six-product bf16 path."""
