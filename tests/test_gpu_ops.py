@@ -640,6 +640,41 @@ def test_conv_dgrad_fused_bn_backward_reduction(C, hw, amode):
     assert rel(outs[1][1], outs[0][1]) < 2e-5
 
 
+def test_fused_reduction_and_amax_fallbacks_are_loud_or_exact():
+    """The optional fused paths say so when a shape is not theirs: fb_conv_bwd_stat_supported is 0 for fp32 / stride 2 / 1x1 calls and fb_conv2d
+    then refuses bst_x instead of ignoring it; fb_bn_apply's amax_out takes the separate fb_absmax pass when the channel count does not fit
+    the span kernel (C = 96) and still returns the exact per-group maxima; amax_out on bf16 tensors is refused."""
+    lib = _lib()
+    torch.manual_seed(5)
+    n, hw, C = 4, 8, 128
+    dy = torch.randn(n, hw, hw, C, device="cuda")
+    wt = torch.randn(C, 9, C, device="cuda") * 0.05
+    x = torch.randn(n, hw, hw, C, device="cuda")
+    bits = torch.randint(0, 256, (n * hw * hw * C // 8,), device="cuda", dtype=torch.uint8)
+    part = torch.zeros(2, n * hw * hw // 128, C, device="cuda")
+    with pytest.raises(lib.EngineError):                                        # fp32: not implemented, and loudly so
+        lib.conv2d(dy, wt, torch.empty_like(dy), 3, 3, 1, 1, 1, stat_partial=part, bst_x=x, bst_mask=bits)
+    a = lib.ConvArgs(dy.data_ptr(), wt.data_ptr(), dy.data_ptr(), None, part.data_ptr(), n, hw, hw, C, hw, hw, C, 1, 1, 1, 0, 1, 0, 0, 0,
+                     lib.dtype_code(torch.bfloat16), None, x.data_ptr(), bits.data_ptr(), None, None, 0)
+    assert lib.load().fb_conv_bwd_stat_supported(lib.C.byref(a)) == 0          # 1x1: no fused reduction
+    # amax_out through the grid-stride form of fb_bn_apply (C = 96: 24 vectors per pixel do not divide 256)
+    C2, groups, ipg = 96, 2, 4
+    px, ppg = groups * ipg * hw * hw, ipg * hw * hw
+    x2 = torch.randn(px, C2, device="cuda") * 3
+    y2 = torch.empty_like(x2)
+    scale, shift = torch.rand(groups, C2, device="cuda") + 0.5, torch.randn(groups, C2, device="cuda")
+    amax = torch.zeros(groups, device="cuda")
+    ws = torch.zeros(int(lib.load().fb_ws_bn_amax_floats(px, C2, ppg)) + 1, device="cuda")
+    lib.call("fb_bn_apply", x2.data_ptr(), y2.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, None, None, px, C2, ppg, 0, 1, None, None, 0,
+             lib.dtype_code(torch.float32), amax.data_ptr(), ws.data_ptr())
+    ref = torch.relu(x2.view(groups, -1, C2) * scale[:, None] + shift[:, None])
+    assert torch.allclose(y2.view(groups, -1, C2), ref, rtol=1e-6, atol=1e-6) and torch.equal(amax, y2.reshape(groups, -1).abs().max(1).values)
+    with pytest.raises(lib.EngineError):
+        xb = x2[:, :64].contiguous().bfloat16()
+        lib.call("fb_bn_apply", xb.data_ptr(), torch.empty_like(xb).data_ptr(), scale.data_ptr(), shift.data_ptr(), None, None, None, px, 64, ppg, 0, 1,
+                 None, None, 0, lib.dtype_code(torch.bfloat16), amax.data_ptr(), ws.data_ptr())
+
+
 def test_engine_per_tensor_weight_decay_matches_torch_sgd():
     """Engine.sgd_step_per_tensor (hyp.only_linear_layers_weight_decay) vs torch.optim.SGD with one param group per tensor, two steps
     (first-step momentum initialisation included)."""
