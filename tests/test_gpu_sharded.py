@@ -140,8 +140,10 @@ def test_rccl_collectives_one_rank(tmp_path, monkeypatch):
             assert got["stats"][key] == ref["stats"][key], (mode, key)
         # (with an early bucket |g_k|^2 is the sum of two partial sums: last-bit differences in the recorded chunk norms only)
         assert np.allclose(got["stats"]["grad_norm"], ref["stats"]["grad_norm"], rtol=0 if mode is False else 1e-6), mode
+        # p.grad = the CLIPPED mean gradient: the clip norm is the sum of the exchange's two bucket norms here and one reduction over the
+        # whole arena in the plain step -- the same number up to the association of the last addition, i.e. the scale may differ by one ulp
         for a, b in zip(got["grads"], ref["grads"]):
-            assert torch.equal(a, b), mode
+            assert torch.allclose(a, b, rtol=5e-7, atol=0), mode
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL wants one device per rank")
