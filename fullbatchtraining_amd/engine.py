@@ -326,13 +326,14 @@ class Engine:
     # to run: the number of slices fixes the order in which a chunk's pixels are summed, and a chunk's gradient must not depend on how
     # chunks are batched or sharded (the 2-rank == 1-process tests).  Same-box A/B (ms/step at 390 chunks | at a rank's 49 chunks of an
     # 8-GPU job): nominal 49: 244.6 | 31.76, 70: 242.4 | 31.64, 98: 240.3 | 32.08.
-    # fp32 engines run groups of at most 63 chunks (2^31-byte tensors): their nominal group is 49 (config 3: 1412 vs 1477 ms/step with 98).
+    # fp32 engines run groups of at most 63 chunks (2^31-byte tensors; 390 chunks = 7 x 56): their nominal group is 56 (config 3, same box:
+    # nominal 49: 1483, 56: 1455, 64: 1458, 98: +65 ms/step).
     NOMINAL_GROUP = int(os.environ.get("FB_NOMINAL_GROUP", "0"))
 
     def _choose_split(self, L):
         """Split the pixel reduction of wgrad so that >= ~1000 workgroups exist; slices are multiples of the K-step."""
         bf16 = self.dt == torch.bfloat16
-        G = self.NOMINAL_GROUP or (98 if bf16 else 49)
+        G = self.NOMINAL_GROUP or (98 if bf16 else 56)
         widths = (4, 8, 16, 32) if L.stride == 1 else ((4, 8, 16) if (bf16 or self.f32_split == "f16x2") else ())
         if (L.R == 3 and L.stride in (1, 2) and L.pad == 1 and L.hout == L.wout and L.hin == L.stride * L.hout and L.wout in widths
                 and L.cin_pad % 64 == 0 and L.cout % 64 == 0 and not (L.wout == 4 and self.chunk % 2)):
