@@ -194,7 +194,7 @@ class _Pool:
 
 class Engine:
     def __init__(self, model, pixels, chunk, max_groups, compute_dtype=torch.bfloat16, device="cuda", fd_sets=0, arena_align=64,
-                 chunk_valid=None):
+                 chunk_valid=None, nominal_group=None):
         """``fd_sets``: extra per-chunk gradient/parameter sets for finite differences (0 none, 1 forward, 2 central).
         ``chunk``: images per statistics group AS STORED; ``chunk_valid`` (default ``chunk``): the real images of a chunk.  A chunk size
         whose pixels do not fill whole 128-pixel statistics blocks on every feature map (e.g. data.batch_size=125) is stored padded
@@ -208,6 +208,9 @@ class Engine:
         self.dtc = lib.dtype_code(compute_dtype)
         self.plan = Plan(model, pixels, arena_align)
         self.chunk, self.G = chunk, max_groups
+        # the chunk group the weight-gradient K-slice counts are sized for: a property of the GLOBAL problem (all ranks and the 1-process run
+        # pass the same number), never of the group this engine happens to run -- see _choose_split
+        self.nominal_group = int(os.environ.get("FB_NOMINAL_GROUP", "0")) or int(nominal_group or max_groups)
         self.valid = chunk if chunk_valid is None else int(chunk_valid)
         if not 0 < self.valid <= chunk:
             raise lib.EngineError(f"chunk_valid={chunk_valid} outside (0, {chunk}]")
@@ -322,18 +325,14 @@ class Engine:
         self.loss = torch.zeros(self.G, **f32)
         self.correct = torch.zeros(self.G, **f32)
 
-    # K-slice counts are chosen for a NOMINAL group of 98 chunks (the benchmark's group on one GPU), never for the group the engine happens
-    # to run: the number of slices fixes the order in which a chunk's pixels are summed, and a chunk's gradient must not depend on how
-    # chunks are batched or sharded (the 2-rank == 1-process tests).  Same-box A/B (ms/step at 390 chunks | at a rank's 49 chunks of an
-    # 8-GPU job): nominal 49: 244.6 | 31.76, 70: 242.4 | 31.64, 98: 240.3 | 32.08.
-    # fp32 engines run groups of at most 63 chunks (2^31-byte tensors; 390 chunks = 7 x 56): their nominal group is 56 (config 3, same box:
-    # nominal 49: 1483, 56: 1455, 64: 1458, 98: +65 ms/step).
-    NOMINAL_GROUP = int(os.environ.get("FB_NOMINAL_GROUP", "0"))
-
+    # K-slice counts are sized for ``self.nominal_group`` -- the chunk group of the whole problem on ONE GPU (the trainer passes
+    # group_size(all chunks, chunk_group, cap), the same number on every rank) -- never for the group this engine runs: the number of slices
+    # fixes the order in which a chunk's pixels are summed, and a chunk's gradient must not depend on how chunks are batched or sharded (the
+    # 2-rank == 1-process tests).  A rank of an 8-GPU job (49 chunks, slices sized for 98) pays 1 % for it: 32.08 vs 31.76 ms/step.
     def _choose_split(self, L):
         """Split the pixel reduction of wgrad so that >= ~1000 workgroups exist; slices are multiples of the K-step."""
         bf16 = self.dt == torch.bfloat16
-        G = self.NOMINAL_GROUP or (98 if bf16 else 56)
+        G = self.nominal_group
         widths = (4, 8, 16, 32) if L.stride == 1 else ((4, 8, 16) if (bf16 or self.f32_split == "f16x2") else ())
         if (L.R == 3 and L.stride in (1, 2) and L.pad == 1 and L.hout == L.wout and L.hin == L.stride * L.hout and L.wout in widths
                 and L.cin_pad % 64 == 0 and L.cout % 64 == 0 and not (L.wout == 4 and self.chunk % 2)):

@@ -442,9 +442,12 @@ class FullBatchTrainer:
         # chunk sizes that do not fill whole 128-pixel statistics blocks (data.batch_size=125: all 50 000 images in 400 chunks,
         # reference data_preparation.py:64-72) are stored padded with zero images (label -1)
         self.chunk_pad = padded_chunk(plan, self.chunk)
-        G = group_size(self.shard.count, int(cfg.impl.get("engine", {}).get("chunk_group", 98)), cap=max_group(plan, self.chunk_pad, self.dtype))
+        want, cap = int(cfg.impl.get("engine", {}).get("chunk_group", 98)), max_group(plan, self.chunk_pad, self.dtype)
+        G = group_size(self.shard.count, want, cap=cap)
+        # K-slice counts of the weight gradients are sized for the group of the WHOLE problem on one GPU -- the same number on every rank, so
+        # that a chunk's summation order (hence its gradient, bit for bit) does not depend on the number of GPUs
         self.engine = Engine(model, X.shape[-1], self.chunk_pad, G, compute_dtype=self.dtype, device=self.device, fd_sets=fd_sets,
-                             arena_align=64 * self.world, chunk_valid=self.chunk)
+                             arena_align=64 * self.world, chunk_valid=self.chunk, nominal_group=group_size(self.n_chunks, want, cap=cap))
         self.engine.label_smoothing = getattr(self.loss_fn, "smoothing", 0.0)
         self.engine.only_incorrect = getattr(self.loss_fn, "only_incorrect", False)
         stem = self.engine.plan.stem
