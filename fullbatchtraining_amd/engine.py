@@ -193,6 +193,8 @@ class _Pool:
 
 
 class Engine:
+    AMAX_BLOCK, AMAX_SLOT_LIMIT = 256, 16384         # fp16x2 scale slots: rows per allocation, sanity limit on distinct operand buffers
+
     def __init__(self, model, pixels, chunk, max_groups, compute_dtype=torch.bfloat16, device="cuda", fd_sets=0, arena_align=64,
                  chunk_valid=None, nominal_group=None):
         """``fd_sets``: extra per-chunk gradient/parameter sets for finite differences (0 none, 1 forward, 2 central).
@@ -255,8 +257,11 @@ class Engine:
         self.eps_n = torch.zeros(self.G, **f32)
         self.norms2 = torch.zeros(2, **f32)
         # one scale per CHUNK and tensor (a chunk's arithmetic must not depend on how chunks are batched or sharded): slots of G floats
-        self.amax_buf = torch.zeros(256, self.G, device=self.device, dtype=torch.float32)
-        self.amax_map, self.amax_next = {}, 0
+        # Every tensor (buffer address) OWNS its slot for the life of the engine -- the activation, pool and dataset buffers are a fixed
+        # set -- so a slot can never be handed to a second tensor while a kernel still reads the first one's scale through it (a
+        # 256-entry ring did exactly that on ResNet-152: ~310 slots per forward + backward, fp16 overflow in the early weight gradients).
+        # ``amax_map`` says whose slot holds the magnitudes of the tensor's CURRENT content.
+        self.amax_blocks, self.amax_slots, self.amax_map, self.amax_handouts = [], {}, {}, 0
         for li, L in enumerate(self.plan.layers):
             L.li = li
         self.w_amax = [torch.zeros(len(self.plan.layers), self.G if k else 1, device=self.device, dtype=torch.float32) for k in range(2)]
@@ -466,9 +471,19 @@ class Engine:
 
     def _amax_slot(self, t, numel):
         """Slot (G floats) for a tensor whose PRODUCER tracks the largest magnitudes itself (fb_bn_apply / fb_bn_bwd_apply ``amax_out``)."""
-        slot = self.amax_buf[self.amax_next].data_ptr()
-        self.amax_next = (self.amax_next + 1) % self.amax_buf.shape[0]
-        self.amax_map[t.data_ptr()] = (slot, numel)
+        key = t.data_ptr()
+        self.amax_handouts += 1
+        slot = self.amax_slots.get(key)
+        if slot is None:
+            idx = len(self.amax_slots)
+            if idx >= self.AMAX_SLOT_LIMIT:
+                raise lib.EngineError(f"fp16x2 scale slots: more than {self.AMAX_SLOT_LIMIT} distinct operand buffers -- buffers are expected to be "
+                                      "persistent (activations, pool, dataset slices); something allocates a new tensor per launch")
+            blk, row = divmod(idx, self.AMAX_BLOCK)
+            if blk == len(self.amax_blocks):         # (earlier blocks stay where they are: their slot pointers are in flight)
+                self.amax_blocks.append(torch.zeros(self.AMAX_BLOCK, self.G, device=self.device, dtype=torch.float32))
+            slot = self.amax_slots[key] = self.amax_blocks[blk][row].data_ptr()
+        self.amax_map[key] = (slot, numel)
         return slot
 
     def _amax_pair(self, L, src, numel, wsets, G):

@@ -177,8 +177,9 @@ def test_bottleneck_standard_stem_chunk_gradients_vs_oracle():
 
 
 def test_resnet152_at_224_directional_derivative():
-    """BASELINE config 5 at its real shape (ResNet-152, 'standard' stem, 224x224 inputs, one chunk of 128 images, exact-f32 path as the
-    regulariser uses it): too large for the CPU oracle inside a test, so a size-independent property ties the backward kernels to the
+    """BASELINE config 5 at its real shape (ResNet-152, 'standard' stem, 224x224 inputs, one chunk of 128 images, fp32 storage with the
+    bf16x6 split -- the arithmetic of plain fp32 training; the regulariser's f16x2 arithmetic at this shape is covered by
+    test_resnet152_at_224_regulariser_f16x2 below): too large for the CPU oracle inside a test, so a size-independent property ties the backward kernels to the
     forward ones -- the change of the chunk loss between theta + c g and theta - c g equals <g, theta+ - theta-> (the ACTUAL fp32
     difference of the two parameter vectors: |g| is ~1500 at initialisation, so a step that moves the loss by 1e-3 changes most
     weights by less than their fp32 spacing and the rounded step has to be accounted for).  Measured 1.0003; 0.989 / 1.025 at a
@@ -212,6 +213,86 @@ def test_resnet152_at_224_directional_derivative():
     # determinism at this size: a second evaluation reproduces loss and gradient bit for bit
     loss1, g1 = loss_and_grad()
     assert loss1 == loss0 and torch.equal(g1, g)
+
+
+def test_resnet152_at_224_regulariser_f16x2(monkeypatch):
+    """BASELINE config 5 WITH the regulariser, in the arithmetic it runs by default (f16x2: two scaled fp16 pieces per operand, one
+    power-of-two scale per chunk and tensor).  ResNet-152 needs ~310 scale slots per forward + backward; round 2 handed them out from a
+    ring of 256, so the weight gradients of the first layers read another tensor's scale -> fp16 overflow -> NaN loss after one update,
+    and nothing tested f16x2 at this depth.  (i) two regularised steps stay finite, (ii) the directional-derivative property of the raw
+    chunk gradient holds on the f16x2 path, (iii) the regularised chunk gradient agrees with the bf16x6 (exact fp32 product) engine to
+    5e-2 (the finite-difference quotient amplifies the 2^-22 operand rounding; ResNet-18 at 16 px measures 4e-3)."""
+    from fullbatchtraining_amd.engine import Engine
+
+    pixels, chunk, G = 224, 128, 1
+    x, y = make_data(chunk, pixels)
+    yd = y.cuda()
+    results = {}
+    for split in ("f16x2", "bf16x6"):
+        monkeypatch.setenv("FB_F32_SPLIT", split)
+        cfg, model, eng, stem_patches = _build(152, pixels, chunk, G, torch.float32, stem="standard", fd_sets=1)
+        assert eng.f32_split == split
+        patches = stem_patches(x.cuda(), eng.plan.stem, torch.float32)
+        loss, _, sq = eng.full_gradient(patches, yd, 0.1, block_strength=0.5, eps=1e-2, implementation="forward-differences")
+        torch.cuda.synchronize()
+        results[split] = (float(loss[0]), eng.avg.clone().cpu().double(), float(sq[0]))
+        assert np.isfinite(results[split][0]) and bool(torch.isfinite(eng.avg).all()) and bool(torch.isfinite(eng.g_fd[0][0]).all())
+        if split == "f16x2":
+            print(f"f16x2 scale slots: {eng.amax_handouts} hand-outs in one regularised evaluation, {len(eng.amax_slots)} distinct buffers")
+            assert eng.amax_handouts > 2 * 256           # (two passes) the shape that overran the old ring of 256 within ONE pass
+            # (ii) directional derivative of the raw chunk gradient on this arithmetic
+            def loss_and_grad():
+                eng.prep_weights(eng.theta, 1)
+                eng.group_gradient(patches, yd, G, eng.g)
+                torch.cuda.synchronize()
+                return float(eng.loss[0]), eng.g[0].clone()
+
+            loss0, g = loss_and_grad()
+            gn = float(g.double().norm())
+            theta0 = eng.theta.clone()
+            c = 5e-4 * max(1.0, abs(loss0)) / gn ** 2
+            tp, tm = theta0 + c * g, theta0 - c * g
+            predicted = float((g.double() * (tp.double() - tm.double())).sum())
+            eng.theta.copy_(tp)
+            lp, _ = loss_and_grad()
+            eng.theta.copy_(tm)
+            lm, _ = loss_and_grad()
+            eng.theta.copy_(theta0)
+            print(f"resnet152@224 f16x2: loss {loss0:.5f}, |g| {gn:.2f}, (L+ - L-) / <g, theta+ - theta-> = {(lp - lm) / predicted:.4f}")
+            assert abs((lp - lm) / predicted - 1.0) < 2e-2, (lp, lm, predicted)
+            # (i) two regularised steps: update with the clipped regularised gradient, evaluate again
+            eng.full_gradient(patches, yd, 0.1, block_strength=0.5, eps=1e-2, implementation="forward-differences")
+            eng.grad_and_param_sqnorm()
+            eng.sgd_step(0.1, 5e-4, 0.9, 0.0, True, grad_clip=0.25)
+            loss2, _, sq2 = eng.full_gradient(patches, yd, 0.1, block_strength=0.5, eps=1e-2, implementation="forward-differences")
+            torch.cuda.synchronize()
+            print(f"resnet152@224 f16x2 + regulariser: loss {results[split][0]:.5f} -> {float(loss2[0]):.5f}, |g_k|^2 {results[split][2]:.4e} -> {float(sq2[0]):.4e}")
+            assert np.isfinite(float(loss2[0])) and np.isfinite(float(sq2[0])) and bool(torch.isfinite(eng.avg).all())
+        del eng, patches
+        torch.cuda.empty_cache()
+    (l16, a16, s16), (l6, a6, s6) = results["f16x2"], results["bf16x6"]
+    err = float((a16 - a6).norm() / a6.norm())
+    print(f"resnet152@224 regularised chunk gradient, f16x2 vs bf16x6: {err:.3e}; loss {l16:.6f} vs {l6:.6f}; |g_k|^2 {s16:.5e} vs {s6:.5e}")
+    assert abs(l16 - l6) < 1e-3 * abs(l6)
+    assert abs(s16 - s6) < 1e-2 * s6
+    assert err < 5e-2, err
+
+
+def test_f16x2_scale_slots_are_owned_by_their_buffer(monkeypatch):
+    """Host-side contract of the fp16x2 scale slots: a buffer keeps ONE slot for the life of the engine, distinct live buffers never
+    share one (however many there are), and the pool invalidates the cached magnitudes of a buffer it hands out again."""
+    monkeypatch.setenv("FB_F32_SPLIT", "f16x2")
+    cfg, model, eng, stem_patches = _build(18, 16, 32, 2, torch.float32, fd_sets=1)
+    bufs = [torch.empty(64, device="cuda") for _ in range(600)]          # > 2 allocation blocks of 256
+    slots = [eng._amax_slot(t, 64) for t in bufs]
+    assert len(set(slots)) == len(slots)
+    assert [eng._amax_slot(t, 64) for t in bufs] == slots
+    t = eng.pool.get((4, 4))
+    eng._amax_slot(t, 16)
+    assert t.data_ptr() in eng.amax_map
+    eng.pool.put(t)
+    t2 = eng.pool.get((4, 4))
+    assert t2.data_ptr() == t.data_ptr() and t.data_ptr() not in eng.amax_map
 
 
 def test_imagenet_shaped_maps_chunk_gradient_vs_oracle():
