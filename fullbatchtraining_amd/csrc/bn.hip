@@ -4,6 +4,7 @@
 // All reductions are two-stage with a fixed order (no atomics): results are bit-reproducible run to run, which the
 // finite-difference regulariser relies on (both passes see identically ordered sums).
 #include "common.h"
+#include "profile.h"
 
 // Two-stage fixed-order sum of the per-pixel-block partials of one (group, channel): blockDim.x threads = 16 channels x SEGS segments
 // (SEGS = blockDim.x / 16: 16 or 64); segment s adds blocks s, s+SEGS, ... in double, then the SEGS segment sums are added in order.
@@ -267,9 +268,12 @@ extern "C" int fb_bn_apply(const void* x, void* y, const float* scale, const flo
     if (C % 8 != 0) FB_FAIL(FB_ERR_SHAPE, "fb_bn_apply: C=%d must be a multiple of 8", C);
     if (pool_out && !fb_bn_apply_can_pool(C, pool_W, pixels_per_group, dtype))
         FB_FAIL(FB_ERR_UNSUPPORTED, "fb_bn_apply: fused 2x2 average pooling needs bf16, W * C == 2048 and whole row pairs per group (C=%d W=%d)", C, pool_W);
+    const int32_t info[FB_PROF_INFO] = {(int32_t)(n_pixels / 128), C, (int32_t)(pixels_per_group / 128), dtype, res ? 1 : 0, mask_out ? 1 : 0, 0, pool_out ? 1 : 0, 0, 0, 0};
+    const int prof = fb_prof_begin(FB_PROF_BN_APPLY, (hipStream_t)stream, info);
     bool tracked = false;
     if (dtype == FB_F32) tracked = launch_bn_apply<float>(x, y, scale, shift, res, rscale, rshift, n_pixels, C, pixels_per_group, valid_pixels_per_group, relu, (unsigned char*)mask_out, (uint4*)pool_out, amax_out, amax_ws, (hipStream_t)stream);
     else launch_bn_apply<bf16_tag>(x, y, scale, shift, res, rscale, rshift, n_pixels, C, pixels_per_group, valid_pixels_per_group, relu, (unsigned char*)mask_out, (uint4*)pool_out, nullptr, nullptr, (hipStream_t)stream);
+    fb_prof_end(prof, (hipStream_t)stream);
     FB_CHECK_LAUNCH("fb_bn_apply");
     if (amax_out && !tracked) return fb_absmax((const float*)y, pixels_per_group * C, (int32_t)n_groups, pixels_per_group * C, 1, amax_out, stream);
     return FB_OK;
@@ -417,12 +421,15 @@ extern "C" int fb_bn_bwd_reduce(const void* dout, const void* y, const void* mas
     const int n_mblocks = fb_bn_bwd_reduce_rows(n_pixels, pixels_per_group);
     const size_t smem = (size_t)rows * C * 2 * sizeof(float);
     if (smem > 64 * 1024) FB_FAIL(FB_ERR_UNSUPPORTED, "fb_bn_bwd_reduce: C=%d too large", C);
+    const int32_t info[FB_PROF_INFO] = {(int32_t)(n_pixels / 128), C, (int32_t)(pixels_per_group / 128), dtype, 0, (mask || y) ? 1 : 0, 0, 0, 0, 0, 0};
+    const int prof = fb_prof_begin(FB_PROF_BN_BWD_REDUCE, (hipStream_t)stream, info);
     if (dtype == FB_F32)
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<float>), dim3(n_mblocks), dim3(256), smem, (hipStream_t)stream, (const uint4*)dout, (const uint4*)y,
                            (const unsigned char*)mask, (const uint4*)x, mean_tab, invstd, ch_total, ch_off, partial, (long long)n_pixels, C, (long long)pixels_per_group, n_mblocks, PB);
     else
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_tag>), dim3(n_mblocks), dim3(256), smem, (hipStream_t)stream, (const uint4*)dout, (const uint4*)y,
                            (const unsigned char*)mask, (const uint4*)x, mean_tab, invstd, ch_total, ch_off, partial, (long long)n_pixels, C, (long long)pixels_per_group, n_mblocks, PB);
+    fb_prof_end(prof, (hipStream_t)stream);
     FB_CHECK_LAUNCH("fb_bn_bwd_reduce");
     return FB_OK;
 }
@@ -553,7 +560,9 @@ extern "C" int fb_bn_bwd_apply(const void* dout, const void* y, const void* mask
     const int V = dtype == FB_F32 ? 4 : 8;
     const int cvec = C / V;
     const long long n_vec = n_pixels * cvec, vpg = pixels_per_group * cvec;
+    const int32_t info[FB_PROF_INFO] = {(int32_t)(n_pixels / 128), C, (int32_t)(pixels_per_group / 128), dtype, 0, (mask || y) ? 1 : 0, dy_out ? 1 : 0, 0, 0, 0, 0};
     if (256 % cvec == 0 && vpg > 0) {
+        const int prof = fb_prof_begin(FB_PROF_BN_BWD_APPLY, (hipStream_t)stream, info);
         const int span = bn_span(n_vec);
         const dim3 grid((unsigned)((vpg + span - 1) / span), (unsigned)((n_vec + vpg - 1) / vpg));
         if (dtype == FB_F32)
@@ -562,6 +571,7 @@ extern "C" int fb_bn_bwd_apply(const void* dout, const void* y, const void* mask
         else
             hipLaunchKernelGGL((bn_bwd_apply_span_kernel<bf16_tag>), grid, dim3(256), 0, (hipStream_t)stream, (const uint4*)dout, (const uint4*)y,
                                (const unsigned char*)mask, (const uint4*)x, coef, (uint4*)dx, (uint4*)dy_out, n_vec, cvec, vpg, C, span, nullptr);
+        fb_prof_end(prof, (hipStream_t)stream);
         if (amax_out) hipLaunchKernelGGL(amax_finish_kernel, dim3(grid.y), dim3(256), 0, (hipStream_t)stream, amax_ws, (int)grid.x, amax_out);
         FB_CHECK_LAUNCH("fb_bn_bwd_apply");
         return FB_OK;

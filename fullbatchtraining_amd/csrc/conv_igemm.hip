@@ -275,15 +275,25 @@ extern "C" int fb_conv2d(const fb_conv_args* a, void* stream) {
     p.M = a->n_img * p.qH * p.qW;
     p.n_mblocks = ((p.M + 127) / 128) * classes;
     hipStream_t st = (hipStream_t)stream;
-    const int prof = fb_prof_begin(a->mode == 0 ? FB_PROF_IGEMM_FWD : FB_PROF_IGEMM_DGRAD, st);
+    const int32_t info[FB_PROF_INFO] = {a->n_img, a->Hs, a->Ws, a->Cs, a->Hd, a->Wd, a->Cd, a->R, a->stride,
+                                        (a->addend ? a->addend_mode : 0) | (a->addend_mask ? 4 : 0) | (a->bst_x ? 8 : 0) | (a->dtype << 4), 0};
+    const int prof = fb_prof_begin(a->mode == 0 ? FB_PROF_IGEMM_FWD : FB_PROF_IGEMM_DGRAD, st, info);
     static const bool v1 = getenv("FB_IGEMM_V1") != nullptr;
-    if (!fb_try_conv1x1_k32(a, st) && !fb_try_conv3x3s2_dgrad_quad(a, st) && !fb_try_conv3x3_halo5(a, st) && !fb_try_conv3x3_halo4(a, st)) {
+    int kernel = 0;
+    if (fb_try_conv1x1_k32(a, st)) kernel = FB_K_CONV1X1_K32;
+    else if (fb_try_conv3x3s2_dgrad_quad(a, st)) kernel = FB_K_S2_DGRAD_QUAD;
+    else if (fb_try_conv3x3_halo5(a, st)) kernel = FB_K_HALO5;
+    else if (fb_try_conv3x3_halo4(a, st)) kernel = FB_K_HALO4;
+    else {
         p.zeros = nullptr;
+        kernel = FB_K_IGEMM_GLDS;
         if (v1 || !fb_launch_igemm_glds(p, classes, a->dtype, st)) {
             if (p.amax_src) FB_FAIL(FB_ERR_UNSUPPORTED, "fb_conv2d: the register-staged implicit GEMM has no fp16x2 path (tensor beyond 2^31 bytes or FB_IGEMM_V1)");
             if (a->dtype == FB_F32) launch_conv<float>(p, classes, st); else launch_conv<bf16_tag>(p, classes, st);
+            kernel = FB_K_IGEMM_V1;
         }
     }
+    fb_prof_kernel(prof, kernel);
     fb_prof_end(prof, st);
     FB_CHECK_LAUNCH("fb_conv2d");
     return FB_OK;

@@ -257,8 +257,10 @@ extern "C" int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream) {
     p.px_per_split = (int)(ceil_div64(ceil_div64(p.px_per_group, a->split_k), kstep) * kstep);
     const int taps = a->R * a->S;
     const bool split = fb_f32_split_enabled();
-    const int prof = fb_prof_begin(FB_PROF_WGRAD, st);
-    if (fb_try_wgrad3x3_v2(a, st) || fb_try_wgrad3x3(a, st)) {
+    const int32_t info[FB_PROF_INFO] = {a->n_img, a->Hs, a->Ws, a->Cs, a->Hd, a->Wd, a->Cd, a->R, a->stride, a->split_k | (a->dtype << 16), FB_K_WGRAD_GENERIC};
+    const int prof = fb_prof_begin(FB_PROF_WGRAD, st, info);
+    if (fb_try_wgrad3x3_v2(a, st)) { fb_prof_kernel(prof, FB_K_WGRAD3X3_V2);
+    } else if (fb_try_wgrad3x3(a, st)) { fb_prof_kernel(prof, FB_K_WGRAD3X3_V1);
     } else if (big) {
         dim3 grid((a->Cd / 128) * (a->Cs / 128), taps, n_groups * a->split_k);
         if (hsplit) hipLaunchKernelGGL((conv_wgrad_kernel<f32h_tag, 2, 2, 1, 1, 4>), grid, dim3(256), 0, st, p);

@@ -8,7 +8,7 @@
 
 thread_local char fb_err_buf[512] = "";
 extern "C" const char* fb_last_error_string(void) { return fb_err_buf; }
-extern "C" int fb_abi_version(void) { return 9; }
+extern "C" int fb_abi_version(void) { return 10; }
 
 // ---- workspace sizes (floats) ------------------------------------------------------------------------------------------
 extern "C" int64_t fb_ws_conv_stat_floats(const fb_conv_args* a) {
@@ -27,7 +27,7 @@ bool fb_f32_split_enabled() {
 }
 
 namespace {
-struct Pair { hipEvent_t a, b; int cls; };
+struct Pair { hipEvent_t a, b; int cls; int32_t info[FB_PROF_INFO]; };
 bool g_on = false;
 std::vector<Pair> g_pool;
 size_t g_used = 0;
@@ -60,16 +60,36 @@ extern "C" int fb_profile_enable(int on, int capacity) {
     return FB_OK;
 }
 
-int fb_prof_begin(int cls, hipStream_t st) {
+int fb_prof_begin(int cls, hipStream_t st, const int32_t* info) {
     if (!g_on) return -1;
     if (g_used >= g_pool.size()) { g_dropped[cls]++; return -1; }
     const int id = (int)g_used++;
     g_pool[id].cls = cls;
+    for (int i = 0; i < FB_PROF_INFO; ++i) g_pool[id].info[i] = info ? info[i] : 0;
     hipEventRecord(g_pool[id].a, st);
     return id;
 }
+void fb_prof_kernel(int id, int kernel) {
+    if (id >= 0) g_pool[id].info[FB_PROF_INFO - 1] = kernel;
+}
 void fb_prof_end(int id, hipStream_t st) {
     if (id >= 0) hipEventRecord(g_pool[id].b, st);
+}
+
+// Per-launch records of everything recorded since the last fb_profile_read (which resets; call this one first): row i of `info`
+// ([cap][FB_PROF_INFO + 1] int32) = {class, the FB_PROF_INFO shape words the entry point filed (fb_engine.h), the last one = kernel id},
+// ms[i] = elapsed milliseconds.  Returns the number of rows written (<= cap), negative on error; blocks until the launches finish.
+extern "C" int64_t fb_profile_read_launches(int32_t* info, float* ms, int64_t cap) {
+    int64_t n = 0;
+    for (size_t i = 0; i < g_used && n < cap; ++i, ++n) {
+        if (hipEventSynchronize(g_pool[i].b) != hipSuccess) FB_FAIL(FB_ERR_LAUNCH, "fb_profile_read_launches: event sync failed");
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_pool[i].a, g_pool[i].b) != hipSuccess) FB_FAIL(FB_ERR_LAUNCH, "fb_profile_read_launches: elapsed failed");
+        info[n * (FB_PROF_INFO + 1)] = g_pool[i].cls;
+        for (int k = 0; k < FB_PROF_INFO; ++k) info[n * (FB_PROF_INFO + 1) + 1 + k] = g_pool[i].info[k];
+        ms[n] = t;
+    }
+    return n;
 }
 
 // Sums elapsed ms and launch counts per class for everything recorded since the last read; blocks until those launches finish.

@@ -167,12 +167,37 @@ def stem_patches(x_nchw, layer, dtype, aug=None, out=None):
     return out
 
 
+class _Events:
+    """Cross-stream ordering through the library's event table (``fb_event_*``): the same events order eager launches and the launches
+    of replayed command lists.  Eager code draws ids from a ring (re-recording an event whose waits have been issued is safe: a wait
+    binds to the record that precedes it in host order); a recording gets fresh ids that stay with its list."""
+    RING = 1024
+
+    def __init__(self):
+        self.ring, self.pos = [], 0
+
+    def record(self, stream=None):
+        if lib.recording():
+            ev = lib.event_new()
+        elif len(self.ring) < self.RING:
+            ev = lib.event_new()
+            self.ring.append(ev)
+        else:
+            ev = self.ring[self.pos]
+            self.pos = (self.pos + 1) % self.RING
+        lib.event_record(ev, stream)
+        return ev
+
+    def wait(self, ev, stream=None):
+        lib.event_wait(ev, stream)
+
+
 class _Pool:
-    """Stream-ordered scratch reuse keyed by element count.  A buffer may be returned together with an event of another
+    """Stream-ordered scratch reuse keyed by element count.  A buffer may be returned together with an event (``_Events`` id) of another
     stream that still reads it (the weight-gradient stream): the next user waits for that event before writing."""
 
-    def __init__(self, device, dtype, on_reuse=None):
-        self.device, self.dtype, self.free, self.on_reuse = device, dtype, {}, on_reuse
+    def __init__(self, device, dtype, on_reuse=None, events=None):
+        self.device, self.dtype, self.free, self.on_reuse, self.events = device, dtype, {}, on_reuse, events
 
     def get(self, shape):
         numel = math.prod(shape)
@@ -180,7 +205,7 @@ class _Pool:
         if lst:
             t, ev = lst.pop(0)                       # oldest first: its reader has most likely finished
             if ev is not None:
-                torch.cuda.current_stream().wait_event(ev)
+                self.events.wait(ev)
             if self.on_reuse is not None:
                 self.on_reuse(t)
             return t.view(shape)
@@ -270,7 +295,12 @@ class Engine:
             n_max = self.G * chunk
             need = max(lib.load().fb_ws_bn_amax_floats(n_max * L.hout * L.wout, L.cout, chunk * L.hout * L.wout) for L in self.plan.layers)
             self.amax_ws = torch.zeros(int(need), device=self.device, dtype=torch.float32)
-        self.pool = _Pool(self.device, self.dt, on_reuse=lambda t: self.amax_map.pop(t.data_ptr(), None))
+        self.events = _Events()
+        self.pool = _Pool(self.device, self.dt, on_reuse=lambda t: self.amax_map.pop(t.data_ptr(), None), events=self.events)
+        # native launch executor (csrc/cmdlist.cpp): the launches of one chunk group's forward + backward (and of the weight preparation) are a
+        # static sequence -- recorded the first time, replayed with one host call afterwards (FB_REPLAY=0: every launch through ctypes)
+        self.use_replay = os.environ.get("FB_REPLAY", "1") != "0"
+        self.cmdlists, self.replays, self.MAX_CMDLISTS = {}, 0, 96
         self.masks = {}
         self.fuse_bwd_stat = os.environ.get("FB_FUSED_BWD_STAT", "0") != "0"     # BN-backward reduction in the input-gradient epilogues: built, parity-tested,
         # measured SLOWER at step level (profiles/r2_notes.md: the separate HBM-bound reduction overlaps the weight-gradient stream) -> off
@@ -449,14 +479,18 @@ class Engine:
         slot = 1 if per_chunk else 0
         wf, wd = self.w_fwd[slot], self.w_dgrad[slot]
         es = wf.element_size()
-        for li, L in enumerate(self.plan.layers):
-            dst_d = wd.data_ptr() + es * L.wc_off if L is not self.plan.stem else None
-            am = None
-            if self.f32_split == "f16x2":            # one scale per layer and weight set, shared by its forward and transposed copies;
-                am = self.w_amax[slot][li].data_ptr()                           # the copies are then written as fp16x2 planes
-                call("fb_absmax", theta.data_ptr() + 4 * L.w_off, L.cout * L.taps * L.cin_real, nsets, self.plan.P, 1, am)
-            call("fb_weight_prep", theta.data_ptr() + 4 * L.w_off, self.plan.P, self.plan.wc_total, nsets, L.cout, L.taps, L.cin_real,
-                 L.cin_pad, wf.data_ptr() + es * L.wc_off, dst_d, self.dtc, am)
+
+        def body():
+            for li, L in enumerate(self.plan.layers):
+                dst_d = wd.data_ptr() + es * L.wc_off if L is not self.plan.stem else None
+                am = None
+                if self.f32_split == "f16x2":        # one scale per layer and weight set, shared by its forward and transposed copies;
+                    am = self.w_amax[slot][li].data_ptr()                       # the copies are then written as fp16x2 planes
+                    call("fb_absmax", theta.data_ptr() + 4 * L.w_off, L.cout * L.taps * L.cin_real, nsets, self.plan.P, 1, am)
+                call("fb_weight_prep", theta.data_ptr() + 4 * L.w_off, self.plan.P, self.plan.wc_total, nsets, L.cout, L.taps, L.cin_real,
+                     L.cin_pad, wf.data_ptr() + es * L.wc_off, dst_d, self.dtc, am)
+
+        self._replayable(("prep", theta.data_ptr(), nsets, slot), body)
 
     def _amax(self, t, numel, G):
         """Device pointer of the per-chunk largest magnitudes (G floats) of the first ``numel`` values of ``t`` (fp16x2 split scales),
@@ -629,11 +663,11 @@ class Engine:
         if self.wstream is None:
             launch()
             return
-        ready = torch.cuda.current_stream().record_event()
+        ready = self.events.record()
         with torch.cuda.stream(self.wstream):
-            self.wstream.wait_event(ready)
+            self.events.wait(ready)
             launch()
-            self._wgrad_event = self.wstream.record_event()
+            self._wgrad_event = self.events.record()
 
     def _dgrad_args(self, L, src, wptr, dst, addend, G, wsets, addend_mode, addend_mask=None, stat=None, bst_x=None, bst_mask=None, amax=(None, None)):
         n = G * self.chunk
@@ -743,14 +777,38 @@ class Engine:
         self._wgrad(S, patches, dx, G, gout)
         pool.put(dx, event=self._wgrad_event)
         if self.wstream is not None:                     # gout is complete (and the activations are free) after this point
-            torch.cuda.current_stream().wait_stream(self.wstream)
+            self.events.wait(self.events.record(self.wstream))
 
     # ------------------------------------------------------------------------------------------- chunk-group gradient --
+    def _replayable(self, key, body):
+        """Run ``body`` (a static sequence of library launches and event operations that depends on nothing but ``key`` and the
+        engine's construction) -- through the interpreter the first time, recording it; as one native replay of the recorded list afterwards."""
+        if not self.use_replay:
+            return body()
+        streams = [torch.cuda.current_stream(), self.wstream]
+        cl = self.cmdlists.get(key)
+        if cl is not None:
+            cl.replay(streams)
+            self.replays += 1
+            return
+        if len(self.cmdlists) >= self.MAX_CMDLISTS:      # (keys that never repeat, e.g. a dataset re-gathered into new buffers every step)
+            self.cmdlists.pop(next(iter(self.cmdlists)))
+        with lib.Recorder(streams) as rec:
+            body()
+        self.cmdlists[key] = rec.finish()
+
     def group_gradient(self, patches, labels, G, gout, wsets=1, theta=None, pidx=0, on_block_done=None):
         """fwd + bwd for ``G`` chunks: per-chunk raw gradients in gout[:G], losses/corrects in self.loss/self.correct."""
         theta = self.theta if theta is None else theta
-        self.forward(patches, labels, G, wsets, theta, pidx)
-        self.backward(patches, G, wsets, theta, gout, pidx, on_block_done)
+
+        def body():
+            self.forward(patches, labels, G, wsets, theta, pidx)
+            self.backward(patches, G, wsets, theta, gout, pidx, on_block_done)
+
+        if on_block_done is not None or getattr(self, "_eval", False):
+            return body()                            # (a host callback inside the sequence: the multi-GPU late bucket)
+        self._replayable(("group", patches.data_ptr(), labels.data_ptr(), G, gout.data_ptr(), wsets, theta.data_ptr(), pidx, self.chunk, self.valid,
+                          float(self.label_smoothing), bool(self.only_incorrect), self.fuse_bwd_stat), body)
 
     # --------------------------------------------------------------------------------------- full-batch gradient + step --
     def full_gradient(self, patches, labels, lr, block_strength=0.0, eps=1e-2, implementation="forward-differences",

@@ -5,11 +5,12 @@ Wrappers take ``torch`` tensors only to read ``data_ptr()`` -- memory and stream
 """
 import ctypes as C
 import os
+import struct
 
 import torch
 
 FB_F32, FB_BF16 = 0, 1
-EXPECTED_ABI = 9          # fb_abi_version() the ctypes structs / signatures below were written for
+EXPECTED_ABI = 10         # fb_abi_version() the ctypes structs / signatures below were written for
 MT_BLOCKS = 1024
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libfbengine.so")
 
@@ -79,8 +80,14 @@ _SIGS = {
 }
 EXPORTS = tuple(_SIGS) + ("fb_last_error_string", "fb_abi_version", "fb_profile_enable", "fb_profile_read", "fb_ws_conv_stat_floats",
                           "fb_ws_wgrad_slab_floats", "fb_ws_bn_partial_floats", "fb_ws_mt_floats", "fb_bn_bwd_reduce_rows", "fb_conv_masked_addend_supported", "fb_conv_bwd_stat_supported",
-                          "fb_bn_apply_can_pool", "fb_ws_bn_amax_floats")
-PROF_CLASSES = ("igemm_fwd", "igemm_dgrad", "wgrad")
+                          "fb_bn_apply_can_pool", "fb_ws_bn_amax_floats", "fb_profile_read_launches", "fb_cmd_fn_id", "fb_cmd_fn_nargs", "fb_event_new",
+                          "fb_event_record", "fb_event_wait", "fb_cmdlist_create", "fb_cmdlist_destroy", "fb_cmdlist_size", "fb_cmdlist_add_call",
+                          "fb_cmdlist_add_event", "fb_cmdlist_replay")
+PROF_CLASSES = ("igemm_fwd", "igemm_dgrad", "wgrad", "bn_apply", "bn_bwd_reduce", "bn_bwd_apply")
+PROF_INFO = 11
+PROF_KERNELS = {0: "?", 1: "conv_igemm_kernel (register-staged)", 2: "conv_igemm_v3_kernel", 3: "conv3x3s1_halo4_kernel", 4: "conv3x3s1_c64_halo5_kernel",
+                5: "conv3x3s2_dgrad_quad_kernel", 6: "conv1x1_k32_kernel", 7: "conv1x1_stream_kernel", 8: "conv3x3s2_fwd_kernel",
+                16: "conv_wgrad_kernel", 17: "conv_wgrad3x3_kernel", 18: "conv_wgrad3x3_v2_kernel"}
 
 
 def profile_enable(on, capacity=32768):
@@ -94,10 +101,26 @@ def profile_read():
     """-> {class: (ms, launches, dropped)} for launches recorded since the previous read (synchronises on them)."""
     lib = load()
     lib.fb_profile_read.argtypes = [C.POINTER(c_double), C.POINTER(c_i64), C.POINTER(c_i64)]
-    ms, n, d = (c_double * 3)(), (c_i64 * 3)(), (c_i64 * 3)()
+    k = len(PROF_CLASSES)
+    ms, n, d = (c_double * k)(), (c_i64 * k)(), (c_i64 * k)()
     if lib.fb_profile_read(ms, n, d) != 0:
         raise EngineError(lib.fb_last_error_string().decode())
     return {k: (ms[i], n[i], d[i]) for i, k in enumerate(PROF_CLASSES)}
+
+
+
+def profile_read_launches(cap=1 << 18):
+    """-> list of (class name, shape words tuple, ms) for every launch recorded since the previous ``profile_read`` (call this first:
+    ``profile_read`` resets the records)."""
+    lib = load()
+    lib.fb_profile_read_launches.argtypes, lib.fb_profile_read_launches.restype = [C.POINTER(c_int), C.POINTER(c_float), c_i64], c_i64
+    info, ms = (c_int * (cap * (PROF_INFO + 1)))(), (c_float * cap)()
+    n = lib.fb_profile_read_launches(info, ms, cap)
+    if n < 0:
+        raise EngineError(lib.fb_last_error_string().decode())
+    w = PROF_INFO + 1
+    return [(PROF_CLASSES[info[i * w]], tuple(info[i * w + 1:(i + 1) * w]), ms[i]) for i in range(n)]
+
 
 _lib = None
 
@@ -131,6 +154,17 @@ def load():
         lib.fb_conv_bwd_stat_supported.argtypes, lib.fb_conv_bwd_stat_supported.restype = [C.POINTER(ConvArgs)], c_int
         lib.fb_ws_bn_amax_floats.argtypes, lib.fb_ws_bn_amax_floats.restype = [c_i64, c_int, c_i64], c_i64
         lib.fb_bn_apply_can_pool.argtypes, lib.fb_bn_apply_can_pool.restype = [c_int, c_int, c_i64, c_int], c_int
+        lib.fb_cmd_fn_id.argtypes, lib.fb_cmd_fn_id.restype = [C.c_char_p], c_int
+        lib.fb_cmd_fn_nargs.argtypes, lib.fb_cmd_fn_nargs.restype = [c_int], c_int
+        lib.fb_event_new.argtypes, lib.fb_event_new.restype = [], c_int
+        lib.fb_event_record.argtypes, lib.fb_event_record.restype = [c_int, c_void_p], c_int
+        lib.fb_event_wait.argtypes, lib.fb_event_wait.restype = [c_int, c_void_p], c_int
+        lib.fb_cmdlist_create.argtypes, lib.fb_cmdlist_create.restype = [], c_void_p
+        lib.fb_cmdlist_destroy.argtypes, lib.fb_cmdlist_destroy.restype = [c_void_p], None
+        lib.fb_cmdlist_size.argtypes, lib.fb_cmdlist_size.restype = [c_void_p], c_i64
+        lib.fb_cmdlist_add_call.argtypes, lib.fb_cmdlist_add_call.restype = [c_void_p, c_int, C.POINTER(C.c_uint64), c_int, c_int, c_void_p, c_int], c_int
+        lib.fb_cmdlist_add_event.argtypes, lib.fb_cmdlist_add_event.restype = [c_void_p, c_int, c_int, c_int], c_int
+        lib.fb_cmdlist_replay.argtypes, lib.fb_cmdlist_replay.restype = [c_void_p, C.POINTER(c_void_p), c_int], c_int
         _lib = lib
     return _lib
 
@@ -148,11 +182,152 @@ def _stream():
 
 
 def call(name, *args):
-    """Invoke an entry point on torch's current stream; raises EngineError on a non-zero status."""
+    """Invoke an entry point on torch's current stream; raises EngineError on a non-zero status.  While a ``Recorder`` is active the
+    call is also appended to its command list (it still executes: the recording pass is an ordinary pass)."""
     lib = load()
-    status = getattr(lib, name)(*args, _stream())
+    st = _stream()
+    status = getattr(lib, name)(*args, st)
     if status != 0:
         raise EngineError(f"{name} failed ({status}): {lib.fb_last_error_string().decode()} [args: {args}]")
+    if _recorder is not None:
+        _recorder.add_call(name, args, st)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# native launch executor (csrc/cmdlist.cpp): record a static sequence of calls once, replay it with one host call
+# ---------------------------------------------------------------------------------------------------------------------
+_recorder = None
+
+
+def recording():
+    return _recorder is not None
+
+
+def _check(status, what):
+    if status != 0:
+        raise EngineError(f"{what} failed ({status}): {load().fb_last_error_string().decode()}")
+
+
+def event_new():
+    ev = load().fb_event_new()
+    if ev < 0:
+        raise EngineError(load().fb_last_error_string().decode())
+    return ev
+
+
+def event_record(ev, stream=None):
+    """Record library event ``ev`` on ``stream`` (a torch stream; default: the current one)."""
+    st = _stream() if stream is None else stream.cuda_stream
+    _check(load().fb_event_record(ev, st), "fb_event_record")
+    if _recorder is not None:
+        _recorder.add_event(1, ev, st)
+
+
+def event_wait(ev, stream=None):
+    """Make ``stream`` (default: the current one) wait for the last record of library event ``ev``."""
+    st = _stream() if stream is None else stream.cuda_stream
+    _check(load().fb_event_wait(ev, st), "fb_event_wait")
+    if _recorder is not None:
+        _recorder.add_event(2, ev, st)
+
+
+def _pack_words(name, args):
+    """One 64-bit word per argument (the convention of fb_cmdlist_add_call) + the argument struct to copy, if the call has one."""
+    sig = _SIGS[name][:-1]
+    if len(args) != len(sig):
+        raise EngineError(f"{name}: {len(args)} arguments for a signature of {len(sig)}")
+    words = (C.c_uint64 * len(sig))()
+    blob = None
+    for i, (t, a) in enumerate(zip(sig, args)):
+        if t is c_float:
+            words[i] = struct.unpack("<I", struct.pack("<f", float(a)))[0]
+        elif t is c_double:
+            words[i] = struct.unpack("<Q", struct.pack("<d", float(a)))[0]
+        elif t is c_void_p or t is c_int or t is c_i64:
+            words[i] = (0 if a is None else int(a)) & 0xFFFFFFFFFFFFFFFF
+        elif i == 0 and hasattr(a, "_obj"):              # C.byref(ConvArgs / WgradArgs): the executor keeps its own copy
+            blob = a._obj
+        else:
+            raise EngineError(f"{name}: argument {i} of type {t} cannot be recorded")
+    return words, blob
+
+
+class CommandList:
+    """A recorded sequence of library calls and event operations (``Recorder``); ``replay`` issues it natively."""
+
+    def __init__(self, handle, n_streams, keep):
+        self.handle, self.n_streams, self.keep = handle, n_streams, keep
+
+    def __len__(self):
+        return int(load().fb_cmdlist_size(self.handle))
+
+    def replay(self, streams):
+        """``streams``: torch streams in the order the recorder was given them (None entries are allowed where the recording did not use them)."""
+        arr = (c_void_p * self.n_streams)(*[None if s is None else s.cuda_stream for s in streams])
+        _check(load().fb_cmdlist_replay(self.handle, arr, self.n_streams), "fb_cmdlist_replay")
+
+    def __del__(self):
+        try:
+            if self.handle and _lib is not None:
+                _lib.fb_cmdlist_destroy(self.handle)
+        except Exception:
+            pass
+        self.handle = None
+
+
+class Recorder:
+    """``with Recorder(streams) as rec: ...`` -- every ``call`` / ``event_record`` / ``event_wait`` issued inside (they execute as usual) is
+    appended to a command list; ``rec.finish()`` returns it.  ``streams``: the torch streams the region may use; a call on any other
+    stream raises.  ``keep(obj)``: objects (buffers) that must stay alive as long as the list does."""
+
+    def __init__(self, streams):
+        self.streams = list(streams)
+        self.handles = [None if s is None else s.cuda_stream for s in self.streams]
+        self.handle = load().fb_cmdlist_create()
+        self.kept = []
+        self._fn_ids = {}
+
+    def __enter__(self):
+        global _recorder
+        if _recorder is not None:
+            raise EngineError("Recorder: recordings do not nest")
+        _recorder = self
+        return self
+
+    def __exit__(self, *exc):
+        global _recorder
+        _recorder = None
+        if exc[0] is not None and self.handle:
+            load().fb_cmdlist_destroy(self.handle)
+            self.handle = None
+        return False
+
+    def _stream_index(self, st):
+        try:
+            return self.handles.index(st)
+        except ValueError:
+            raise EngineError("Recorder: a call was issued on a stream the recording does not know") from None
+
+    def keep(self, obj):
+        self.kept.append(obj)
+
+    def add_call(self, name, args, st):
+        fn = self._fn_ids.get(name)
+        if fn is None:
+            fn = self._fn_ids[name] = load().fb_cmd_fn_id(name.encode())
+            if fn < 0:
+                raise EngineError(f"Recorder: {name} cannot be part of a command list")
+        words, blob = _pack_words(name, args)
+        _check(load().fb_cmdlist_add_call(self.handle, fn, words, len(words), self._stream_index(st), C.addressof(blob) if blob is not None else None,
+                                          C.sizeof(blob) if blob is not None else 0), "fb_cmdlist_add_call")
+
+    def add_event(self, kind, ev, st):
+        _check(load().fb_cmdlist_add_event(self.handle, kind, ev, self._stream_index(st)), "fb_cmdlist_add_event")
+
+    def finish(self):
+        out = CommandList(self.handle, len(self.streams), self.kept)
+        self.handle = None
+        return out
 
 
 def dtype_code(dtype):

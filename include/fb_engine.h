@@ -42,7 +42,33 @@ int fb_abi_version(void);
  * for the recorded launches and returns, per kernel class {0: igemm fwd, 1: igemm dgrad, 2: wgrad}, the summed
  * elapsed milliseconds, the number of launches and the number of launches that were not recorded (pool exhausted). */
 int fb_profile_enable(int on, int capacity);
-int fb_profile_read(double* ms, int64_t* launches, int64_t* dropped);
+int fb_profile_read(double* ms, int64_t* launches, int64_t* dropped);   /* arrays of 6: + {3: BN apply, 4: BN backward reduce, 5: BN backward apply} */
+/* Per-launch records of everything recorded since the last fb_profile_read (which resets: call this one first).  Row i of `info`
+ * ([cap][12] int32): {class, 11 shape words}: convolutions {n_img, Hs, Ws, Cs, Hd, Wd, Cd, R, stride, flags, kernel id}, BatchNorm passes
+ * {pixels/128, C, pixels_per_group/128, dtype, residual?, mask?, dy_out?, pooled?, 0, 0, 0}; ms[i] = elapsed milliseconds.
+ * Returns the number of rows written (<= cap) or a negative fb_status. */
+int64_t fb_profile_read_launches(int32_t* info, float* ms, int64_t cap);
+
+/* ---------------------------------------------------------------- native launch executor -------------------------- */
+/* The reference drives its hot loop from the Python interpreter, one dispatch per operator (training.py:144-174).  A chunk group's
+ * forward + backward here is a STATIC sequence of 430 (ResNet-18) to 6000 (ResNet-152) launches, so a host binding records it once and
+ * replays it with one call: fb_cmdlist_add_call files an entry point (fb_cmd_fn_id(name)) with one 64-bit word per argument except the
+ * trailing stream (integers / pointers extended to 64 bits, float / double as bit patterns; `blob`: the argument struct word 0 points
+ * to -- copied into the list) and the INDEX of the stream it goes to; fb_cmdlist_add_event files a record (kind 1) or wait (kind 2) of a
+ * library event (fb_event_new; fb_event_record / fb_event_wait are the eager forms on the same events, so eager and replayed regions
+ * order against each other).  fb_cmdlist_replay issues the list in order on streams[index].  Lists are host objects: created /
+ * destroyed by the caller, never shared between threads. */
+int32_t fb_cmd_fn_id(const char* name);          /* -1: this entry point cannot be recorded */
+int32_t fb_cmd_fn_nargs(int32_t fn);             /* arguments including the stream */
+int32_t fb_event_new(void);                      /* -1 on failure */
+int fb_event_record(int32_t ev, void* stream);
+int fb_event_wait(int32_t ev, void* stream);
+void* fb_cmdlist_create(void);
+void fb_cmdlist_destroy(void* list);
+int64_t fb_cmdlist_size(const void* list);
+int fb_cmdlist_add_call(void* list, int32_t fn, const uint64_t* words, int32_t n_words, int32_t stream_idx, const void* blob, int32_t blob_bytes);
+int fb_cmdlist_add_event(void* list, int32_t kind, int32_t ev, int32_t stream_idx);
+int fb_cmdlist_replay(const void* list, void* const* streams, int32_t n_streams);
 
 /* ---------------------------------------------------------------- convolution ------------------------------------ */
 /* Implicit-GEMM convolution on MFMA.  mode 0: forward  y = conv(x, w)        (ATen convolution, resnets.py:69,206,209,150)

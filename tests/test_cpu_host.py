@@ -44,6 +44,41 @@ def test_workspace_size_queries():
     assert h.fb_ws_mt_floats(1) == 2 * lib.MT_BLOCKS and h.fb_ws_mt_floats(39) == 39 * lib.MT_BLOCKS
 
 
+def test_command_list_host_side():
+    """Native launch executor, host side only (no launch): every recordable entry point resolves, argument words are packed as the C side
+    unpacks them (one 64-bit word per argument, floats / doubles as bit patterns, the argument struct copied), malformed commands are refused."""
+    import ctypes as C
+    import struct
+
+    from fullbatchtraining_amd import lib
+    h = lib.load()
+    for name in ("fb_conv2d", "fb_conv2d_wgrad", "fb_bn_apply", "fb_bn_bwd_apply", "fb_head_loss", "fb_mt_accumulate", "fb_weight_prep", "fb_absmax"):
+        fn = h.fb_cmd_fn_id(name.encode())
+        assert fn >= 0, name
+        assert h.fb_cmd_fn_nargs(fn) == len(lib._SIGS[name]), name          # (including the stream)
+    assert h.fb_cmd_fn_id(b"fb_stem_patches") == -1                         # takes a HOST array: cannot be recorded
+    a = lib.ConvArgs(n_img=7, Hs=3)
+    words, blob = lib._pack_words("fb_conv2d", (C.byref(a),))
+    assert blob is a and len(words) == 1
+    words, blob = lib._pack_words("fb_bn_fwd_finalize", (0x1234, 5, -1, 64, 2.5, None, 8, 9, 1e-5, 1, 2, 3, 4, 5, 6, 7))
+    assert blob is None and words[0] == 0x1234 and words[2] == 0xFFFFFFFFFFFFFFFF and words[5] == 0
+    assert struct.unpack("<d", struct.pack("<Q", words[4]))[0] == 2.5
+    assert struct.unpack("<f", struct.pack("<I", words[8] & 0xFFFFFFFF))[0] == np.float32(1e-5)
+    cl = h.fb_cmdlist_create()
+    try:
+        fn = h.fb_cmd_fn_id(b"fb_bn_fwd_finalize")
+        assert h.fb_cmdlist_add_call(cl, fn, words, len(words), 0, None, 0) == 0
+        assert h.fb_cmdlist_add_call(cl, fn, words, len(words) - 1, 0, None, 0) != 0      # wrong word count
+        assert h.fb_cmdlist_add_call(cl, 9999, words, len(words), 0, None, 0) != 0
+        assert h.fb_cmdlist_add_event(cl, 1, 12345, 0) != 0                                # unknown event
+        assert h.fb_cmdlist_size(cl) == 1
+        streams = (C.c_void_p * 1)(None)
+        assert h.fb_cmdlist_replay(cl, streams, 0) != 0                                    # stream index 0 of 0 streams
+        assert b"stream" in h.fb_last_error_string()
+    finally:
+        h.fb_cmdlist_destroy(cl)
+
+
 def test_engine_fails_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")

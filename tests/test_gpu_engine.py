@@ -295,6 +295,42 @@ def test_f16x2_scale_slots_are_owned_by_their_buffer(monkeypatch):
     assert t2.data_ptr() == t.data_ptr() and t.data_ptr() not in eng.amax_map
 
 
+@pytest.mark.parametrize("dtype,fd", [(torch.bfloat16, 0), (torch.float32, 1)])
+def test_replayed_command_lists_equal_interpreted_launches(dtype, fd, monkeypatch):
+    """The native launch executor (csrc/cmdlist.cpp) replays exactly the launches the interpreter issued when the list was recorded: three
+    full-gradient evaluations + updates with replay on (the first records, the next two replay) give bit-identical parameters, running
+    statistics, losses and per-chunk norms to the same three steps with every launch going through ctypes (FB_REPLAY=0) -- plain bf16 and
+    the fp32 finite-difference passes (per-chunk weight sets, fp16x2 scale slots), two chunk groups per step, ragged last group."""
+    pixels, chunk, G, n_chunks = 16, 32, 3, 5
+    x, y = make_data(chunk * n_chunks, pixels)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FB_REPLAY", mode)
+        cfg, model, eng, stem_patches = _build(18, pixels, chunk, G, dtype, fd_sets=fd)
+        assert eng.use_replay == (mode == "1")
+        patches, yd = stem_patches(x.cuda(), eng.plan.stem, dtype), y.cuda()
+        trace = []
+        for step in range(3):
+            loss, correct, sq = eng.full_gradient(patches, yd, 0.1, block_strength=0.5 if fd else 0.0)
+            eng.grad_and_param_sqnorm()
+            eng.sgd_step(0.1, 5e-4, 0.9, 0.0, True, grad_clip=0.25)
+            trace.append((loss.clone(), correct.clone(), sq.clone()))
+        torch.cuda.synchronize()
+        if mode == "1":
+            per_step = 2 * (1 + fd) + 1 + 2 * fd          # group passes + weight preparations (shared set + per-chunk sets of each group)
+            assert eng.replays == 2 * per_step, (eng.replays, per_step)
+            assert len(eng.cmdlists) == per_step
+            assert sum(len(c) for c in eng.cmdlists.values()) > 400
+        out[mode] = (eng.theta.clone(), eng.mom.clone(), eng.running_mean.clone(), eng.running_var.clone(), trace, eng.num_batches_tracked)
+    a, b = out["0"], out["1"]
+    for i in range(4):
+        assert torch.equal(a[i], b[i]), i
+    for ta, tb in zip(a[4], b[4]):
+        for u, v in zip(ta, tb):
+            assert torch.equal(u, v)
+    assert a[5] == b[5]
+
+
 def test_imagenet_shaped_maps_chunk_gradient_vs_oracle():
     """ResNet-18 with the 'standard' (ImageNet) stem on 96x96 inputs: feature maps 48 -> (MaxPool) 24, 12, 6, 3 -- non-power-of-two
     sizes like the 56/28/14/7 of the 224x224 configurations (every stride-2 transition halves an even size, as there; the

@@ -8,6 +8,7 @@ import sys
 from collections import defaultdict
 
 os.environ.setdefault("FB_WGRAD_STREAM", "0")
+os.environ["FB_REPLAY"] = "0"          # every launch through the (timed) Python call wrapper
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
