@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3     # f32-input MFMA
+PEAK_HBM_GBS = 8000.0       # HBM3E (spec; 6290 achievable, MI355X_MICROARCH.md)
 CHUNK = 128
 N_IMAGES = 50_000
 
@@ -96,62 +97,250 @@ def cpu_baseline(budget_s=24.0):
             "reference_in_build_container": "SURVEY.md section 6: the real reference, 8 threads: ~122 images/s (off), ~50 images/s (on)"}
 
 
-def side_configs(args, device, X, Y, main_trainer):
-    """Timed in the same run as the headline line (N = 1): BASELINE config 3 (GradRegularizer block_strength 0.5, forward differences,
-    fp32 passes) and the distance between the bf16 path that produced `value` and the fp32 path on the mean gradient of 16 chunks."""
+def _timed_steps(trainer, n_steps, warm):
+    for _ in range(warm):
+        trainer.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        trainer.step()
+    trainer.flush_stats()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n_steps
+
+
+def _side_trainer(args, device, X, Y, overrides, name, env=None):
+    """A second trainer on the same resident synthetic dataset (another configuration of BASELINE.json, timed in the same run)."""
     from fullbatchtraining_amd.cfg import compose
     from fullbatchtraining_amd.models import construct_model
     from fullbatchtraining_amd.training import FullBatchTrainer
 
-    n_steps, warm = 2, 1
-    cfg = compose(["hyp=gradreg", "hyp.warmup=0", f"hyp.steps={n_steps + warm}", "hyp.grad_reg.block_strength=0.5",
-                   f"impl.engine.chunk_group={args.chunk_group}", "impl.mixed_precision=False", "data.augmentations_train="],
-                  original_cwd=os.path.join(ROOT, "gpurun_out"), name="bench_gradreg")
-    torch.manual_seed(1)
-    model = construct_model(cfg.model, 3, 10)
-    setup = dict(device=device, dtype=torch.float, memory_format=torch.contiguous_format)
-    tr = FullBatchTrainer(model, (X, Y), None, setup, cfg)
-    for _ in range(warm):
-        tr.step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n_steps):
-        tr.step()
-    tr.flush_stats()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / n_steps
-    flop = 2 * 3328997376 * tr.datapoints
-    mode = tr.engine.f32_split                              # "f16x2": two scaled fp16 pieces per operand, three MFMAs per product; "bf16x6": three bf16 pieces, six
-    per_product = 3 if mode == "f16x2" else 6
-    arithmetic = ("convolutions on the fp16 matrix pipe: every fp32 operand as two scaled fp16 pieces (22 significand bits, one power-of-two scale per chunk "
-                  "and tensor), three MFMAs per product (f16x2)" if mode == "f16x2" else
-                  "convolutions on the bf16 matrix pipe with an exact three-way split of every fp32 operand (bf16x6)")
-    out = {"configs": {"gradreg": {
-        "workload": f"ResNet-18 CIFAR-10 full-batch GD step + GradRegularizer block_strength=0.5 (forward differences, eps 1e-2), {tr.n_chunks} chunks x "
-                    f"{tr.chunk}, fp32 storage; {arithmetic}",
-        "ms_per_step": round(1000 * dt, 1), "value": round(tr.datapoints / dt, 1), "unit": "images/s", "steps": n_steps, "warmup": warm, "dtype": "f32",
-        "tflops": round(flop / dt / 1e12, 1),
-        "roofline": {"bound": "mfma", "peak": round(PEAK_BF16_TFLOPS / per_product, 1),
-                     "unit": f"TFLOP/s (fp32-equivalent: {per_product} 16-bit MFMAs per fp32 product)",
-                     "achieved": round(flop / dt / 1e12, 1), "frac": round(flop / dt / 1e12 / (PEAK_BF16_TFLOPS / per_product), 4),
-                     "frac_of_f32_mfma_peak": round(flop / dt / 1e12 / PEAK_F32_TFLOPS, 4)}}}}
-    # bf16 vs fp32 on the mean gradient of the first 16 chunks at the benchmark's parameters (tests/test_gpu_bf16_parity.py)
-    K = 16
-    e16, e32 = main_trainer.engine, tr.engine
-    e32.theta.copy_(e16.theta), e32.running_mean.copy_(e16.running_mean), e32.running_var.copy_(e16.running_var)
-    res = []
-    for eng, t in ((e16, main_trainer), (e32, tr)):
-        rm, rv, nbt = eng.running_mean.clone(), eng.running_var.clone(), eng.num_batches_tracked
-        eng.full_gradient(t.patches[:K * t.chunk_pad], t.labels[:K * t.chunk_pad], 0.1)
-        eng.running_mean.copy_(rm), eng.running_var.copy_(rv)
-        eng.num_batches_tracked = nbt
-        res.append(eng.avg.double().clone())
-    a, b = res[1], res[0]
-    out["parity"] = {"bf16_vs_f32_mean_gradient_rel_l2": round(float((a - b).norm() / a.norm()), 4),
-                     "cosine": round(float((a * b).sum() / (a.norm() * b.norm())), 5), "chunks": K,
-                     "note": "error of the bf16 path on the MEAN gradient of 16 chunks at the benchmark's current parameters; it is noise, not bias: "
-                             "0.22 / 0.15 / 0.08 / 0.04 at K = 1 / 4 / 16 / 64 chunks (tests/test_gpu_bf16_parity.py), f32 path vs float64 oracle "
-                             "2.5e-6..2e-3 (tests/test_gpu_engine.py)"}
+    saved = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        cfg = compose(overrides + [f"impl.engine.chunk_group={args.chunk_group}", "data.augmentations_train="],
+                      original_cwd=os.path.join(ROOT, "gpurun_out"), name=name)
+        torch.manual_seed(1)
+        model = construct_model(cfg.model, 3, 10)
+        setup = dict(device=device, dtype=torch.float, memory_format=torch.contiguous_format)
+        return FullBatchTrainer(model, (X, Y), None, setup, cfg)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _mean_gradient(trainer, n_chunks, block_strength=0.0):
+    """Mean (regularised) gradient of the first ``n_chunks`` chunks at the trainer's current parameters; BN running statistics restored."""
+    eng = trainer.engine
+    rm, rv, nbt = eng.running_mean.clone(), eng.running_var.clone(), eng.num_batches_tracked
+    rows = n_chunks * trainer.chunk_pad
+    eng.full_gradient(trainer.patches[:rows], trainer.labels[:rows], 0.1, block_strength=block_strength)
+    eng.running_mean.copy_(rm), eng.running_var.copy_(rv)
+    eng.num_batches_tracked = nbt
+    return eng.avg.double().clone()
+
+
+def _rel(a, b):
+    return {"rel_l2": round(float((a - b).norm() / b.norm()), 5), "cosine": round(float((a * b).sum() / (a.norm() * b.norm())), 6)}
+
+
+def side_configs(args, device, X, Y, main_trainer):
+    """Timed in the same run as the headline line (N = 1), on the same resident dataset:
+      configs.k400            all 50 000 images as 400 chunks of 125 (data.batch_size = 125: the number BASELINE's metric is quoted on)
+      configs.gradreg         BASELINE config 3 (GradRegularizer block_strength 0.5, forward differences) at REFERENCE precision: fp32 storage,
+                              every convolution product exact to 2^-23 (three bf16 pieces per operand, six MFMAs: "bf16x6")
+      configs.gradreg_f16x2   the same step in the arithmetic the engine uses by default for the regulariser: operands carried as two scaled
+                              fp16 pieces (22 significand bits), three MFMAs per product
+      parity                  bf16 (the arithmetic behind `value`) vs fp32 on the mean gradient of ALL chunks of the step, and f16x2 vs
+                              bf16x6 on the regularised mean gradient of 16 chunks"""
+    import gc
+
+    out = {"configs": {}, "parity": {}}
+    flop_img = 3328997376
+    # ---- all 50 000 images: 400 chunks of 125 ----
+    tr = _side_trainer(args, device, X, Y, ["hyp=fb1", "hyp.warmup=0", "hyp.steps=8", "impl.mixed_precision=True", "data.batch_size=125", "hyp.sub_batch=125"], "bench_k400")
+    dt = _timed_steps(tr, 3, 1)
+    out["configs"]["k400"] = {"workload": f"ResNet-18 CIFAR-10 full-batch GD step over ALL {tr.datapoints} images: {tr.n_chunks} chunks x {tr.chunk} (stored padded to "
+                                          f"{tr.chunk_pad} images per chunk), bf16, grad_reg off", "ms_per_step": round(1000 * dt, 2), "value": round(tr.datapoints / dt, 1),
+                              "unit": "images/s", "steps": 3, "warmup": 1, "dtype": "bf16", "step_mfma_frac": round(flop_img * tr.datapoints / dt / (PEAK_BF16_TFLOPS * 1e12), 4),
+                              "train_loss_last": tr.stats["train_loss"][-1]}
+    del tr
+    gc.collect(), torch.cuda.empty_cache()
+    # ---- config 3 in both arithmetic modes ----
+    e16 = main_trainer.engine
+    grads = {}
+    for mode, label, dtype_label in (("bf16x6", "gradreg", "f32"), ("f16x2", "gradreg_f16x2", "f32-22bit")):
+        tr = _side_trainer(args, device, X, Y, ["hyp=gradreg", "hyp.warmup=0", "hyp.steps=8", "hyp.grad_reg.block_strength=0.5", "impl.mixed_precision=False"],
+                           "bench_" + label, env={"FB_F32_SPLIT": mode})
+        assert tr.engine.f32_split == mode
+        dt = _timed_steps(tr, 2, 1)
+        flop = 2 * flop_img * tr.datapoints
+        per_product = 6 if mode == "bf16x6" else 3
+        out["configs"][label] = {
+            "workload": f"ResNet-18 CIFAR-10 full-batch GD step + GradRegularizer block_strength=0.5 (forward differences, eps 1e-2), {tr.n_chunks} chunks x {tr.chunk}, "
+                        "fp32 storage; " + ("every fp32 operand as three bf16 pieces, six MFMAs per product: products exact to 2^-23 (the reference runs these passes in fp32)"
+                                            if mode == "bf16x6" else "every fp32 operand as two scaled fp16 pieces (22 significand bits, one power-of-two scale per chunk and "
+                                            "tensor), three MFMAs per product -- narrower than the reference's fp32: see parity.f16x2_vs_bf16x6"),
+            "arithmetic": mode, "ms_per_step": round(1000 * dt, 1), "value": round(tr.datapoints / dt, 1), "unit": "images/s", "steps": 2, "warmup": 1, "dtype": dtype_label,
+            "train_loss_last": tr.stats["train_loss"][-1],
+            "roofline": {"bound": "mfma", "unit": "TFLOP/s of 16-bit MFMA work", "mfma_per_product": per_product, "achieved": round(per_product * flop / dt / 1e12, 1),
+                         "peak": PEAK_BF16_TFLOPS, "frac": round(per_product * flop / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "algorithmic_tflops": round(flop / dt / 1e12, 1)}}
+        eng = tr.engine
+        eng.theta.copy_(e16.theta), eng.running_mean.copy_(e16.running_mean), eng.running_var.copy_(e16.running_var)
+        grads[mode] = _mean_gradient(tr, 16, block_strength=0.5)
+        if mode == "bf16x6":
+            # the fp32 (exact-product) gradient of ALL chunks at the benchmark's parameters, against the bf16 path that produced `value`
+            t0 = time.perf_counter()
+            g32 = _mean_gradient(tr, tr.n_chunks)
+            torch.cuda.synchronize()
+            t32 = time.perf_counter() - t0
+            g16 = _mean_gradient(main_trainer, main_trainer.n_chunks)
+            out["parity"]["bf16_vs_f32"] = dict(_rel(g16, g32), chunks=tr.n_chunks, f32_gradient_ms=round(1000 * t32, 1),
+                                                note="MEAN gradient of all chunks of the step (what the update consumes), bf16 engine vs fp32 engine (bf16x6) at "
+                                                     "the benchmark's current parameters; single chunks differ by ~0.2 (ReLU-mask flips of 2^-9-rounded pre-activations: "
+                                                     "noise, not bias -- tests/test_gpu_bf16_parity.py asserts the 1/sqrt(K) decay)")
+            g16_16, g32_16 = _mean_gradient(main_trainer, 16), _mean_gradient(tr, 16)
+            out["parity"]["bf16_vs_f32_16_chunks"] = dict(_rel(g16_16, g32_16), chunks=16)
+        del tr, eng
+        gc.collect(), torch.cuda.empty_cache()
+    out["parity"]["f16x2_vs_bf16x6"] = dict(_rel(grads["f16x2"], grads["bf16x6"]), chunks=16,
+                                            note="regularised (forward differences, block_strength 0.5) mean gradient of 16 chunks of 128 at 32 px, same parameters: "
+                                                 "22-bit operands vs exact fp32 products")
+    return out
+
+
+def _launch_work(cls, w, stem):
+    """Algorithmic FLOP and bytes of one recorded launch from its shape words (include/fb_engine.h: fb_profile_read_launches)."""
+    if cls in ("igemm_fwd", "igemm_dgrad", "wgrad"):
+        n, hs, ws, cs, hd, wd, cd, r, stride, flags, kernel = w
+        eb = 2 if ((flags >> 4) & 1 if cls != "wgrad" else (flags >> 16) & 1) else 4
+        if cls == "igemm_fwd":
+            macs, cin = n * hd * wd * cd * r * r * cs, cs
+            byts = n * hs * ws * cs * eb + n * hd * wd * cd * eb
+        elif cls == "igemm_dgrad":                         # src = dY [Hs,Ws,Cs] -> dst = dX [Hd,Wd,Cd]
+            macs, cin = n * hs * ws * cs * r * r * cd, cd
+            addend = flags & 3
+            byts = n * hs * ws * cs * eb + n * hd * wd * cd * eb * (2 if addend == 1 else 1) + (n * hd * wd * cd * eb // 4 if addend == 2 else 0)
+        else:                                              # x [Hs,Ws,Cs], dy [Hd,Wd,Cd]
+            macs, cin = n * hd * wd * cd * r * r * cs, cs
+            byts = n * hs * ws * cs * eb + n * hd * wd * cd * eb
+        if r == 1 and cin == stem.cin_pad and (hd == stem.hout if cls != "igemm_dgrad" else False):
+            macs = macs * stem.cin_real // stem.cin_pad    # the pre-gathered stem patches are zero-padded 27 -> 32 (147 -> 160): not algorithmic work
+        shape = f"{cs}->{cd} k{r} s{stride} {hs}x{ws}->{hd}x{wd}" + (" +add" if cls == "igemm_dgrad" and flags & 3 else "")
+        return 2.0 * macs, float(byts), shape, kernel
+    px128, c, _, dtype, res, mask, dy_out, pooled = w[:8]
+    eb = 2 if dtype == 1 else 4
+    elems = px128 * 128 * c
+    passes = {"bn_apply": 2 + res + 0.25 * pooled, "bn_bwd_reduce": 2, "bn_bwd_apply": 3 + dy_out}[cls]
+    return 0.0, elems * eb * passes + (elems * eb / 16 if mask else 0), f"C{c} {px128 * 128} px", 0
+
+
+def _kernel_table(launches, stem, n_steps):
+    """Per (kernel, class, shape): launches, ms per step, algorithmic TFLOP/s and GB/s, fractions of both ceilings."""
+    from fullbatchtraining_amd import lib
+    rows = {}
+    for cls, words, ms in launches:
+        flop, byts, shape, kernel = _launch_work(cls, words, stem)
+        name = lib.PROF_KERNELS.get(kernel, "?") if flop else {"bn_apply": "bn_apply_span_kernel", "bn_bwd_reduce": "bn_bwd_reduce_kernel", "bn_bwd_apply": "bn_bwd_apply_span_kernel"}[cls]
+        r = rows.setdefault((name, cls, shape), [0, 0.0, 0.0, 0.0])
+        r[0] += 1
+        r[1] += ms
+        r[2] += flop
+        r[3] += byts
+    table = []
+    for (name, cls, shape), (n, ms, flop, byts) in rows.items():
+        tf, gbs = flop / (ms * 1e-3) / 1e12, byts / (ms * 1e-3) / 1e9
+        table.append({"kernel": name, "class": cls, "shape": shape, "launches_per_step": round(n / n_steps, 2), "ms_per_step": round(ms / n_steps, 3),
+                      "avg_launch_us": round(1000 * ms / n, 1), "tflops": round(tf, 1), "gbs_algorithmic": round(gbs, 1),
+                      "frac_mfma": round(tf / PEAK_BF16_TFLOPS, 4), "frac_hbm": round(gbs / PEAK_HBM_GBS, 4),
+                      "flop_per_launch": flop / n, "bytes_per_launch": byts / n})
+    table.sort(key=lambda r: -r["ms_per_step"])
+    return table
+
+
+def _by_kernel(table):
+    agg = {}
+    for r in table:
+        a = agg.setdefault(r["kernel"], {"ms_per_step": 0.0, "launches_per_step": 0.0, "flop": 0.0, "bytes": 0.0})
+        a["ms_per_step"] += r["ms_per_step"]
+        a["launches_per_step"] += r["launches_per_step"]
+        a["flop"] += r["flop_per_launch"] * r["launches_per_step"]
+        a["bytes"] += r["bytes_per_launch"] * r["launches_per_step"]
+    for k, a in agg.items():
+        a["tflops"] = round(a["flop"] / (a["ms_per_step"] * 1e-3) / 1e12, 1)
+        a["gbs_algorithmic"] = round(a["bytes"] / (a["ms_per_step"] * 1e-3) / 1e9, 1)
+        a["frac_mfma"], a["frac_hbm"] = round(a["tflops"] / PEAK_BF16_TFLOPS, 4), round(a["gbs_algorithmic"] / PEAK_HBM_GBS, 4)
+        a["avg_launch_us"] = round(1000 * a["ms_per_step"] / a["launches_per_step"], 1)
+        a["flop_per_launch"], a["bytes_per_launch"] = a.pop("flop") / a["launches_per_step"], a.pop("bytes") / a["launches_per_step"]
+        a["ms_per_step"], a["launches_per_step"] = round(a["ms_per_step"], 3), round(a["launches_per_step"], 2)
+    return agg
+
+
+def roofline_objects(args, trainer, launches, launches_iso, sec_per_step, world, headline, passes):
+    """`roofline` (dominant MFMA kernel), `roofline_hbm` (dominant HBM-bound kernel), `hbm` (PMC traffic of the whole step) and the
+    per-kernel / per-shape tables behind them.  Kernel = the __global__ function that served the launches (not a class of them)."""
+    eng = trainer.engine
+    stem = eng.plan.stem
+    in_region = _kernel_table(launches, stem, args.steps)
+    iso = _kernel_table(launches_iso, stem, 1) if launches_iso else None
+    k_in, k_iso = _by_kernel(in_region), (_by_kernel(iso) if iso else None)
+    basis = k_iso or k_in                                   # additive durations (one stream) decide which kernel dominates
+    mfma = {k: v for k, v in basis.items() if v["flop_per_launch"] > 0}
+    hbmk = {k: v for k, v in basis.items() if v["flop_per_launch"] == 0}
+    dom = max(mfma, key=lambda k: mfma[k]["ms_per_step"])
+    dom_h = max(hbmk, key=lambda k: hbmk[k]["ms_per_step"]) if hbmk else None
+    profiled = trainer.dtype == torch.bfloat16 and args.grad_reg == 0 and world == 1 and eng.G == 98 and headline and args.chunk == CHUNK
+    pmc = None
+    if profiled:            # HBM bytes from the PMC passes (tools/pmc_bench.sh: FETCH_SIZE x2 + WRITE_SIZE, one counter per rocprofv3 pass, MI355X_MICROARCH.md)
+        path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        with open(path) as handle:                          # a missing or unreadable evidence file is an error, not a null
+            pmc = json.load(handle)
+        if not pmc.get("kernels") or not pmc.get("total_bytes_per_step"):
+            raise RuntimeError(f"{path}: no per-kernel PMC traffic in it (regenerate with tools/pmc_bench.sh)")
+
+    def traffic_of(kernel):
+        if pmc is None:
+            return None
+        hits = [v for k, v in pmc["kernels"].items() if kernel in k]
+        n = sum(v["launches"] for v in hits)
+        return sum(v["bytes_per_launch"] * v["launches"] for v in hits) / n if n else None
+
+    def worst(rows, key):
+        rows = [r for r in rows if r["ms_per_step"] >= 0.25]        # launches that matter (>= 0.1 % of the step)
+        r = min(rows, key=lambda r: r[key])
+        return {k: r[k] for k in ("kernel", "class", "shape", "ms_per_step", "avg_launch_us", "tflops", "gbs_algorithmic", "frac_mfma", "frac_hbm")}
+
+    table = iso or in_region
+    conv_rows = [r for r in table if r["flop_per_launch"] > 0]
+    flop_img = 3328997376 if headline else sum(conv_flops(eng.plan, 1).values())
+    out = {"roofline": {
+        "bound": "mfma", "kernel": dom, "achieved": k_in[dom]["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": k_in[dom]["frac_mfma"],
+        "traffic": traffic_of(dom), "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": ("profiles/hbm_traffic.json: " + pmc["command"]) if pmc else None,
+        "flop_per_launch": k_in[dom]["flop_per_launch"], "avg_launch_us": k_in[dom]["avg_launch_us"], "launches_per_step": k_in[dom]["launches_per_step"],
+        "algorithmic_bytes_per_launch": k_in[dom]["bytes_per_launch"],
+        "measured": "HIP events on the launch stream around every launch, over a repetition of the timed steps in the production schedule (weight-gradient "
+                    "kernels on a second stream beside these launches); `isolated` = one more step with one stream: every kernel alone on the device",
+        "achieved_isolated": k_iso[dom]["tflops"] if k_iso else None, "frac_isolated": k_iso[dom]["frac_mfma"] if k_iso else None,
+        "step_mfma_frac": round(flop_img * passes * trainer.datapoints / sec_per_step / world / (PEAK_BF16_TFLOPS * 1e12), 4),
+        "per_kernel": {k: {f: v[f] for f in ("ms_per_step", "launches_per_step", "avg_launch_us", "tflops", "frac_mfma", "gbs_algorithmic", "frac_hbm")} for k, v in basis.items()},
+        "per_kernel_in_region": {k: {f: v[f] for f in ("ms_per_step", "tflops", "frac_mfma")} for k, v in k_in.items() if v["flop_per_launch"] > 0},
+        "worst_mfma_launch": worst(conv_rows, "frac_mfma"),
+        "worst_launch_vs_both_ceilings": worst([dict(r, best=max(r["frac_mfma"], r["frac_hbm"])) for r in conv_rows], "best"),
+        "per_shape": [{k: r[k] for k in ("kernel", "class", "shape", "launches_per_step", "ms_per_step", "avg_launch_us", "tflops", "gbs_algorithmic", "frac_mfma", "frac_hbm")}
+                      for r in table[:48]]}}
+    if dom_h is not None:
+        out["roofline_hbm"] = {"bound": "hbm", "kernel": dom_h, "achieved": k_in[dom_h]["gbs_algorithmic"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": k_in[dom_h]["frac_hbm"], "achievable": 6290.0, "frac_of_achievable": round(k_in[dom_h]["gbs_algorithmic"] / 6290.0, 4),
+                               "traffic": traffic_of(dom_h), "algorithmic_bytes_per_launch": k_in[dom_h]["bytes_per_launch"], "avg_launch_us": k_in[dom_h]["avg_launch_us"],
+                               "achieved_isolated": k_iso[dom_h]["gbs_algorithmic"] if k_iso else None}
+    if pmc is not None:
+        total = pmc["total_bytes_per_step"]
+        out["hbm"] = {"bytes_per_step": total, "tb_per_s": round(total / sec_per_step / 1e12, 3), "peak_tb_per_s": PEAK_HBM_GBS / 1e3,
+                      "frac": round(total / sec_per_step / 1e9 / PEAK_HBM_GBS, 4), "source": "profiles/hbm_traffic.json: " + pmc["command"],
+                      "by_kernel_gb_per_step": {k: round(v["bytes_per_launch"] * v["launches"] / 1e9, 2) for k, v in sorted(pmc["kernels"].items(), key=lambda kv: -kv[1]["bytes_per_launch"] * kv[1]["launches"])[:12]}}
     return out
 
 
@@ -267,9 +456,7 @@ def main():
 
     for _ in range(args.warmup):
         trainer.step()
-    timing = not args.no_kernel_timing
-    if timing:            # HIP events around every convolution launch, on its launch stream, INSIDE the timed region
-        lib.profile_enable(True, 65536)
+    # ---- the timed region: EXACTLY --steps steps of the production schedule, no instrumentation ----
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -277,24 +464,40 @@ def main():
     trainer.flush_stats()            # the statistics of every timed step are read back and recorded inside the timed region
     sync()
     elapsed = time.perf_counter() - t0
-    prof, prof_iso = None, None
-    if timing:
-        prof = lib.profile_read()
-        if not args.serialize:
-            # In the timed region the weight-gradient kernels run on their own stream beside dgrad / BN backward, so an event bracket there
-            # times a kernel that shares the GPU.  One more step of the same workload with that stream folded into the main one gives
-            # the duration of each kernel alone on the device ("isolated"), which is what the rocprofv3 summaries in profiles/ show.
-            saved, eng.wstream = eng.wstream, None
-            trainer.step()
-            sync()
-            eng.wstream = saved
-            prof_iso = lib.profile_read()
-        lib.profile_enable(False)
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(t[0])
+    enqueue_ms = round(1000 * sum(trainer.enqueue_times[-args.steps:]) / max(args.steps, 1), 2)
+    loss_last = trainer.stats["train_loss"][-1]
 
+    # ---- the same --steps steps again with HIP events (libfbengine's fb_profile_*) around every convolution and BatchNorm launch, on its
+    # launch stream: the in-region kernel durations of the roofline object (its wall time is reported beside `ms_per_step`) ----
+    launches = launches_iso = None
+    elapsed_ev = None
+    if not args.no_kernel_timing:                       # (every rank steps: the step is collective)
+        lib.profile_enable(True, 1 << 17)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            trainer.step()
+        trainer.flush_stats()
+        sync()
+        elapsed_ev = time.perf_counter() - t0
+        launches = lib.profile_read_launches()
+        lib.profile_read()
+        if not args.serialize and world == 1:
+            # In the production schedule the weight-gradient kernels run on their own stream beside dgrad / BN backward, so an event bracket
+            # there times a kernel that shares the GPU.  One more step with that stream folded into the main one gives each kernel's
+            # duration alone on the device ("isolated"): what the rocprofv3 --kernel-trace summaries under profiles/ show.
+            saved_stream, saved_lists = eng.wstream, eng.cmdlists
+            eng.wstream, eng.cmdlists = None, {}
+            trainer.step()
+            torch.cuda.synchronize()
+            eng.wstream, eng.cmdlists = saved_stream, saved_lists
+            launches_iso = lib.profile_read_launches()
+            lib.profile_read()
+        lib.profile_enable(False)
     if rank == 0:
         images_per_step = trainer.datapoints
         steps_per_sec = args.steps / elapsed
@@ -305,56 +508,22 @@ def main():
             "value": round(images_per_step * steps_per_sec, 1), "unit": "images/s",
             "steps_per_sec": round(steps_per_sec, 4), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "bf16" if trainer.dtype == torch.bfloat16 else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if trainer.dtype == torch.bfloat16 else ("f32" if eng.f32_split != "f16x2" else "f32-22bit"), "data": "synthetic",
             "config": {"workload": f"{'ResNet-18 CIFAR-10' if headline else args.model + ' ' + str(args.pixels) + 'px'} full-batch GD step, {trainer.n_chunks} chunks x {trainer.chunk} = {images_per_step} "
                                    f"images/step (drop_last), grad_reg block_strength={args.grad_reg}, fp32 master/accumulate",
-                       "chunk_group": eng.G, "parallelism": f"dp{world} (contiguous chunk ranges, reduce-scatter + all-gather)"},
-            "train_loss_last": trainer.stats["train_loss"][-1],
+                       "chunk_group": eng.G, "parallelism": f"dp{world} (contiguous chunk ranges, reduce-scatter + all-gather)",
+                       "launches": "native command lists (one host call per chunk group)" if eng.use_replay else "one ctypes call per launch (FB_REPLAY=0)"},
+            "train_loss_last": loss_last,
             # host time from the start of a step until its last kernel is queued (mean over the timed steps): launch overhead that the
             # GPU hides as long as it stays below ms_per_step
-            "host_enqueue_ms_per_step": round(1000 * sum(trainer.enqueue_times[-args.steps:]) / max(args.steps, 1), 2),
+            "host_enqueue_ms_per_step": enqueue_ms,
             "outside_the_step": "the dataset is resident in HBM and the stem's im2col patches (fb_stem_patches, 3.3 GB bf16, ~3 ms) are "
                                 "gathered once before the timed region (static, un-augmented dataset); inside: weight prep, all chunk "
                                 "forward/backward passes, running mean, clip + SGD update, statistics read-back",
         }
-        if prof is not None:
-            peak = PEAK_BF16_TFLOPS if trainer.dtype == torch.bfloat16 else PEAK_F32_TFLOPS
-
-            def per_class(table, n_steps):
-                flops = conv_flops(eng.plan, trainer.shard.count * trainer.chunk * n_steps * passes)
-                res = {}
-                for k, (ms, launches, dropped) in table.items():
-                    if launches:
-                        scale = launches / max(launches + dropped, 1)
-                        res[k] = {"ms_total": round(ms, 2), "launches": launches, "dropped": dropped, "avg_launch_us": round(1000 * ms / launches, 2),
-                                  "tflops": round(flops[k] * scale / (ms * 1e-3) / 1e12, 1)}
-                return res, flops
-
-            kernels, flops = per_class(prof, args.steps)
-            iso = per_class(prof_iso, 1)[0] if prof_iso is not None else None
-            # dominant class = the one with the most kernel time when every kernel has the device to itself (inside the timed region the
-            # weight-gradient launches of the second stream overlap the others, so the in-region durations are not additive)
-            dom = max(iso or kernels, key=lambda k: (iso or kernels)[k]["ms_total"])
-            # HBM bytes per launch of the same kernel class from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, one counter per rocprofv3
-            # pass as MI355X_MICROARCH.md prescribes; tools/pmc_bench.sh writes the file, profiles/ keeps the copy behind the number)
-            traffic, traffic_src = None, None
-            try:
-                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")) as handle:
-                    pmc = json.load(handle)
-                if trainer.dtype == torch.bfloat16 and args.grad_reg == 0 and world == 1 and eng.G == 98 and headline:   # the profiled configuration
-                    traffic, traffic_src = pmc["classes"][dom]["bytes_per_launch"], "profiles/hbm_traffic.json: " + pmc["command"]
-            except (OSError, KeyError, ValueError):
-                pass
-            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-                               "flop_per_launch": flops[dom] / max(kernels[dom]["launches"] + kernels[dom]["dropped"], 1),
-                               "avg_launch_us": kernels[dom]["avg_launch_us"], "kernels": kernels,
-                               "measured": "HIP events on the launch stream around every launch of the class, inside the timed region"
-                                           + (" (--serialize: one stream)" if args.serialize else " (production schedule: weight-gradient kernels "
-                                              "run on a second stream beside these launches; `isolated` = the same from one extra step with one stream)"),
-                               "achieved_isolated": iso[dom]["tflops"] if iso else None, "frac_isolated": round(iso[dom]["tflops"] / peak, 4) if iso else None,
-                               "isolated": iso,
-                               "step_mfma_frac": round((3328997376 if headline else sum(conv_flops(eng.plan, 1).values())) * passes * images_per_step * steps_per_sec / world / (peak * 1e12), 4)}
+        if launches is not None:
+            out["ms_per_step_with_kernel_events"] = round(1000 * elapsed_ev / args.steps, 2)
+            out.update(roofline_objects(args, trainer, launches, launches_iso, elapsed / args.steps, world, headline, passes))
         if world == 1 and headline and args.grad_reg == 0 and trainer.dtype == torch.bfloat16 and not args.no_side_configs:
             out.update(side_configs(args, device, X, Y, trainer))
         if world == 1 and not args.no_cpu_baseline:
