@@ -15,6 +15,8 @@ mean and changes chunk composition; here the 1-process semantics are
 The collective wiring is independent of the compute backend: ``ShardOps`` supplies scale / squared-norm / update
 callables (HIP kernels in the product, CPU stand-ins in the gloo tests).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -70,7 +72,10 @@ class BucketExchange:
     called early -- from the stream on which bucket i's running mean was completed (``Engine.full_gradient(late_bucket=...)``) -- and
     ``finish()`` starts whatever has not left yet, waits, all-reduces the squared norm, runs the shard-local clip + update on the
     rank's range of every bucket and all-gathers the updated parameters bucket by bucket.
-    Total traffic is that of ONE reduce-scatter + ONE all-gather of the arena, cut in two messages each."""
+    Total traffic is that of ONE reduce-scatter + ONE all-gather of the arena, cut in two messages each.
+    On gloo (CPU tests, shared-device development runs) ``start`` is a BLOCKING all-reduce of the bucket in place: the ranks rendezvous
+    inside the backward pass, so that path checks ordering and arithmetic, never overlap; and the ranges of ``avg`` a rank does not own
+    hold the reduced values there but the rank's un-reduced local values on RCCL -- they are undefined until ``gather_sharded_state``."""
 
     def __init__(self, avg, theta, plan, ops, bounds, group=None):
         self.avg, self.theta, self.plan, self.ops, self.group = avg, theta, plan, ops, group
@@ -99,6 +104,13 @@ class BucketExchange:
             work = None
         else:
             work = dist.reduce_scatter_tensor(shard, part, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if os.environ.get("FB_EXCHANGE_POISON") == "1":
+            # test switch: once the bucket has left, nothing may read this rank's LOCAL values of it again (finish() consumes ``shard``; the
+            # ranges of ``avg`` a rank does not own are undefined until gather_sharded_state()).  Overwrite them with NaN behind the
+            # collective, on the stream it was started from: any later consumer of the stale slice poisons the step.
+            if work is not None:
+                work.wait()
+            part.fill_(float("nan"))
         self.pending[i] = (shard, work, torch.cuda.current_stream().record_event() if part.is_cuda else None)
 
     def finish(self):

@@ -482,6 +482,11 @@ class FullBatchTrainer:
         """One optimizer step = the reference's ``optimizer.step(gradient_evaluation)`` (training.py:226-237)."""
         cfg, eng, hyp = self.cfg, self.engine, self.cfg.hyp
         train_time = time.time()
+        # reference `train_time` = wall time of the gradient evaluation (training.py:112,122), which ends in a device sync there.  Here the host
+        # runs a step ahead of the GPU and a step's statistics are read back while the next one is queued, so the step's duration is taken
+        # on the DEVICE: from this event (it follows the previous step's last kernel in stream order) to the read-back of the statistics
+        self._step_begin = torch.cuda.Event(enable_timing=True)
+        self._step_begin.record()
         if self.augment is not None and self.images is not None:
             self._regather_augmented()
         if self.shuffler is not None:
@@ -667,9 +672,9 @@ class FullBatchTrainer:
         dev = torch.cat([loss_k, correct_k, sq_k, norms2, pre2, clipped])
         host = self._pinned.pop() if self._pinned and self._pinned[-1].numel() == dev.numel() else torch.empty(dev.numel(), dtype=torch.float32, pin_memory=True)
         host.copy_(dev, non_blocking=True)
-        done = torch.cuda.Event()
+        done = torch.cuda.Event(enable_timing=True)
         done.record()
-        self._pending.append((host, done, lr, train_time))
+        self._pending.append((host, done, lr, (self._step_begin, done)))
         self.flush_stats(keep=1)
 
     def flush_stats(self, keep=0):
@@ -706,7 +711,7 @@ class FullBatchTrainer:
             full_loss = full_loss + lr / 4 * hyp.grad_reg.acc_strength * pre2
         stats.raw("train_loss").append(train_loss.item())
         stats.raw("train_acc").append(correct_k.sum().item() / self.datapoints)
-        stats.raw("train_time").append(time.time() - train_time)
+        stats.raw("train_time").append(train_time[0].elapsed_time(train_time[1]) * 1e-3)
         stats.raw("param_norm").append(param_norm.item())
         stats.raw("grad_norm").append(full_grad_norm.sqrt().item())
         stats.raw("full_loss").append(full_loss.item())

@@ -266,10 +266,10 @@ def _worker(rank, world, port, K, P, out_dir, bucketed=False):
         theta[lo:lo + n] -= lr * (d + mu * mom[lo:lo + n])
 
     ops = ShardOps(scale=lambda t, a: t.mul_(a), sqnorm=lambda t: t.pow(2).sum(), update=update)
-    if bucketed:       # two buckets; rank 0 starts the late one early (as the engine does from its side stream), rank 1 only in finish()
+    if bucketed:       # two buckets; even ranks start the late one early (as the engine does from its side stream), odd ranks only in finish()
         from fullbatchtraining_amd.parallel import BucketExchange
         ex = BucketExchange(avg, theta, plan, ops, [0, 64 * 2, P])
-        if rank == 0:
+        if rank % 2 == 0:
             ex.start(1)
         gnorm2 = ex.finish()
     else:
@@ -290,13 +290,15 @@ def _worker(rank, world, port, K, P, out_dir, bucketed=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("bucketed", [False, True])
-def test_sharded_step_matches_single_process(tmp_path, bucketed):
-    """2 gloo ranks: reduce-scatter(sum of K_r/K-scaled local means) + sharded clip/SGD + all-gather == 1-process step on the
-    exact mean (checked with the oracle's SGD), stats gathered in chunk order, BN running stats recombined exactly."""
+@pytest.mark.parametrize("bucketed,K,world", [(False, 7, 2), (True, 7, 2), (True, 390, 8), (False, 390, 8), (True, 5, 8)])
+def test_sharded_step_matches_single_process(tmp_path, bucketed, K, world):
+    """gloo ranks (2, and the benchmark's 8 with its 390 chunks: 49 / 48 per rank; 5 chunks on 8 ranks: ranks WITHOUT chunks):
+    reduce-scatter(sum of K_r/K-scaled local means) + sharded clip/SGD + all-gather == 1-process step on the exact mean (checked with the
+    oracle's SGD), stats gathered in chunk order, BN running stats recombined exactly; bucketed: half of the ranks start their late bucket
+    early, the others in finish() -- every rank still issues its collectives in the same order."""
     from oracle import fb_oracle as orc
 
-    K, P, world = 7, 64 * 6, 2
+    P = 64 * 6
     port = _free_port()
     mp.spawn(_worker, args=(world, port, K, P, str(tmp_path), bucketed), nprocs=world, join=True)
     torch.manual_seed(0)
@@ -321,4 +323,5 @@ def test_sharded_step_matches_single_process(tmp_path, bucketed):
         assert torch.allclose(o["running"], running, rtol=1e-5, atol=1e-6)
         for lo, n in o["owned"]:           # sharded momentum: this rank's range of every bucket
             assert torch.allclose(o["mom_shard"][lo:lo + n], momentum[0][lo:lo + n], rtol=1e-5, atol=1e-6)
-    assert torch.equal(outs[0]["theta"], outs[1]["theta"])
+    for o in outs[1:]:
+        assert torch.equal(outs[0]["theta"], o["theta"])

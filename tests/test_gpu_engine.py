@@ -270,7 +270,7 @@ def test_resnet152_at_224_regulariser_f16x2(monkeypatch):
             assert np.isfinite(float(loss2[0])) and np.isfinite(float(sq2[0])) and bool(torch.isfinite(eng.avg).all())
         del eng, patches
         torch.cuda.empty_cache()
-    (l16, a16, s16), (l6, a6, s6) = results["f16x2"], results["bf16x6"]
+    (l16, a16, s16, _), (l6, a6, s6, _) = results["f16x2"], results["bf16x6"]
     err = float((a16 - a6).norm() / a6.norm())
     print(f"resnet152@224 regularised chunk gradient, f16x2 vs bf16x6: {err:.3e}; loss {l16:.6f} vs {l6:.6f}; |g_k|^2 {s16:.5e} vs {s6:.5e}")
     assert abs(l16 - l6) < 1e-4 * abs(l6)

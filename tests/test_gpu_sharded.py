@@ -129,10 +129,18 @@ def test_rccl_collectives_one_rank(tmp_path, monkeypatch):
     backend with a process group of ONE rank on cuda:0 (FB_FORCE_DIST=1 routes the step through the sharded path): on a 1-GPU box this
     is the only way to execute those calls; the arithmetic must equal the plain 1-process step bit for bit."""
     out = str(tmp_path)
-    for mode in (False, "onegroup", "onegroup_gradreg"):      # "onegroup*": the late bucket's asynchronous reduce-scatter starts on the side stream
+    # "onegroup*": the late bucket's asynchronous reduce-scatter starts on the side stream, from inside the last backward pass; "+poison": the
+    # local values of that bucket are overwritten with NaN behind the collective (FB_EXCHANGE_POISON) -- any consumer of the stale slice
+    # (a launch ordered on the wrong stream, an update reading ``avg`` instead of the reduced shard) would poison the step
+    for mode in (False, "onegroup", "onegroup_gradreg", "onegroup+poison", "onegroup_gradreg+poison"):
+        poison = mode is not False and mode.endswith("+poison")
+        mode = mode[:-len("+poison")] if poison else mode
         monkeypatch.delenv("FB_FORCE_DIST", raising=False)
+        monkeypatch.delenv("FB_EXCHANGE_POISON", raising=False)
         mp.spawn(_run, args=(1, 0, out, mode), nprocs=1, join=True)
         monkeypatch.setenv("FB_FORCE_DIST", "1")
+        if poison:
+            monkeypatch.setenv("FB_EXCHANGE_POISON", "1")
         mp.spawn(_run, args=(1, _free_port(), out, mode, "nccl", "rccl1"), nprocs=1, join=True)
         ref, got = torch.load(os.path.join(out, "w1_r0.pt")), torch.load(os.path.join(out, "rccl1_r0.pt"))
         _compare(got, ref, mode)
