@@ -51,7 +51,11 @@ def krsc(w):  # [co, ci, kh, kw] -> [co, kh*kw, ci]
                                                    (64, 64, 3, 1, 8, 2400), (64, 128, 3, 1, 16, 300), (64, 64, 3, 1, 32, 160),   # > 2 tiles per persistent workgroup
                                                    (32, 64, 1, 1, 32, 40), (32, 64, 1, 1, 32, 300),   # stem on patches: streaming K = 32 kernel (bf16), grid-stride
                                                    (64, 128, 3, 2, 32, 3), (128, 256, 3, 2, 16, 6), (96, 64, 3, 2, 16, 4),   # more stride-2 shapes
-                                                   (128, 128, 3, 1, 4, 48), (512, 512, 3, 1, 4, 272), (64, 256, 3, 1, 4, 16)])   # 4x4 maps: 128-channel halo tiles (bf16)
+                                                   (128, 128, 3, 1, 4, 48), (512, 512, 3, 1, 4, 272), (64, 256, 3, 1, 4, 16),   # 4x4 maps: 128-channel halo tiles (bf16)
+                                                   # short-K 1x1 convolutions: streaming kernel (bf16), every (K, channels-per-wave) variant, ragged pixel counts,
+                                                   # several units per persistent workgroup
+                                                   (64, 128, 1, 1, 16, 3), (128, 256, 1, 1, 8, 5), (256, 512, 1, 1, 4, 16), (256, 1024, 1, 1, 14, 2), (64, 256, 1, 1, 8, 3),
+                                                   (128, 128, 1, 1, 8, 40), (256, 128, 1, 1, 6, 3), (64, 128, 1, 1, 6, 3), (64, 128, 1, 1, 16, 700), (256, 256, 1, 1, 14, 300)])
 def test_conv_fwd_and_stats(dtype, cin, cout, k, stride, hw, n):
     lib = _lib()
     torch.manual_seed(0)
@@ -82,7 +86,11 @@ def test_conv_fwd_and_stats(dtype, cin, cout, k, stride, hw, n):
                                                           # stride-2 quad kernel (bf16): dY 16x16 / 8x8 / 4x4, ragged image counts, all addend modes
                                                           (64, 128, 3, 2, 32, 3, 2), (128, 256, 3, 2, 16, 5, 1), (64, 64, 3, 2, 8, 11, 2),
                                                           (128, 96, 3, 2, 16, 2, 0), (64, 128, 3, 2, 32, 70, 0),
-                                                          (256, 128, 3, 1, 4, 32, 1), (128, 256, 3, 1, 4, 16, 0), (512, 512, 3, 1, 4, 272, 1)])   # 4x4 maps, 128-channel halo tiles
+                                                          (256, 128, 3, 1, 4, 32, 1), (128, 256, 3, 1, 4, 16, 0), (512, 512, 3, 1, 4, 272, 1),   # 4x4 maps, 128-channel halo tiles
+                                                          # 1x1 input gradients: streaming kernel (K = the forward layer's output channels <= 256), with / without the
+                                                          # same-shape addend; pooled addend and K = 512 stay on the implicit GEMM
+                                                          (256, 128, 1, 1, 8, 5, 0), (1024, 256, 1, 1, 7, 4, 1), (512, 128, 1, 1, 8, 3, 1), (128, 64, 1, 1, 16, 300, 1),
+                                                          (256, 64, 1, 1, 8, 6, 2), (256, 512, 1, 1, 4, 16, 1)])
 def test_conv_dgrad(dtype, cin, cout, k, stride, hw, n, amode, monkeypatch):
     monkeypatch.setenv("FB_S2_QUAD_ALL", "1")      # the quad kernel also for 4x4 gradients (production keeps the implicit GEMM there)
     lib = _lib()

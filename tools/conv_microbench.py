@@ -11,6 +11,10 @@ CASES = {  # name: (cin, cout, k, stride, hw, n_img)
     "d2": (64, 128, 3, 2, 32, 12544), "d3": (128, 256, 3, 2, 16, 12544), "d4": (256, 512, 3, 2, 8, 12544),
     "s2": (64, 128, 1, 1, 16, 12544), "s3": (128, 256, 1, 1, 8, 12544), "s4": (256, 512, 1, 1, 4, 12544),
     "l2g": (128, 128, 3, 1, 16, 12544), "l3g": (256, 256, 3, 1, 8, 12544), "l4g": (512, 512, 3, 1, 4, 12544), "stemg": (32, 64, 1, 1, 32, 12544),
+    # ResNet-152 @224, one chunk group of 4 chunks (512 images): the 1x1 convolutions of the Bottleneck stages and their 3x3s
+    "b1a": (64, 256, 1, 1, 56, 512), "b1b": (256, 64, 1, 1, 56, 512), "b2a": (128, 512, 1, 1, 28, 512), "b2b": (512, 128, 1, 1, 28, 512),
+    "b3a": (256, 1024, 1, 1, 14, 512), "b3b": (1024, 256, 1, 1, 14, 512), "b4a": (512, 2048, 1, 1, 7, 512), "b4b": (2048, 512, 1, 1, 7, 512),
+    "c1": (64, 64, 3, 1, 56, 512), "c2": (128, 128, 3, 1, 28, 512), "c3": (256, 256, 3, 1, 14, 512), "c4": (512, 512, 3, 1, 7, 512),
     "l1big": (64, 64, 3, 1, 32, 3840), "l2big": (128, 128, 3, 1, 16, 3840), "l3big": (256, 256, 3, 1, 8, 3840), "l4big": (512, 512, 3, 1, 4, 3840),
 }
 
@@ -43,10 +47,12 @@ def main():
         dx = torch.empty(n, hw, hw, cin, device="cuda", dtype=dtype)
         stat = torch.zeros(2, (n * ho * ho + 127) // 128, cout, device="cuda")
         flops = 2 * n * ho * ho * cout * k * k * cin
+        eb = 2 if dtype == torch.bfloat16 else 4
+        byts = (x.numel() + y.numel()) * eb
         t = bench(lambda: lib.conv2d(x, w, y, k, k, stride, pad, 0, stat_partial=stat))
-        print(f"{name:5s} fwd   {t:8.1f} us  {flops / t / 1e6:7.1f} TF/s")
+        print(f"{name:5s} fwd   {t:8.1f} us  {flops / t / 1e6:7.1f} TF/s  {byts / t / 1e3:7.1f} GB/s", flush=True)
         t = bench(lambda: lib.conv2d(dy, wt, dx, k, k, stride, pad, 1))
-        print(f"{name:5s} dgrad {t:8.1f} us  {flops / t / 1e6:7.1f} TF/s")
+        print(f"{name:5s} dgrad {t:8.1f} us  {flops / t / 1e6:7.1f} TF/s  {byts / t / 1e3:7.1f} GB/s", flush=True)
         ipg = 128
         if os.environ.get("NO_WGRAD"):
             continue
