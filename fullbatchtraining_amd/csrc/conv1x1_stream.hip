@@ -237,7 +237,10 @@ int fb_try_conv1x1_stream(const fb_conv_args* a, hipStream_t st) {
     if (M * a->Cs * 2 >= (1LL << 31) || M * a->Cd * 2 >= (1LL << 40)) return 0;
     // 4-wave workgroups, two per CU (64 KiB of LDS each): a wave owns 32 channels; K >= 128: 4 channel waves = 128 channels per workgroup, every
     // wave reads the whole sub-tile; K = 64 (sub-tiles of 256 pixels, output-dominated traffic): 2 channel waves x 2 pixel halves
-    static const int nw = getenv("FB_C1S_NW") ? atoi(getenv("FB_C1S_NW")) : 4;
+    // measured (tools/conv_microbench.py, profiles/r3_notes.md): 8-wave workgroups (one per CU) are 5-10 % faster for the forward shapes, 4-wave
+    // ones (two per CU: one computes while the other waits for its loads and store acknowledgements) for most input gradients
+    static const int nw_env = getenv("FB_C1S_NW") ? atoi(getenv("FB_C1S_NW")) : 0;
+    const int nw = nw_env ? nw_env : (a->mode == 0 ? 8 : 4);
     const int CW = (nw == 8 && a->Cs != 64 && a->Cd % 256 != 0) ? 16 : 32;
     const int NWC = nw == 8 ? (a->Cs == 64 ? 4 : 8) : (a->Cs == 64 ? 2 : 4);
     const int pxt = 16384 / a->Cs, unit = pxt > 128 ? pxt : 128;
