@@ -61,8 +61,9 @@ class Block:
 def max_group(plan, chunk, dtype):
     """Largest chunk group whose biggest activation tensor (NHWC, compute dtype) stays below 2^31 bytes: the LDS-DMA kernels address
     their operands with 32-bit buffer offsets and hand larger tensors to the slower pointer-based kernels."""
-    per_image = max(max(L.hout * L.wout * L.cout, L.hin * L.win * L.cin_pad) for L in plan.layers)
-    per_image = max(per_image, plan.stem.hout * plan.stem.wout * plan.stem.cin_pad)
+    # (the stem's pre-gathered patches -- 7x7x3 -> 160 values per pixel for the ImageNet stem, the largest tensor by far -- do not count: the two
+    # launches that read them are cut into chunk ranges below 2^31 bytes, Engine._stem_ranges; ResNet-152 @224: groups of 10 chunks instead of 4)
+    per_image = max(max(L.hout * L.wout * L.cout, L.hin * L.win * (L.cin_pad if L is not plan.stem else 0)) for L in plan.layers)
     return max(1, ((1 << 31) - 1) // (chunk * per_image * torch.empty((), dtype=dtype).element_size()))
 
 
@@ -525,13 +526,45 @@ class Engine:
             return None, None
         return self._amax(src, numel, G), self.w_amax[1 if wsets > 1 else 0][L.li].data_ptr()
 
+    def _stem_ranges(self, G):
+        """Chunk ranges [(g0, g_n)] of a group whose stem patches stay below 2^31 bytes each (32-bit buffer offsets of the LDS-DMA kernels)."""
+        S = self.plan.stem
+        per_chunk = self.chunk * S.hin * S.win * S.cin_pad * torch.empty((), dtype=self.dt).element_size()
+        step = max(1, int(os.environ.get("FB_STEM_RANGE_BYTES", (1 << 31) - 1)) // per_chunk)       # (the variable: tests force several ranges)
+        return [(g0, min(step, G - g0)) for g0 in range(0, G, step)]
+
     def _conv_bn_fwd(self, L, src, G, wsets, theta, pidx):
+        if L is self.plan.stem and len(self._stem_ranges(G)) > 1 and not getattr(self, "_in_stem_range", False):
+            # the stem of a large group, range by range: every per-chunk quantity (statistics tables, scale / shift, outputs) is indexed by
+            # chunk, so a range is the same call on offset views
+            self._in_stem_range = True
+            try:
+                amax = self._amax_pair(L, src, G * self.chunk * L.hin * L.win * L.cin_pad, wsets, G)      # per-chunk scales of the WHOLE group, once
+                for g0, g_n in self._stem_ranges(G):
+                    self._conv_bn_fwd_range(L, src, g0, g_n, wsets, theta, pidx, amax)
+            finally:
+                self._in_stem_range = False
+            return
+        self._conv_bn_fwd_range(L, src, 0, G, wsets, theta, pidx)
+
+    def _conv_bn_fwd_range(self, L, src, g0, G, wsets, theta, pidx, amax=None):
+        """conv + batch statistics of chunks [g0, g0 + G) of the launch group (g0 > 0 only for the stem of a large group)."""
+        es = src.element_size()
+        i0 = g0 * self.chunk                              # first image
+        src_ptr = src.data_ptr() + i0 * L.hin * L.win * L.cin_pad * es
+        x_ptr = L.x.data_ptr() + i0 * L.hout * L.wout * L.cout * es
         n = G * self.chunk
         wf = self.w_fwd[1 if wsets > 1 else 0]
         wptr = wf.data_ptr() + wf.element_size() * L.wc_off
         evalm = getattr(self, "_eval", False)
-        am_s, am_w = self._amax_pair(L, src, n * L.hin * L.win * L.cin_pad, wsets, G)
-        a = lib.ConvArgs(src.data_ptr(), wptr, L.x.data_ptr(), None, None if evalm else self.stat_ws.data_ptr(), n, L.hin, L.win, L.cin_pad, L.hout, L.wout,
+        if amax is None:
+            am_s, am_w = self._amax_pair(L, src, n * L.hin * L.win * L.cin_pad, wsets, G)
+        else:                                             # a range of a larger group: per-chunk entries (and per-chunk weight sets) start at chunk g0
+            am_s = amax[0] + 4 * g0 if amax[0] is not None else None
+            am_w = (amax[1] + (4 * g0 if wsets > 1 else 0)) if amax[1] is not None else None
+        if wsets > 1:
+            wptr += g0 * self.plan.wc_total * wf.element_size()
+        a = lib.ConvArgs(src_ptr, wptr, x_ptr, None, None if evalm else self.stat_ws.data_ptr(), n, L.hin, L.win, L.cin_pad, L.hout, L.wout,
                          L.cout, L.R, L.S, L.stride, L.pad, 0, self.chunk if wsets > 1 else n, self.plan.wc_total if wsets > 1 else 0,
                          0, self.dtc, None, None, None, am_s, am_w, self.chunk)
         call("fb_conv2d", lib.C.byref(a))
@@ -540,10 +573,12 @@ class Engine:
         px = n * L.hout * L.wout
         n_mblocks = (px + 127) // 128
         pstride = self.plan.P if wsets > 1 else 0
+        tab_off = 4 * g0 * self.plan.ch_total            # per-chunk rows of the statistics tables / coefficient arrays
+        th_off = 4 * g0 * pstride                         # per-chunk parameter sets
         call("fb_bn_fwd_finalize", self.stat_ws.data_ptr(), n_mblocks, G, L.cout, float(self.valid * L.hout * L.wout),
-             theta.data_ptr() + 4 * L.g_off, theta.data_ptr() + 4 * L.b_off, pstride, BN_EPS,
-             self.mean_tab[pidx].data_ptr(), self.var_tab[pidx].data_ptr(), self.plan.ch_total, L.ch_off,
-             L.scale.data_ptr(), L.shift.data_ptr(), L.invstd.data_ptr())
+             theta.data_ptr() + 4 * L.g_off + th_off, theta.data_ptr() + 4 * L.b_off + th_off, pstride, BN_EPS,
+             self.mean_tab[pidx].data_ptr() + tab_off, self.var_tab[pidx].data_ptr() + tab_off, self.plan.ch_total, L.ch_off,
+             L.scale.data_ptr() + 4 * g0 * L.cout, L.shift.data_ptr() + 4 * g0 * L.cout, L.invstd.data_ptr() + 4 * g0 * L.cout)
 
     def _bn_apply(self, L, out, G, relu=True, res=None, resL=None, pool=None):
         """``pool``: the 2x2-average-pooled copy of ``out`` the NEXT block's shortcut reads, written by the same pass where the library can
@@ -650,15 +685,23 @@ class Engine:
         am_x = am_dy = None
         if self.f32_split == "f16x2":                # (computed on the main stream, before the event the weight-gradient stream waits for)
             am_x, am_dy = self._amax(src, n * L.hin * L.win * L.cin_pad, G), self._amax(dx, n * L.hout * L.wout * L.cout, G)
-        a = lib.WgradArgs(src.data_ptr(), dx.data_ptr(), gout.data_ptr() + 4 * L.w_off if direct else self.slab_ws.data_ptr(), n, L.hin, L.win,
-                          L.cin_pad, L.hout, L.wout, L.cout, L.R, L.S, L.stride, L.pad, self.chunk, L.split_k, self.dtc,
-                          self.plan.P if direct else 0, am_x, am_dy)
+        ranges = self._stem_ranges(G) if L is self.plan.stem else [(0, G)]
+        es = src.element_size()
+        args = []
+        for g0, g_n in ranges:                       # (more than one range: only the stem of a group whose patches exceed 2^31 bytes)
+            i0 = g0 * self.chunk
+            args.append((g0, g_n, lib.WgradArgs(src.data_ptr() + i0 * L.hin * L.win * L.cin_pad * es, dx.data_ptr() + i0 * L.hout * L.wout * L.cout * es,
+                                                gout.data_ptr() + 4 * (L.w_off + g0 * self.plan.P) if direct else self.slab_ws.data_ptr(), g_n * self.chunk,
+                                                L.hin, L.win, L.cin_pad, L.hout, L.wout, L.cout, L.R, L.S, L.stride, L.pad, self.chunk, L.split_k, self.dtc,
+                                                self.plan.P if direct else 0, am_x + 4 * g0 if am_x is not None else None,
+                                                am_dy + 4 * g0 if am_dy is not None else None)))
 
         def launch():
-            call("fb_conv2d_wgrad", lib.C.byref(a))
-            if not direct:
-                call("fb_wgrad_reduce", self.slab_ws.data_ptr(), gout.data_ptr() + 4 * L.w_off, self.plan.P, G, L.split_k, L.cout, L.taps,
-                     L.cin_pad, L.cin_real)
+            for g0, g_n, a in args:
+                call("fb_conv2d_wgrad", lib.C.byref(a))
+                if not direct:
+                    call("fb_wgrad_reduce", self.slab_ws.data_ptr(), gout.data_ptr() + 4 * (L.w_off + g0 * self.plan.P), self.plan.P, g_n, L.split_k, L.cout,
+                         L.taps, L.cin_pad, L.cin_real)
 
         if self.wstream is None:
             launch()

@@ -341,6 +341,39 @@ def test_replayed_command_lists_equal_interpreted_launches(dtype, fd, monkeypatc
     assert a[5] == b[5]
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, "f16x2+fd"])
+def test_stem_launch_ranges_equal_one_launch(dtype, monkeypatch):
+    """The pre-gathered patches of the ImageNet stem (7x7x3 -> 160 values per pixel) are the largest tensor of ResNet-152 @224 and used to cap
+    the chunk group at 4; the two launches that read them are now cut into chunk ranges below 2^31 bytes (Engine._stem_ranges) and the
+    group is sized by the other tensors (10 chunks).  A forced split (one chunk per range) must reproduce the single launch bit for bit:
+    statistics tables, coefficients, outputs and per-chunk gradient rows are all indexed by chunk."""
+    pixels, chunk, G = 64, 32, 3
+    x, y = make_data(chunk * G, pixels)
+    fd = dtype == "f16x2+fd"                  # the regulariser's passes: per-chunk fp16x2 scales and per-chunk weight sets in the second pass
+    dtype = torch.float32 if fd else dtype
+    out = {}
+    for limit in (None, 1):
+        if limit is None:
+            monkeypatch.delenv("FB_STEM_RANGE_BYTES", raising=False)
+        else:
+            monkeypatch.setenv("FB_STEM_RANGE_BYTES", str(limit))
+        cfg, model, eng, stem_patches = _build(18, pixels, chunk, G, dtype, stem="standard", fd_sets=1 if fd else 0)
+        assert len(eng._stem_ranges(G)) == (1 if limit is None else G)
+        patches = stem_patches(x.cuda(), eng.plan.stem, dtype)
+        if fd:
+            assert eng.f32_split == "f16x2"
+            eng.full_gradient(patches, y.cuda(), 0.1, block_strength=0.5)
+            torch.cuda.synchronize()
+            out[limit] = (eng.g[:G].clone(), eng.g_fd[0][:G].clone(), eng.avg.clone(), eng.mean_tab[:, :G].clone(), eng.var_tab[:, :G].clone())
+            continue
+        eng.prep_weights(eng.theta, 1)
+        eng.group_gradient(patches, y.cuda(), G, eng.g)
+        torch.cuda.synchronize()
+        out[limit] = (eng.g[:G].clone(), eng.loss[:G].clone(), eng.mean_tab[0, :G].clone(), eng.var_tab[0, :G].clone())
+    for a, b in zip(out[None], out[1]):
+        assert torch.equal(a, b)
+
+
 def test_imagenet_shaped_maps_chunk_gradient_vs_oracle():
     """ResNet-18 with the 'standard' (ImageNet) stem on 96x96 inputs: feature maps 48 -> (MaxPool) 24, 12, 6, 3 -- non-power-of-two
     sizes like the 56/28/14/7 of the 224x224 configurations (every stride-2 transition halves an even size, as there; the
