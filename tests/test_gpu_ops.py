@@ -354,6 +354,27 @@ def test_bn_running_update():
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hw,n,C", [(8, 3, 64), (7, 2, 64), (14, 5, 128), (112, 2, 64)])
+def test_maxpool_backward_with_ties(dtype, hw, n, C):
+    """MaxPool2d(3, 2, 1) backward on POST-ReLU input (exact zeros: whole windows tie, the first maximum in row-major window order takes the
+    gradient, torch's CPU semantics), even and odd map sizes, the ImageNet stem's 112x112."""
+    lib = _lib()
+    torch.manual_seed(7)
+    x = q(torch.relu(torch.randn(n, C, hw, hw) - 0.3), dtype)
+    xr = x.clone().requires_grad_(True)
+    mp = F.max_pool2d(xr, 3, 2, 1)
+    dmp = q(torch.randn_like(mp), dtype)
+    mp.backward(dmp)
+    xd = nhwc(x).to(dtype).cuda()
+    dxm = torch.full_like(xd, float("nan"))
+    lib.call("fb_maxpool3s2_bwd", xd.data_ptr(), nhwc(dmp).to(dtype).cuda().data_ptr(), dxm.data_ptr(), n, hw, hw, C, lib.dtype_code(dtype))
+    got = nchw(dxm.float().cpu())
+    assert bool(torch.isfinite(got).all())
+    assert rel(got, xr.grad) < tol(dtype, 0.5)
+    assert float((got - q(xr.grad, dtype)).abs().max()) <= (0 if dtype == torch.float32 else 2 ** -7 * float(xr.grad.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_pools_and_head(dtype):
     lib = _lib()
     torch.manual_seed(6)
