@@ -1,6 +1,6 @@
 // Weight gradient of 3x3 / pad 1 convolutions of stride 1 and 2, bf16, all nine taps from one LDS-resident input halo.
 //
-//   dW[co][tap][ci] = sum_p dY[p][co] * X[stride*p + tap - 1][ci]     (output maps 32x32 .. 4x4; stride 2: 16x16 .. 4x4)
+//   dW[co][tap][ci] = sum_p dY[p][co] * X[stride*p + tap - 1][ci]     (output maps 32x32 .. 4x4 and 56 / 28 / 14; stride 2: 16x16 .. 4x4)
 //
 // One workgroup owns a 64(co) x 64(ci) x 9(tap) output block and a slice of whole images of one chunk (split-K over images).
 // Wave w accumulates ci block [16w,16w+16) x 9 taps x 64 co (36 fragments = 144 accumulator registers).  Per K-step
@@ -51,8 +51,32 @@ constexpr unsigned W3_OOB = 0x80000000u;
 //   stride 1: W = 32: 2 image rows per step, W = 16: 4 image rows, W = 8: one whole image, W = 4: two whole images (32 pixels)
 //   stride 2: 32 output pixels per step -- W = 16: 2 output rows (5 input rows), W = 8: 4 output rows (9 input rows, half an
 //             image), W = 4: two whole images (9 input rows each)
+// Feature maps whose width is not a power of two (ImageNet-shaped models: 56 / 28 / 14): a 32-pixel block no longer covers whole image
+// rows, so a lane's halo row depends on the block (PER_BLOCK: one address register per block, tap column and 4-pixel half instead of an
+// immediate) and a step covers RS whole rows padded to a multiple of 32 pixels (the padding pixels carry dY = 0 through out-of-range DMA
+// offsets): W = 56: 1 row (56 of 64 pixels), W = 28: 4 rows (112 of 128), W = 14: 7 rows (98 of 128).  Stages of 32-40 KiB: two workgroups per CU.
+template <int W> struct W3GeoGen {
+    static constexpr bool PER_BLOCK = true;
+    static constexpr int RS = W == 56 ? 1 : (W == 28 ? 4 : 7);
+    static constexpr int VALID = RS * W;                                       // real output pixels of a step
+    static constexpr int KPX = (VALID + 31) / 32 * 32;
+    static constexpr int PITCH = W == 56 ? 64 : (W == 28 ? 32 : 16);
+    static constexpr int IMGS = 1;
+    static constexpr int IMG_ROWS = (RS + 2) * PITCH;
+    static constexpr int HROWS = IMG_ROWS;                                     // 192, 192, 144
+    static constexpr bool WHOLE = false;
+    // halo row (vertical tap index 0) of pixel p of the step for tap column s; padding pixels read row 0 (their dY is zero)
+    __device__ static __forceinline__ int pix_row(int p, int s) { return p < VALID ? (p / W) * PITCH + (p % W) + s : 0; }
+    static constexpr int blk_rows(int, int R) { return R * PITCH; }           // (the block is in the lane registers)
+    __device__ static __forceinline__ int fB(int row) { return w3_f(row); }
+};
 template <int W, int SD> struct W3Geo;
+template <> struct W3Geo<56, 1> : W3GeoGen<56> {};
+template <> struct W3Geo<28, 1> : W3GeoGen<28> {};
+template <> struct W3Geo<14, 1> : W3GeoGen<14> {};
 template <int W> struct W3Geo<W, 1> {
+    static constexpr bool PER_BLOCK = false;
+    static constexpr int VALID = W == 4 ? 32 : 64;
     static constexpr int KPX = W == 4 ? 32 : 64;                               // output pixels per step
     static constexpr int PITCH = W == 32 ? 48 : (W == 16 ? 32 : 16);           // halo row pitch (multiple of 16)
     static constexpr int RS = W >= 16 ? 64 / W : W;                            // output rows covered by a step (per image)
@@ -71,6 +95,8 @@ template <int W> struct W3Geo<W, 1> {
     __device__ static __forceinline__ int fB(int row) { return w3_f(row); }
 };
 template <int W> struct W3Geo<W, 2> {
+    static constexpr bool PER_BLOCK = false;
+    static constexpr int VALID = 32;
     static constexpr int KPX = 32;
     static constexpr int PITCH = W == 16 ? 40 : (W == 8 ? 24 : 16);            // >= 2W + 1 columns, multiple of 8
     static constexpr int RS = W == 16 ? 2 : 4;
@@ -130,7 +156,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Par
     for (int k = 0; k < KA; ++k) {
         const int row = (wave + 4 * k) * 8 + lrow8;                          // pixel of the step
         const int lslot = ((lane & 7) >> 1) ^ w3_f(row);
-        voffA[k] = (unsigned)(row * rowA_b + tile_m * 128 + lslot * 32 + (lane & 1) * 16);
+        voffA[k] = row < G::VALID ? (unsigned)(row * rowA_b + tile_m * 128 + lslot * 32 + (lane & 1) * 16) : W3_OOB;
     }
     int hyB[KB]; unsigned voffB[KB];
 #pragma unroll
@@ -185,13 +211,18 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Par
 #pragma unroll
     for (int i = 0; i < 4; ++i) la[i] = lds0 + pl * 128 + ((i ^ w3_f(pl)) * 32) + (t & 3) * 8;
     // B: halo row = lane_row(pl, s) + immediate; slot = wave ^ f(row); the read of pixels +4 has its own registers
-    unsigned lb[3], lbh[3];
+    constexpr int NBLK = G::PER_BLOCK ? KPX / 32 : 1;
+    unsigned lb[NBLK][3], lbh[NBLK][3];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const int row = G::lane_row(pl, s), rowh = row + G::HI_DELTA;
-        lb[s] = lds0 + A_BYTES + row * 128 + ((wave ^ G::fB(row)) * 32) + (t & 3) * 8;
-        lbh[s] = lds0 + A_BYTES + rowh * 128 + ((wave ^ G::fB(rowh)) * 32) + (t & 3) * 8;
-    }
+    for (int blk = 0; blk < NBLK; ++blk)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            int row, rowh;
+            if constexpr (G::PER_BLOCK) { row = G::pix_row(blk * 32 + pl, s); rowh = G::pix_row(blk * 32 + pl + 4, s); }
+            else { row = G::lane_row(pl, s); rowh = row + G::HI_DELTA; }
+            lb[blk][s] = lds0 + A_BYTES + row * 128 + ((wave ^ G::fB(row)) * 32) + (t & 3) * 8;
+            lbh[blk][s] = lds0 + A_BYTES + rowh * 128 + ((wave ^ G::fB(rowh)) * 32) + (t & 3) * 8;
+        }
 
     f32x4_t acc[9][4];
 #pragma unroll
@@ -208,14 +239,16 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Par
         const int cur = step & 1;
         if (step + 1 < n_steps) issue(cur ^ 1, step + 1);
         const unsigned so = cur * STAGE;
-        unsigned a0[4], b0[3], b1[3];
+        unsigned a0[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) a0[i] = la[i] + so;
-#pragma unroll
-        for (int s = 0; s < 3; ++s) { b0[s] = lb[s] + so; b1[s] = lbh[s] + so; }
         w3_static_for<0, KPX / 32>([&](auto blkc) {
             constexpr int BLK = decltype(blkc)::value;
             constexpr int PB = BLK * 32;                                  // first pixel of the 32-pixel block
+            constexpr int BI = G::PER_BLOCK ? BLK : 0;
+            unsigned b0[3], b1[3];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) { b0[s] = lb[BI][s] + so; b1[s] = lbh[BI][s] + so; }
             uint4 af[4];
             w3_static_for<0, 4>([&](auto ic) {
                 constexpr int I = decltype(ic)::value;
@@ -265,7 +298,8 @@ int fb_try_wgrad3x3_v2(const fb_wgrad_args* a, hipStream_t st) {
     const int SD = a->stride;
     if (a->Hs != SD * a->Hd || a->Ws != SD * a->Wd || a->Hd != a->Wd) return 0;
     const int W = a->Wd;
-    if (W != 32 && W != 16 && W != 8 && W != 4) return 0;
+    const bool general = SD == 1 && (W == 56 || W == 28 || W == 14);     // ImageNet-shaped maps: rows padded to 32-pixel blocks
+    if (W != 32 && W != 16 && W != 8 && W != 4 && !general) return 0;
     if (SD == 2 && W == 32) return 0;
     if (a->Cs % 64 != 0 || a->Cd % 64 != 0) return 0;
     // K slices are whole images; the last slice of a chunk may be shorter (or empty: it then contributes zeros)
@@ -281,7 +315,10 @@ int fb_try_wgrad3x3_v2(const fb_wgrad_args* a, hipStream_t st) {
     const int n_groups = a->n_img / a->imgs_per_group;
     dim3 grid((a->Cd / 64) * (a->Cs / 64) * n_groups * a->split_k);
     if (SD == 1) {
-        if (W == 32) hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<32, 1>), grid, dim3(256), 0, st, p);
+        if (W == 56) hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<56, 1>), grid, dim3(256), 0, st, p);
+        else if (W == 28) hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<28, 1>), grid, dim3(256), 0, st, p);
+        else if (W == 14) hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<14, 1>), grid, dim3(256), 0, st, p);
+        else if (W == 32) hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<32, 1>), grid, dim3(256), 0, st, p);
         else if (W == 16) hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<16, 1>), grid, dim3(256), 0, st, p);
         else if (W == 8) hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<8, 1>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<4, 1>), grid, dim3(256), 0, st, p);

@@ -369,7 +369,7 @@ class Engine:
         """Split the pixel reduction of wgrad so that >= ~1000 workgroups exist; slices are multiples of the K-step."""
         bf16 = self.dt == torch.bfloat16
         G = self.nominal_group
-        widths = (4, 8, 16, 32) if L.stride == 1 else ((4, 8, 16) if (bf16 or self.f32_split == "f16x2") else ())
+        widths = ((4, 8, 16, 32) + ((14, 28, 56) if bf16 else ())) if L.stride == 1 else ((4, 8, 16) if (bf16 or self.f32_split == "f16x2") else ())
         if (L.R == 3 and L.stride in (1, 2) and L.pad == 1 and L.hout == L.wout and L.hin == L.stride * L.hout and L.wout in widths
                 and L.cin_pad % 64 == 0 and L.cout % 64 == 0 and not (L.wout == 4 and self.chunk % 2)):
             # all-taps halo wgrad kernel: split-K over whole images (pairs for 4x4 maps); any split works (ragged last slice).

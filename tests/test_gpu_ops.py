@@ -180,7 +180,10 @@ def test_conv_f32_fp16x2_split(cin, cout, k, stride, hw, n, magnitude):
                                                                   (64, 64, 3, 1, 4, 6, 1, 3), (64, 64, 3, 1, 4, 6, 1, 2),
                                                                   (64, 128, 3, 2, 32, 4, 2, 2), (128, 64, 3, 2, 16, 6, 1, 3), (64, 64, 3, 2, 8, 8, 2, 2),   # stride 2, all taps
                                                                   (128, 128, 3, 2, 16, 5, 1, 1),
-                                                                  (64, 64, 3, 1, 16, 10, 2, 3), (64, 64, 3, 1, 32, 7, 1, 4), (64, 64, 3, 1, 4, 10, 2, 3), (64, 128, 3, 2, 16, 7, 2, 5)])   # ragged K slices
+                                                                  (64, 64, 3, 1, 16, 10, 2, 3), (64, 64, 3, 1, 32, 7, 1, 4), (64, 64, 3, 1, 4, 10, 2, 3), (64, 128, 3, 2, 16, 7, 2, 5),   # ragged K slices
+                                                                  # ImageNet-shaped maps (56 / 28 / 14): all-taps kernel with image rows padded to 32-pixel blocks
+                                                                  (64, 64, 3, 1, 56, 2, 2, 1), (128, 128, 3, 1, 28, 4, 2, 3), (256, 256, 3, 1, 14, 8, 2, 3), (64, 128, 3, 1, 14, 7, 1, 2),
+                                                                  (128, 64, 3, 1, 28, 3, 2, 1)])
 def test_conv_wgrad(dtype, cin, cout, k, stride, hw, ipg, groups, split):
     lib = _lib()
     torch.manual_seed(2)

@@ -56,7 +56,7 @@ def main():
         ipg = 128
         if os.environ.get("NO_WGRAD"):
             continue
-        for split in ((32, 8, 1) if k == 3 and stride == 1 else (8, 1)):
+        for split in ((int(os.environ["SPLITS"]),) if os.environ.get("SPLITS") else ((32, 8, 1) if k == 3 and stride == 1 else (8, 1))):
             slab = torch.empty(n // ipg * split * cout * k * k * cin, device="cuda")
             try:
                 t = bench(lambda: lib.conv2d_wgrad(x, dy, slab, k, k, stride, pad, ipg, split))
