@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 
 int fb_try_wgrad3x3(const fb_wgrad_args* a, hipStream_t st);      // conv_wgrad3x3.hip
 int fb_try_wgrad3x3_v2(const fb_wgrad_args* a, hipStream_t st);   // conv_wgrad3x3_v2.hip
+int fb_try_wgrad1x1(const fb_wgrad_args* a, hipStream_t st);      // conv_wgrad1x1.hip
 
 extern "C" int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream) {
     if (!a || !a->x || !a->dy || !a->dw_partial) FB_FAIL(FB_ERR_ARG, "fb_conv2d_wgrad: null pointer");
@@ -261,6 +262,7 @@ extern "C" int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream) {
     const int prof = fb_prof_begin(FB_PROF_WGRAD, st, info);
     if (fb_try_wgrad3x3_v2(a, st)) { fb_prof_kernel(prof, FB_K_WGRAD3X3_V2);
     } else if (fb_try_wgrad3x3(a, st)) { fb_prof_kernel(prof, FB_K_WGRAD3X3_V1);
+    } else if (fb_try_wgrad1x1(a, st)) { fb_prof_kernel(prof, FB_K_WGRAD1X1);
     } else if (big) {
         dim3 grid((a->Cd / 128) * (a->Cs / 128), taps, n_groups * a->split_k);
         if (hsplit) hipLaunchKernelGGL((conv_wgrad_kernel<f32h_tag, 2, 2, 1, 1, 4>), grid, dim3(256), 0, st, p);

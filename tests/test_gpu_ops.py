@@ -183,7 +183,11 @@ def test_conv_f32_fp16x2_split(cin, cout, k, stride, hw, n, magnitude):
                                                                   (64, 64, 3, 1, 16, 10, 2, 3), (64, 64, 3, 1, 32, 7, 1, 4), (64, 64, 3, 1, 4, 10, 2, 3), (64, 128, 3, 2, 16, 7, 2, 5),   # ragged K slices
                                                                   # ImageNet-shaped maps (56 / 28 / 14): all-taps kernel with image rows padded to 32-pixel blocks
                                                                   (64, 64, 3, 1, 56, 2, 2, 1), (128, 128, 3, 1, 28, 4, 2, 3), (256, 256, 3, 1, 14, 8, 2, 3), (64, 128, 3, 1, 14, 7, 1, 2),
-                                                                  (128, 64, 3, 1, 28, 3, 2, 1)])
+                                                                  (128, 64, 3, 1, 28, 3, 2, 1),
+                                                                  # 1x1 weight gradients: large-tile LDS-DMA kernel (bf16), every wave-tile variant, ragged pixel ranges, empty last slice
+                                                                  (256, 1024, 1, 1, 7, 4, 2, 3), (1024, 256, 1, 1, 7, 4, 1, 2), (64, 256, 1, 1, 8, 3, 2, 2), (256, 64, 1, 1, 8, 3, 1, 1),
+                                                                  (128, 128, 1, 1, 8, 5, 2, 3), (64, 128, 1, 1, 8, 4, 1, 2), (128, 64, 1, 1, 6, 3, 2, 2), (512, 128, 1, 1, 14, 2, 2, 5),
+                                                                  (256, 512, 1, 1, 4, 4, 1, 8)])
 def test_conv_wgrad(dtype, cin, cout, k, stride, hw, ipg, groups, split):
     lib = _lib()
     torch.manual_seed(2)
