@@ -7,7 +7,7 @@ removes the chaos instead of averaging over it: it walks the network layer by la
 (fullbatch/models/resnets.py:179-230 forward, autograd's backward of it) and feeds EVERY library launch the float64 oracle's own tensors of
 that point -- bf16-rounded at the engine's storage points (oracle ``q = bf16_round``), ReLU masks included -- so that each kernel is compared
 with exact arithmetic on identical inputs.  What remains is one bf16 rounding of the output (2^-9 relative) plus fp32 accumulation: every
-tensor must agree to 2^-8 relative L2 and element-wise to 2 ulp (plus a floor for cancelling sums).  A wrong tap, parity class, mask bit,
+tensor must agree to 1e-3 relative L2 (measured 4e-5) and element-wise to 2 ulp (plus a floor for cancelling sums).  A wrong tap, parity class, mask bit,
 channel slice or coefficient in any of the production bf16 kernels (resident-filter 64-channel, persistent halo, implicit GEMM, stride-2 quad
 input gradient, streaming stem, all-taps / per-tap weight gradients, BN apply with residual / pooled output, BN backward with bitmask) moves a
 tensor by >= 1/9 and fails here; the suite's statistical bf16 assertions would not see it.
@@ -20,7 +20,7 @@ from tests.helpers import make_data
 
 pytestmark = pytest.mark.gpu
 
-REL_L2 = 2.0 ** -8          # per tensor
+REL_L2 = 1e-3               # per tensor (measured: <= 4.1e-5 on all 209 tensors; a wrong tap moves a tensor by >= 0.1)
 ULP2 = 2.0 ** -7            # element-wise: 2 bf16 ulp of the reference value ...
 FLOOR = 2.0 ** -9           # ... plus this fraction of the tensor's rms (outputs that are small differences of large terms)
 BAD_FRACTION = 1e-3         # elements allowed outside the element-wise bound (1-ulp accumulator differences next to a rounding boundary)

@@ -204,3 +204,22 @@ def test_sharded_checkpoint_holds_whole_momentum(tmp_path):
             # steps 4-5 of the run: the ranks sum the full-batch gradient in another order than one process, and fp32 chunk-gradient noise
             # has grown to ~2e-3 by step 5 (a resumed shard without its momentum would be off by tens of per cent)
             assert np.allclose(got["stats"][key], ref["stats"][key], rtol=1e-2), (key, got["stats"][key], ref["stats"][key])
+
+
+def test_bench_two_ranks_spawn_and_tear_down_on_one_gpu(tmp_path):
+    """`python bench.py --gpus 2` as the driver calls it: the parent (which has not touched the GPU) starts two ranks through
+    torch.distributed.run, every rank takes its chunk range, runs warm-up + timed + event-instrumented steps, rank 0 prints ONE JSON line, the
+    process group is destroyed and the launcher exits 0.  On a 1-GPU box the two ranks share cuda:0 over gloo (FB_BENCH_SHARE_DEVICE=1: RCCL
+    refuses two ranks on one device), so the number is not a scaling result -- the orchestration is what runs."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, FB_BENCH_SHARE_DEVICE="1")
+    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--images", "2048", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and np.isfinite(out["train_loss_last"])
+    assert out["config"]["parallelism"].startswith("dp2") and "roofline" in out
