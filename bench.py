@@ -118,7 +118,7 @@ def _side_trainer(args, device, X, Y, overrides, name, env=None):
     saved = {k: os.environ.get(k) for k in (env or {})}
     os.environ.update(env or {})
     try:
-        cfg = compose(overrides + [f"impl.engine.chunk_group={args.chunk_group}", "data.augmentations_train="],
+        cfg = compose(overrides + [f"impl.engine.chunk_group={args.chunk_group}"] + ([] if any("device_augment=True" in o for o in overrides) else ["data.augmentations_train="]),
                       original_cwd=os.path.join(ROOT, "gpurun_out"), name=name)
         torch.manual_seed(1)
         model = construct_model(cfg.model, 3, 10)
@@ -167,6 +167,15 @@ def side_configs(args, device, X, Y, main_trainer):
                                           f"{tr.chunk_pad} images per chunk), bf16, grad_reg off", "ms_per_step": round(1000 * dt, 2), "value": round(tr.datapoints / dt, 1),
                               "unit": "images/s", "steps": 3, "warmup": 1, "dtype": "bf16", "step_mfma_frac": round(flop_img * tr.datapoints / dt / (PEAK_BF16_TFLOPS * 1e12), 4),
                               "train_loss_last": tr.stats["train_loss"][-1]}
+    del tr
+    gc.collect(), torch.cuda.empty_cache()
+    # ---- the headline workload with the stem's patch gather INSIDE the step: on-device RandomCrop(32, 4) + RandomHorizontalFlip of the resident
+    # un-augmented images every step (config/data/CIFAR10.yaml:11-13; the static headline gathers the patches once, outside the timed region) ----
+    tr = _side_trainer(args, device, X, Y, ["hyp=fb1", "hyp.warmup=0", "hyp.steps=8", "impl.mixed_precision=True", "impl.engine.device_augment=True"], "bench_augmented")
+    dt = _timed_steps(tr, 3, 1)
+    out["configs"]["augmented"] = {"workload": f"the headline step with the dataset augmented on the device every step (RandomCrop + flip inside fb_stem_patches: the "
+                                               f"3.3 GB patch gather is part of the step), {tr.n_chunks} chunks x {tr.chunk}, bf16", "ms_per_step": round(1000 * dt, 2),
+                                   "value": round(tr.datapoints / dt, 1), "unit": "images/s", "steps": 3, "warmup": 1, "dtype": "bf16", "train_loss_last": tr.stats["train_loss"][-1]}
     del tr
     gc.collect(), torch.cuda.empty_cache()
     # ---- config 3 in both arithmetic modes ----
