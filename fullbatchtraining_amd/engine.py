@@ -222,7 +222,7 @@ class Engine:
     AMAX_BLOCK, AMAX_SLOT_LIMIT = 256, 16384         # fp16x2 scale slots: rows per allocation, sanity limit on distinct operand buffers
 
     def __init__(self, model, pixels, chunk, max_groups, compute_dtype=torch.bfloat16, device="cuda", fd_sets=0, arena_align=64,
-                 chunk_valid=None, nominal_group=None):
+                 chunk_valid=None, nominal_group=None, f32_split=None):
         """``fd_sets``: extra per-chunk gradient/parameter sets for finite differences (0 none, 1 forward, 2 central).
         ``chunk``: images per statistics group AS STORED; ``chunk_valid`` (default ``chunk``): the real images of a chunk.  A chunk size
         whose pixels do not fill whole 128-pixel statistics blocks on every feature map (e.g. data.batch_size=125) is stored padded
@@ -275,7 +275,8 @@ class Engine:
         # operand tensor: fb_absmax, cached per tensor below), "bf16x6" (three bf16 pieces, six MFMAs); FB_F32_EXACT=1 in the library: exact f32
         # Default: f16x2 for the finite-difference regulariser (its own truncation error, 3.5e-2 in fp32, hides the 2^-22 operand rounding:
         # the float64 oracle with 22-bit operands gives 3.7e-2), bf16x6 for plain fp32 training (held to the tighter fp32-vs-float64 traces)
-        self.f32_split = os.environ.get("FB_F32_SPLIT", "f16x2" if fd_sets else "bf16x6") if compute_dtype == torch.float32 else None
+        # (``f32_split``: the caller's choice where the environment does not say otherwise -- the standalone GradRegularizer object asks for bf16x6)
+        self.f32_split = os.environ.get("FB_F32_SPLIT", f32_split or ("f16x2" if fd_sets else "bf16x6")) if compute_dtype == torch.float32 else None
         self._alloc_activations()
         self.mt_ws = torch.zeros(lib.load().fb_ws_mt_floats(self.G), **f32)
         self.sq = torch.zeros(self.G, **f32)

@@ -3,9 +3,14 @@
 Same constructor, same ``__call__(grads, inputs, labels, pre_grads) -> grads`` (in-place modification), same
 ``create_graph`` attribute and the same six ``implementation`` strings.  The finite-difference variants
 (``forward-differences``, ``forward-differences-legacy``, ``central-differences``) are implemented: the extra
-forward/backward passes at theta +/- eps_n*v run through ``libfbengine.so`` in exact-f32 MFMA (perturbations are ~1e-6 per
-weight, below bf16 resolution).  The autograd-based variants need double backward and raise ``NotImplementedError``;
-``complex-step`` is declared non-working by the reference itself.
+forward/backward passes at theta +/- eps_n*v run through ``libfbengine.so`` with fp32 storage (perturbations are ~1e-6 per
+weight, below bf16 resolution) with exact fp32 products (``bf16x6``: three bf16 pieces per operand; ``FB_F32_SPLIT=f16x2`` selects the
+training loop's faster 22-bit arithmetic).  The caller's ``grads`` come from ITS autograd (other kernels, other summation order), so the forward-difference
+quotient never subtracts them from an engine gradient -- that would divide uncorrelated rounding noise by eps_n: the base gradient at theta
+is evaluated once more by the engine, in the arithmetic and order of the perturbed pass, and vhp = (g_engine(theta + eps_n v) -
+g_engine(theta)) / eps_n is added to the caller's gradient (the training loop, where both passes are the engine's anyway, does the same).
+The autograd-based variants need double backward and raise ``NotImplementedError``; ``complex-step`` is declared non-working by the
+reference itself.
 
 The model must be a ``fullbatchtraining_amd.models.ResNet`` on a HIP device.  Like the reference, BatchNorm running
 statistics are updated again by each extra forward pass; parameters are left untouched (the reference perturbs
@@ -54,8 +59,9 @@ class GradRegularizer:
         key = (inputs.shape[0], inputs.shape[-1], inputs.device)
         if key not in self._engines:
             sets = 2 if self.implementation == "central-differences" else 1
+            # reference precision: the object is the compatibility surface, not the hot path -- exact fp32 products (bf16x6) unless FB_F32_SPLIT says otherwise
             self._engines[key] = Engine(self.model, inputs.shape[-1], inputs.shape[0], 1, compute_dtype=torch.float32,
-                                        device=inputs.device, fd_sets=sets)
+                                        device=inputs.device, fd_sets=sets, f32_split="bf16x6")
             loss_fn = self.loss_fn      # the perturbed passes use the caller's loss (reference modules.py:228-230): CE / smoothing / incorrect-xent
             if not (isinstance(loss_fn, torch.nn.CrossEntropyLoss) or hasattr(loss_fn, "smoothing")):
                 raise NotImplementedError(f"GradRegularizer: loss function {type(loss_fn).__name__} is not implemented by the head kernel")
@@ -83,13 +89,18 @@ class GradRegularizer:
             vpre, vacc = pre.data_ptr(), float(self.acc_strength)
         call("fb_mt_sqnorm", eng.g.data_ptr(), P, 1, P, s, vpre, vacc, eng.vnorm2.data_ptr(), eng.mt_ws.data_ptr())
         passes = [(0.5, 0), (-0.5, 1)] if central else [(1.0, 0)]
+        if not central:          # the base gradient at theta in the engine's own arithmetic (statistics of this pass are not an extra BN update)
+            if getattr(eng, "g_base", None) is None:
+                eng.g_base = torch.zeros_like(eng.g)
+            eng.prep_weights(eng.theta, 1)
+            eng.group_gradient(patches, labels, 1, eng.g_base, 1, eng.theta, 0)
         for sign, slot in passes:
             call("fb_mt_fd_perturb", eng.theta.data_ptr(), eng.g.data_ptr(), P, 1, P, s, float(self.eps), sign, eng.vnorm2.data_ptr(),
                  eng.eps_n.data_ptr(), vpre, vacc, eng.theta_k.data_ptr())
             eng.prep_weights(eng.theta_k, 1, per_chunk=True)
             eng.group_gradient(patches, labels, 1, eng.g_fd[slot], 2, eng.theta_k, 1 + slot)
         eng.avg.zero_()
-        gb = eng.g_fd[1] if central else eng.g
+        gb = eng.g_fd[1] if central else eng.g_base
         call("fb_mt_fd_combine_accumulate", eng.avg.data_ptr(), eng.g.data_ptr(), eng.g_fd[0].data_ptr(), gb.data_ptr(), P, 1, P,
              eng.eps_n.data_ptr(), cf, 0)
         # running statistics: one more EMA update per extra forward pass, in pass order

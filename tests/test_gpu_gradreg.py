@@ -43,8 +43,10 @@ def test_gradreg_object_matches_reference(golden, name):
         per, samp = summarise([g.cpu() for g in grads])
         err = rel_err(samp, data[f"{name}@f64/chunk{k}_reg_sample"])
         noise = rel_err(data[f"{name}/chunk{k}_reg_sample"], data[f"{name}@f64/chunk{k}_reg_sample"])
-        print(f"{name} chunk {k}: GradRegularizer-vs-ref64 {err:.2e} (reference fp32-vs-f64 {noise:.2e})")
-        assert err < max(3 * noise, 2e-2)
+        # the reference's own fp32 run against its float64 run, on either chunk of the scenario: the floor any fp32 evaluation of this quotient sits on
+        floor = max(rel_err(data[f"{name}/chunk{j}_reg_sample"], data[f"{name}@f64/chunk{j}_reg_sample"]) for j in range(2))
+        print(f"{name} chunk {k}: GradRegularizer-vs-ref64 {err:.2e} (reference fp32-vs-f64 {noise:.2e}, worst chunk {floor:.2e})")
+        assert err < max(3 * noise, floor, 2e-2)
         if k == 0:
             # load the model with the reference-equivalent state for the next chunk (BN buffers advanced by both passes)
             pass
