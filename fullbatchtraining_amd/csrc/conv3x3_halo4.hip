@@ -270,6 +270,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
         H4_STAMP(2);
 
         f32x4_t acc[FI][4];
+#ifdef FB_H4_MFMA32
+        typedef __attribute__((ext_vector_type(16))) float h4_f32x16;
+        h4_f32x16 acc32[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc32[i][e] = 0.f;
+#endif
 #pragma unroll
         for (int i = 0; i < FI; ++i)
 #pragma unroll
@@ -315,6 +323,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 } else {
+#ifdef FB_H4_MFMA32
+                // TIMING-ONLY experiment (tools/h4_trace.hip -DFB_H4_MFMA32; results are wrong): the same fragment reads and the same FLOP per
+                // tap issued as v_mfma_f32_32x32x16_bf16 (half as many instructions of twice the work) instead of 16x16x32
+                if constexpr (std::is_same<T, bf16_tag>::value && FI == 4) {
+                    h4_wait_lgkmcnt<FI + 4>();
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; j += 2)
+                            acc32[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf0[i]), __builtin_bit_cast(bf16x8_t, pf0[j] ), acc32[i], 0, 0, 0);
+                    h4_wait_lgkmcnt<0>();
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 1; j < 4; j += 2)
+                            acc32[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf1[i]), __builtin_bit_cast(bf16x8_t, pf1[j]), acc32[i], 0, 0, 0);
+                    // (the unused fragment reads stay: they are volatile asm)
+                } else
+#endif
+                {
                 h4_wait_lgkmcnt<FI + 4>();
 #pragma unroll
                 for (int i = 0; i < FI; ++i)
@@ -325,6 +353,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
                 for (int i = 0; i < FI; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = mma_chunk<T>(wf1[i], pf1[j], acc[i][j]);
+                }
                 }
                 if constexpr (U == 8) {
                     __builtin_amdgcn_s_barrier();         // every wave is done with this halo slice
@@ -396,6 +425,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
             bx_issue(std::integral_constant<int, J + 1>{});
             h4_static_for<0, FI>([&](auto ic) {
                 constexpr int I = decltype(ic)::value;
+#ifdef FB_H4_MFMA32
+                if constexpr (std::is_same<T, bf16_tag>::value && FI == 4) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[I][J][e] = acc32[I][4 * J + e];
+                }
+#endif
                 float v[4] = {acc[I][J][0], acc[I][J][1], acc[I][J][2], acc[I][J][3]};
                 if (p.addend_mode == 1) {
                     if constexpr (EB == 4) {

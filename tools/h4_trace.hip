@@ -3,6 +3,8 @@
 //   /tmp/h4_trace <W> <Cin> <Cout> <n_img> [mode]
 long long* g_h4_trace = nullptr;
 #include "../fullbatchtraining_amd/csrc/conv3x3_halo4.hip"
+thread_local char fb_err_buf[512] = "";                    // (the library's runtime.cpp is not linked into this tool)
+bool fb_f32_split_enabled() { return true; }
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
