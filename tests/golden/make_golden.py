@@ -166,7 +166,15 @@ SCENARIOS_R2 = {
     "fb_r50_gradreg": (64, 64, ["hyp=fb1", "model=resnet50", "model.stem=standard", "hyp.grad_reg.block_strength=0.5", "hyp.steps=2",
                                 "hyp.warmup=0", "hyp.optim.lr=0.02", "data.batch_size=32", "hyp.sub_batch=32"], 51),
 }
-ALL_SCENARIOS = {**SCENARIOS, **SCENARIOS_EXTRA, **SCENARIOS_N4, **SCENARIOS_A9, **SCENARIOS_R2}
+# Round 3 (files scenarios_r3.npz / meta_r3.json, `--r3`): the benchmark's REAL shapes -- ResNet-18, 32 x 32 inputs, chunks of 128 -- with more
+# chunks than any earlier scenario (8 chunks = 1024 images, three chunk groups in the engine test), plain + clip + warm-up, and the regulariser
+# on 4 chunks.  (The earlier scenarios run 16-pixel inputs and at most 512 images: the full-size workload met the reference only in bench.py.)
+SCENARIOS_R3 = {
+    "fb_real_clip": (1024, 32, ["hyp=fbclip", "hyp.steps=3", "hyp.warmup=1", "data.batch_size=128", "hyp.sub_batch=128"], 53),
+    "fb_real_gradreg": (512, 32, ["hyp=fb1", "hyp.steps=2", "hyp.warmup=0", "hyp.grad_reg.block_strength=0.5", "data.batch_size=128",
+                                  "hyp.sub_batch=128"], 57),
+}
+ALL_SCENARIOS = {**SCENARIOS, **SCENARIOS_EXTRA, **SCENARIOS_N4, **SCENARIOS_A9, **SCENARIOS_R2, **SCENARIOS_R3}
 
 
 def run_scenario(fullbatch, compose, scen, out, dtype=torch.float):
@@ -545,6 +553,22 @@ def main_r2():
     print("wrote", os.path.join(HERE, "scenarios_r2.npz"), os.path.join(HERE, "meta_r2.json"))
 
 
+def main_r3():
+    torch.set_num_threads(8)
+    fullbatch = import_reference()
+    from fullbatchtraining_amd.cfg import compose
+
+    out = {}
+    for name in SCENARIOS_R3:
+        run_scenario(fullbatch, compose, name, out)
+        run_scenario(fullbatch, compose, name, out, dtype=torch.double)
+    meta = dict(scenarios={k: dict(n=v[0], pixels=v[1], overrides=v[2], model_seed=v[3]) for k, v in SCENARIOS_R3.items()})
+    np.savez_compressed(os.path.join(HERE, "scenarios_r3.npz"), **out)
+    with open(os.path.join(HERE, "meta_r3.json"), "w") as handle:
+        json.dump(meta, handle, indent=1)
+    print("wrote", os.path.join(HERE, "scenarios_r3.npz"), os.path.join(HERE, "meta_r3.json"))
+
+
 def main():
     torch.set_num_threads(8)
     fullbatch = import_reference()
@@ -573,7 +597,9 @@ def main():
 
 
 if __name__ == "__main__":
-    if "--r2" in sys.argv:
+    if "--r3" in sys.argv:
+        main_r3()
+    elif "--r2" in sys.argv:
         main_r2()
     elif "--a9" in sys.argv:
         main_a9()
