@@ -110,8 +110,12 @@ constexpr int BN_SPAN_U = 2;        // vectors in flight per thread and loop tri
 // streaming accesses of the span kernels: every tensor is far larger than L2 + Infinity Cache and is touched once per kernel
 typedef __attribute__((ext_vector_type(4))) unsigned bn_u32x4_t;
 __device__ __forceinline__ uint4 ld_stream(const uint4* p) {
+#ifdef FB_NO_NT
+    return *p;
+#else
     const bn_u32x4_t v = __builtin_nontemporal_load((const bn_u32x4_t*)p);
     return make_uint4(v[0], v[1], v[2], v[3]);
+#endif
 }
 // loads of the backward REDUCE pass: the apply pass re-reads the same (dout, x) rows right afterwards; -DFB_BN_REDUCE_PLAIN keeps them
 // cacheable (tools/bn_mall_experiment.py: sub-batched reduce -> apply out of the Infinity Cache)
@@ -123,7 +127,11 @@ __device__ __forceinline__ uint4 ld_reduce(const uint4* p) {
 #endif
 }
 __device__ __forceinline__ void st_stream(uint4* p, const uint4& v) {
+#ifdef FB_NO_NT
+    *p = v;
+#else
     __builtin_nontemporal_store((bn_u32x4_t){v.x, v.y, v.z, v.w}, (bn_u32x4_t*)p);
+#endif
 }
 
 // Largest magnitude of what a streaming kernel wrote (scale source of the fp16x2 convolutions, fb_absmax semantics; the caller zeroes the

@@ -288,6 +288,16 @@ __device__ __forceinline__ f32x4_t mma_planes3h(const uint4 (&a)[2], const uint4
 // FB_F32_EXACT=1 (environment, read once): fp32 convolutions on the exact-f32 MFMA instead of the split path (A/B and reference)
 bool fb_f32_split_enabled();
 
+// 128-bit buffer stores with an SGPR offset: keep the four data registers alive for a few wait states after the store.
+// The register allocator likes to reuse a data register in the instruction right behind such a store (seen: v_cndmask writing the next
+// halo request's offset into dword 1 of the vector just stored).  LLVM adds no wait state there -- its hazard table exempts MUBUF stores
+// with a register soffset, as the ISA manual does -- yet on gfx950, whenever a second stream kept the memory pipeline busy, the NEW value
+// now and then reached memory in place of the stored dword: one bf16 of ~1e38 (the low half of a byte offset) in a 50 MB gradient every
+// few launches, then Inf / NaN down the backward chain.  tools/race_probe.py found it (50 % of 3-step runs differed from the one-stream
+// trace; 0 of 192 with the guard); profiles/r3_notes.md has the hunt.
+typedef __attribute__((ext_vector_type(4))) unsigned fb_store_u32x4;
+__device__ __forceinline__ void store_b128_guard(fb_store_u32x4 data) { asm volatile("s_nop 3" ::"v"(data) : "memory"); }
+
 // Sum over the 16 lanes of a DPP row (lanes 16k..16k+15), result in every lane: four v_add_f32 with row_ror modifiers --
 // no LDS traffic (``__shfl_xor`` lowers to ds_bpermute_b32, which queues behind the fragment reads of the co-resident workgroup).
 __device__ __forceinline__ float row16_sum(float v) {

@@ -452,8 +452,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
                            v[2] += 0.25f * __uint_as_float(a.y << 16); v[3] += 0.25f * __uint_as_float(a.y & 0xffff0000u); }
                 }
                 if constexpr (EB == 4) {
-                    __builtin_amdgcn_raw_buffer_store_b128((h4_u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
-                                                           rsrcD, voffD + I * 16 * EB, soff, 0);
+                    const h4_u32x4 outv = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(outv, rsrcD, voffD + I * 16 * EB, soff, 0);
+                    store_b128_guard(outv);
                 } else {
                     // bf16: a lane holds channels 4g..4g+3 of this 16-channel fragment (8 bytes).  v_permlane16_swap exchanges the
                     // odd 16-lane rows of fragment I with the even rows of fragment I+1, after which every lane owns 8 CONSECUTIVE
@@ -463,7 +464,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
                     if constexpr ((I & 1) == 1) {
                         const h4_u32x2 lo = __builtin_amdgcn_permlane16_swap(pk[I - 1][0], pk[I][0], false, false);   // rows (X0,Y0,X2,Y2) / (X1,Y1,X3,Y3)
                         const h4_u32x2 hi = __builtin_amdgcn_permlane16_swap(pk[I - 1][1], pk[I][1], false, false);
-                        __builtin_amdgcn_raw_buffer_store_b128((h4_u32x4){lo[0], hi[0], lo[1], hi[1]}, rsrcD, voffT + (I >> 1) * 32 * EB, soff, 0);
+                        const h4_u32x4 outv = {lo[0], hi[0], lo[1], hi[1]};
+                        __builtin_amdgcn_raw_buffer_store_b128(outv, rsrcD, voffT + (I >> 1) * 32 * EB, soff, 0);
+                        store_b128_guard(outv);
                     }
                 }
                 if constexpr (BST) {

@@ -222,7 +222,9 @@ __global__ __launch_bounds__(256) void conv3x3s1_c64_halo5_kernel(const Halo5Par
                 }
                 const h5_u32x2 lo = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);   // rows: (X0,Y0,X2,Y2) / (X1,Y1,X3,Y3)
                 const h5_u32x2 hi = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
-                __builtin_amdgcn_raw_buffer_store_b128((h5_u32x4){lo[0], hi[0], lo[1], hi[1]}, rsrcD, voffS, J * 2048, 0);
+                const h5_u32x4 outv = {lo[0], hi[0], lo[1], hi[1]};
+                __builtin_amdgcn_raw_buffer_store_b128(outv, rsrcD, voffS, J * 2048, 0);
+                store_b128_guard(outv);
                 ad_issue(std::integral_constant<int, J + 3>{}, Lp);
             }
         } else if constexpr (S == 16) {
@@ -328,6 +330,8 @@ __global__ __launch_bounds__(256) void conv3x3s1_c64_halo5_kernel(const Halo5Par
     epi_prefetch(L);
     if (parity == 0) h5_static_for<0, 18>([&](auto sc) { epi_slice(sc, accA, L); });
     else h5_static_for<0, 18>([&](auto sc) { epi_slice(sc, accB, L); });
+    // (the last tile's dead halo requests are LDS-DMA writes nothing above has waited for: do not let the wave end with one in flight)
+    h5_wait_vmcnt<0>();
     H5_STAMP(4); H5_STAMP(5);
 #endif
 }

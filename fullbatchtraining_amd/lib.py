@@ -12,7 +12,7 @@ import torch
 FB_F32, FB_BF16 = 0, 1
 EXPECTED_ABI = 10         # fb_abi_version() the ctypes structs / signatures below were written for
 MT_BLOCKS = 1024
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libfbengine.so")
+_LIB_PATH = os.environ.get("FB_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libfbengine.so")     # (FB_LIB_PATH: A/B builds, tools/build_variant.py)
 
 c_void_p, c_int, c_i64, c_float, c_double = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 

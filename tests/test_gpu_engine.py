@@ -341,6 +341,41 @@ def test_replayed_command_lists_equal_interpreted_launches(dtype, fd, monkeypatc
     assert a[5] == b[5]
 
 
+def test_two_stream_schedule_is_bit_identical_to_one_stream(monkeypatch):
+    """The schedule bench.py runs (weight gradients and the running-mean pass on a second stream, recorded launches replayed natively) gives bit
+    for bit what the same launches give in one stream, every time: ResNet-18 at the benchmark's real shape (32 x 32, chunks of 128), 8 chunks
+    in groups of 3 / 3 / 2, bf16, three evaluations + updates, ten repetitions against the one-stream trace.  This is the regression test of the
+    store-data hazard of the resident-filter convolution (csrc/common.h store_b128_guard): before the guard half of such runs carried a
+    corrupted bf16 (~1e38, then Inf / NaN) in the 32 x 32 stage's input gradients, and only while two streams kept the CUs busy."""
+    pixels, chunk, G, n_chunks = 32, 128, 3, 8
+    x, y = make_data(chunk * n_chunks, pixels)
+
+    def run():
+        cfg, model, eng, stem_patches = _build(18, pixels, chunk, G, torch.bfloat16)
+        patches, yd = stem_patches(x.cuda(), eng.plan.stem, torch.bfloat16), y.cuda()
+        trace = []
+        for lr in (0.0, 0.4, 0.4):
+            loss, correct, sq = eng.full_gradient(patches, yd, lr)
+            trace += [loss.clone(), correct.clone(), sq.clone(), eng.avg.clone()]
+            eng.grad_and_param_sqnorm()
+            eng.sgd_step(lr, 5e-4, 0.9, 0.0, True, grad_clip=0.25)
+            trace.append(eng.theta.clone())
+        torch.cuda.synchronize()
+        return eng, trace + [eng.running_mean.clone(), eng.running_var.clone()]
+
+    monkeypatch.setenv("FB_WGRAD_STREAM", "0")
+    monkeypatch.setenv("FB_ACC_OVERLAP", "0")
+    eng, ref = run()
+    assert eng.wstream is None and all(bool(torch.isfinite(t).all()) for t in ref)
+    monkeypatch.delenv("FB_WGRAD_STREAM")
+    monkeypatch.delenv("FB_ACC_OVERLAP")
+    for rep in range(10):
+        eng, got = run()
+        assert eng.wstream is not None and eng.use_replay and eng.replays > 0
+        for k, (a, b) in enumerate(zip(ref, got)):
+            assert torch.equal(a, b), (rep, k, float((a - b).abs().max()))
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, "f16x2+fd"])
 def test_stem_launch_ranges_equal_one_launch(dtype, monkeypatch):
     """The pre-gathered patches of the ImageNet stem (7x7x3 -> 160 values per pixel) are the largest tensor of ResNet-152 @224 and used to cap
