@@ -211,6 +211,19 @@ def side_configs(args, device, X, Y, main_trainer):
                                                 note="MEAN gradient of all chunks of the step (what the update consumes), bf16 engine vs fp32 engine (bf16x6) at "
                                                      "the benchmark's current parameters; single chunks differ by ~0.2 (ReLU-mask flips of 2^-9-rounded pre-activations: "
                                                      "noise, not bias -- tests/test_gpu_bf16_parity.py asserts the 1/sqrt(K) decay)")
+            # the production schedule (second stream, replayed command lists) against the same launches in ONE stream: bit-identical or broken
+            # (the check that would have shown round 3's store-data hazard, csrc/common.h store_b128_guard, in the driver's own line)
+            me = main_trainer.engine
+            saved_stream, saved_lists = me.wstream, me.cmdlists
+            me.wstream, me.cmdlists = None, {}
+            try:
+                g_one = _mean_gradient(main_trainer, main_trainer.n_chunks)
+            finally:
+                me.wstream, me.cmdlists = saved_stream, saved_lists
+            again = [_mean_gradient(main_trainer, main_trainer.n_chunks) for _ in range(2)]
+            out["parity"]["two_streams_vs_one"] = dict(bit_identical=bool(torch.equal(g16, g_one) and all(torch.equal(g, g_one) for g in again)),
+                                                       evaluations=3, chunks=main_trainer.n_chunks,
+                                                       max_abs_diff=float(max((g - g_one).abs().max() for g in [g16] + again)))
             g16_16, g32_16 = _mean_gradient(main_trainer, 16), _mean_gradient(tr, 16)
             out["parity"]["bf16_vs_f32_16_chunks"] = dict(_rel(g16_16, g32_16), chunks=16)
         del tr, eng

@@ -296,7 +296,18 @@ bool fb_f32_split_enabled();
 // few launches, then Inf / NaN down the backward chain.  tools/race_probe.py found it (50 % of 3-step runs differed from the one-stream
 // trace; 0 of 192 with the guard); profiles/r3_notes.md has the hunt.
 typedef __attribute__((ext_vector_type(4))) unsigned fb_store_u32x4;
-__device__ __forceinline__ void store_b128_guard(fb_store_u32x4 data) { asm volatile("s_nop 3" ::"v"(data) : "memory"); }
+#ifndef FB_STORE_GUARD_NOPS
+#define FB_STORE_GUARD_NOPS 3          /* s_nop operand: N + 1 wait states (A/B builds: tools/build_variant.py) */
+#endif
+__device__ __forceinline__ void store_b128_guard(fb_store_u32x4 data) {
+#if FB_STORE_GUARD_NOPS >= 0
+#ifdef FB_STORE_GUARD_NOMEM
+    asm volatile("s_nop %1" ::"v"(data), "n"(FB_STORE_GUARD_NOPS));
+#else
+    asm volatile("s_nop %1" ::"v"(data), "n"(FB_STORE_GUARD_NOPS) : "memory");
+#endif
+#endif
+}
 
 // Sum over the 16 lanes of a DPP row (lanes 16k..16k+15), result in every lane: four v_add_f32 with row_ror modifiers --
 // no LDS traffic (``__shfl_xor`` lowers to ds_bpermute_b32, which queues behind the fragment reads of the co-resident workgroup).

@@ -341,21 +341,33 @@ def test_replayed_command_lists_equal_interpreted_launches(dtype, fd, monkeypatc
     assert a[5] == b[5]
 
 
-def test_two_stream_schedule_is_bit_identical_to_one_stream(monkeypatch):
+@pytest.mark.parametrize("case", ["r18-bf16", "r18-fd-f16x2", "r18-fd-bf16x6", "r50-bf16", "r152-bf16"])
+def test_two_stream_schedule_is_bit_identical_to_one_stream(case, monkeypatch):
     """The schedule bench.py runs (weight gradients and the running-mean pass on a second stream, recorded launches replayed natively) gives bit
-    for bit what the same launches give in one stream, every time: ResNet-18 at the benchmark's real shape (32 x 32, chunks of 128), 8 chunks
-    in groups of 3 / 3 / 2, bf16, three evaluations + updates, ten repetitions against the one-stream trace.  This is the regression test of the
-    store-data hazard of the resident-filter convolution (csrc/common.h store_b128_guard): before the guard half of such runs carried a
-    corrupted bf16 (~1e38, then Inf / NaN) in the 32 x 32 stage's input gradients, and only while two streams kept the CUs busy."""
-    pixels, chunk, G, n_chunks = 32, 128, 3, 8
+    for bit what the same launches give in one stream, every time.  ``r18-bf16``: ResNet-18 at the benchmark's real shape (32 x 32, chunks of
+    128), 8 chunks in groups of 3 / 3 / 2, three evaluations + updates, ten repetitions against the one-stream trace -- the regression test of
+    the store-data hazard of the resident-filter convolution (csrc/common.h store_b128_guard): before the guard half of such runs carried a
+    corrupted bf16 (~1e38, then Inf / NaN) in the 32 x 32 stage's input gradients, and only while two streams kept the CUs busy.  The other
+    cases put the remaining kernel families under the same two-stream load: the fp32 finite-difference passes in both split modes (per-chunk
+    weight sets, fp16x2 scale slots) and Bottleneck models with the standard stem (streaming 1x1 kernels, 1x1 / all-taps weight gradients), ResNet-152 at 224 px among them."""
+    fd = case.startswith("r18-fd")
+    if case == "r50-bf16":
+        depth, stem, pixels, chunk, G, n_chunks, dtype, reps = 50, "standard", 64, 32, 2, 5, torch.bfloat16, 6
+    elif case == "r152-bf16":            # BASELINE config 5's shape: 224 px, chunks of 128 (56 / 28 / 14 / 7 maps, MaxPool, 1x1 streaming kernels)
+        depth, stem, pixels, chunk, G, n_chunks, dtype, reps = 152, "standard", 224, 128, 2, 3, torch.bfloat16, 3
+    elif fd:
+        depth, stem, pixels, chunk, G, n_chunks, dtype, reps = 18, "CIFAR", 32, 128, 2, 3, torch.float32, 6
+        monkeypatch.setenv("FB_F32_SPLIT", case.split("-")[-1])
+    else:
+        depth, stem, pixels, chunk, G, n_chunks, dtype, reps = 18, "CIFAR", 32, 128, 3, 8, torch.bfloat16, 10
     x, y = make_data(chunk * n_chunks, pixels)
 
     def run():
-        cfg, model, eng, stem_patches = _build(18, pixels, chunk, G, torch.bfloat16)
-        patches, yd = stem_patches(x.cuda(), eng.plan.stem, torch.bfloat16), y.cuda()
+        cfg, model, eng, stem_patches = _build(depth, pixels, chunk, G, dtype, fd_sets=1 if fd else 0, stem=stem)
+        patches, yd = stem_patches(x.cuda(), eng.plan.stem, dtype), y.cuda()
         trace = []
         for lr in (0.0, 0.4, 0.4):
-            loss, correct, sq = eng.full_gradient(patches, yd, lr)
+            loss, correct, sq = eng.full_gradient(patches, yd, lr, block_strength=0.5 if fd else 0.0)
             trace += [loss.clone(), correct.clone(), sq.clone(), eng.avg.clone()]
             eng.grad_and_param_sqnorm()
             eng.sgd_step(lr, 5e-4, 0.9, 0.0, True, grad_clip=0.25)
@@ -369,11 +381,11 @@ def test_two_stream_schedule_is_bit_identical_to_one_stream(monkeypatch):
     assert eng.wstream is None and all(bool(torch.isfinite(t).all()) for t in ref)
     monkeypatch.delenv("FB_WGRAD_STREAM")
     monkeypatch.delenv("FB_ACC_OVERLAP")
-    for rep in range(10):
+    for rep in range(reps):
         eng, got = run()
         assert eng.wstream is not None and eng.use_replay and eng.replays > 0
         for k, (a, b) in enumerate(zip(ref, got)):
-            assert torch.equal(a, b), (rep, k, float((a - b).abs().max()))
+            assert torch.equal(a, b), (case, rep, k, float((a - b).abs().max()))
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, "f16x2+fd"])
