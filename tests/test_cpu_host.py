@@ -29,6 +29,31 @@ def test_library_exports_every_declared_symbol():
     assert handle.fb_abi_version() == lib.EXPECTED_ABI
 
 
+def test_built_kernels_keep_wide_buffer_store_data_alive():
+    """Static check of the built gfx950 code (tools/hazard_scan.py): no 128-bit MUBUF store with an SGPR offset is followed within two wait
+    states by a write to one of its data registers.  LLVM adds no wait state behind such stores and gfx950 needs one whenever another stream
+    keeps the memory pipeline busy (profiles/r3_notes.md: the rewritten register now and then reached memory instead of the stored dword);
+    the kernels hold the data registers with csrc/common.h store_b128_guard.  The scan must also still SEE such stores (the guarded ones)."""
+    import importlib.util
+
+    import __graft_entry__ as entry
+    from fullbatchtraining_amd import lib
+
+    entry.build()
+    spec = importlib.util.spec_from_file_location("hazard_scan", os.path.join(REPO, "tools", "hazard_scan.py"))
+    hs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hs)
+    ins = hs.disassemble(lib._LIB_PATH)
+    assert len({k for k, _ in ins}) > 100 and sum(1 for _, t in ins if t.startswith("buffer_store_dwordx4")) > 100
+    bad, _ = hs.scan(ins)
+    assert not bad, bad[:3]
+    # the scanner itself: the unguarded shape is reported, a guarded one is not
+    demo = [("k", "buffer_store_dwordx4 v[44:47], v82, s[44:47], s78 offen"), ("k", "v_cndmask_b32_e64 v45, v115, v90, s[10:11]")]
+    assert len(hs.scan(demo)[0]) == 1
+    demo.insert(1, ("k", "s_nop 3"))
+    assert not hs.scan(demo)[0]
+
+
 def test_workspace_size_queries():
     """Host-side arithmetic of the C ABI (no launch): scratch sizes the caller has to provide."""
     from fullbatchtraining_amd import lib
