@@ -4,7 +4,7 @@ Runs three full-gradient evaluations + updates in ONE stream (FB_WGRAD_STREAM=0,
 deterministic, so everything must be bit-identical) and then repeatedly with the schedule under test (the environment as given), and reports
 the first tensors that differ: per-chunk losses, per-chunk squared norms, the averaged gradient per parameter tensor, parameters.
 
-    python tools/race_probe.py [repeats] [n_chunks] [G] [bf16|f32]
+    python tools/race_probe.py [repeats] [n_chunks] [G] [bf16|f32] [steps]      (soak: `3 390 98 bf16 40` = the benchmark's full step, 40 times)
 
 FB_PROBE_INSTRUMENT=1 records checkpoints into the backward pass of the 32 x 32 stage (per-chunk sums of squares of every input gradient /
 BatchNorm-backward result, read as fp32 words) and prints the first non-finite ones; FB_PROBE_TWICE=1 additionally repeats every BatchNorm
@@ -152,8 +152,9 @@ def main():
     n_chunks = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     G = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     dtype = dict(bf16=torch.bfloat16, f32=torch.float32)[sys.argv[4] if len(sys.argv) > 4 else "bf16"]
-    pixels, chunk, steps = 32, 128, 3
-    lrs = [0.0, 0.4, 0.4]
+    pixels, chunk = 32, 128
+    steps = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+    lrs = [0.0] + [0.4] * (steps - 1)
     x, y = make_data(chunk * n_chunks, pixels)
     base = dict(os.environ)
     os.environ["FB_ACC_OVERLAP"] = "0"
