@@ -200,6 +200,15 @@ def side_configs(args, device, X, Y, main_trainer):
         eng = tr.engine
         eng.theta.copy_(e16.theta), eng.running_mean.copy_(e16.running_mean), eng.running_var.copy_(e16.running_var)
         grads[mode] = _mean_gradient(tr, 16, block_strength=0.5)
+        # (the regularised passes too: production schedule vs one stream, bit for bit)
+        saved_stream, saved_lists = eng.wstream, eng.cmdlists
+        eng.wstream, eng.cmdlists = None, {}
+        try:
+            g_one = _mean_gradient(tr, 16, block_strength=0.5)
+        finally:
+            eng.wstream, eng.cmdlists = saved_stream, saved_lists
+        out["parity"].setdefault("two_streams_vs_one_regularised", {})[mode] = dict(
+            bit_identical=bool(torch.equal(grads[mode], g_one)), chunks=16, max_abs_diff=float((grads[mode] - g_one).abs().max()))
         if mode == "bf16x6":
             # the fp32 (exact-product) gradient of ALL chunks at the benchmark's parameters, against the bf16 path that produced `value`
             t0 = time.perf_counter()
