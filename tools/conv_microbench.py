@@ -10,7 +10,7 @@ CASES = {  # name: (cin, cout, k, stride, hw, n_img)
     # the downsampling blocks at the benchmark's group size (98 chunks): stride-2 3x3 and the 1x1 shortcut (on the pooled input)
     "d2": (64, 128, 3, 2, 32, 12544), "d3": (128, 256, 3, 2, 16, 12544), "d4": (256, 512, 3, 2, 8, 12544),
     "s2": (64, 128, 1, 1, 16, 12544), "s3": (128, 256, 1, 1, 8, 12544), "s4": (256, 512, 1, 1, 4, 12544),
-    "l2g": (128, 128, 3, 1, 16, 12544), "l3g": (256, 256, 3, 1, 8, 12544), "l4g": (512, 512, 3, 1, 4, 12544), "stemg": (32, 64, 1, 1, 32, 12544),
+    "l1g": (64, 64, 3, 1, 32, 12544), "l2g": (128, 128, 3, 1, 16, 12544), "l3g": (256, 256, 3, 1, 8, 12544), "l4g": (512, 512, 3, 1, 4, 12544), "stemg": (32, 64, 1, 1, 32, 12544),
     # ResNet-152 @224, one chunk group of 4 chunks (512 images): the 1x1 convolutions of the Bottleneck stages and their 3x3s
     "b1a": (64, 256, 1, 1, 56, 512), "b1b": (256, 64, 1, 1, 56, 512), "b2a": (128, 512, 1, 1, 28, 512), "b2b": (512, 128, 1, 1, 28, 512),
     "b3a": (256, 1024, 1, 1, 14, 512), "b3b": (1024, 256, 1, 1, 14, 512), "b4a": (512, 2048, 1, 1, 7, 512), "b4b": (2048, 512, 1, 1, 7, 512),
@@ -56,7 +56,7 @@ def main():
         ipg = 128
         if os.environ.get("NO_WGRAD"):
             continue
-        for split in ((int(os.environ["SPLITS"]),) if os.environ.get("SPLITS") else ((32, 8, 1) if k == 3 and stride == 1 else (8, 1))):
+        for split in (tuple(int(v) for v in os.environ["SPLITS"].split(",")) if os.environ.get("SPLITS") else ((32, 8, 1) if k == 3 and stride == 1 else (8, 1))):
             slab = torch.empty(n // ipg * split * cout * k * k * cin, device="cuda")
             try:
                 t = bench(lambda: lib.conv2d_wgrad(x, dy, slab, k, k, stride, pad, ipg, split))
