@@ -65,13 +65,16 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(const ConvParams p, 
 
     int a_pix[4], a_y[4], a_x[4];
     const int qHW = p.qH * p.qW;
+    // source pixels are counted from the tile's first image and the descriptor starts there: the 32-bit offsets stay small whatever the
+    // tensor's size (chunk groups beyond 2^31 bytes per tensor)
+    const int n_first = __builtin_amdgcn_readfirstlane((mblk * 128) / qHW);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = mblk * 128 + lrow + 32 * i;
         if (m < p.M) {
             const int n = m / qHW, rem = m - n * qHW, qy = rem / p.qW, qx = rem - qy * p.qW;
             a_y[i] = qy * p.ss; a_x[i] = qx * p.ss;
-            a_pix[i] = n * p.Hs * p.Ws + a_y[i] * p.Ws + a_x[i];
+            a_pix[i] = (n - n_first) * p.Hs * p.Ws + a_y[i] * p.Ws + a_x[i];
         } else {
             a_pix[i] = 0; a_y[i] = -(1 << 28); a_x[i] = 0;
         }
@@ -79,7 +82,10 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(const ConvParams p, 
     const int wset = __builtin_amdgcn_readfirstlane(((mblk * 128) / qHW) / p.imgs_per_wset);
     const int taps = p.R * p.S;
     const int row_b = p.Cs * EB;                                   // bytes of one pixel / one (co, tap) weight row
-    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.n_img * p.Hs * p.Ws * row_b, 0x00020000);
+    const long long img_b = (long long)p.Hs * p.Ws * row_b;
+    const long long left_b = (long long)(p.n_img - n_first) * img_b;
+    const __amdgpu_buffer_rsrc_t rsrcA =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.src + (long long)n_first * img_b), 0, (int)(left_b < 0x7fffffffLL ? left_b : 0x7fffffffLL), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.wgt + (long long)wset * p.wset_stride_bytes), 0, p.Cd * taps * row_b, 0x00020000);
     unsigned voffW[WROWS];
@@ -300,8 +306,9 @@ template <typename T> static void launch(const ConvParams& p, int classes, hipSt
 // returns 1 if launched, 0 if the tensors are too large for 32-bit buffer offsets (caller falls back to conv_igemm.hip)
 int fb_launch_igemm_glds(const ConvParams& p, int classes, int dtype, hipStream_t st) {
     const int EB = dtype == FB_F32 ? 4 : 2;
-    const long long bytesA = (long long)p.n_img * p.Hs * p.Ws * p.Cs * EB, bytesW = (long long)p.Cd * p.R * p.S * p.Cs * EB;
-    if (bytesA >= (1LL << 31) || bytesW >= (1LL << 31)) return 0;
+    // a 128-pixel tile addresses the images it covers (+ the next one) from its own descriptor base
+    const long long bytesA = (long long)(128 / (p.qH * p.qW) + 2) * p.Hs * p.Ws * p.Cs * EB, bytesW = (long long)p.Cd * p.R * p.S * p.Cs * EB;
+    if (bytesA >= (1LL << 31) || bytesW >= (1LL << 31) || (long long)p.n_img * p.qH * p.qW >= (1LL << 31)) return 0;
     if (dtype == FB_F32) {
         if (p.amax_src && p.amax_wgt) launch<f32h_tag>(p, classes, st);
         else if (fb_f32_split_enabled()) launch<f32s_tag>(p, classes, st);

@@ -148,8 +148,13 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Par
     const int rowA_b = p.Cd * 2, rowB_b = p.Cs * 2;    // bytes per pixel of dY / X
     const int lrow8 = lane >> 3;
 
-    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.n_img * p.H * W * rowA_b, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.n_img * Hi * WI * rowB_b, 0x00020000);
+    // descriptors based at the workgroup's first image (a K slice is at most a chunk: the 32-bit offsets below stay small whatever the tensors'
+    // sizes -- chunk groups beyond 2^31 bytes per tensor)
+    const int n_own = max(img_end - img0, 0);
+    const __amdgpu_buffer_rsrc_t rsrcA =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.dy + (long long)img0 * p.H * W * rowA_b), 0, n_own * p.H * W * rowA_b, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (long long)img0 * Hi * WI * rowB_b), 0, n_own * Hi * WI * rowB_b, 0x00020000);
     // per-lane source offsets relative to the first pixel of the step; source-side slot swizzle
     unsigned voffA[KA];
 #pragma unroll
@@ -179,8 +184,8 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Par
     auto issue = [&](int stage, int step) {
         char* base = lds + stage * STAGE;
         int img, y0;
-        if constexpr (G::WHOLE) { img = img0 + step * G::IMGS; y0 = 0; }
-        else { img = img0 + step / steps_per_img; y0 = (step % steps_per_img) * G::RS; }
+        if constexpr (G::WHOLE) { img = step * G::IMGS; y0 = 0; }                        // (image index relative to img0)
+        else { img = step / steps_per_img; y0 = (step % steps_per_img) * G::RS; }
         const int soffA = (img * p.H + y0) * W * rowA_b;
 #pragma unroll
         for (int k = 0; k < KA; ++k)
@@ -305,7 +310,8 @@ int fb_try_wgrad3x3_v2(const fb_wgrad_args* a, hipStream_t st) {
     // K slices are whole images; the last slice of a chunk may be shorter (or empty: it then contributes zeros)
     int imgs_per_block = (a->imgs_per_group + a->split_k - 1) / a->split_k;
     if (W == 4) { if (a->imgs_per_group & 1) return 0; imgs_per_block += imgs_per_block & 1; }   // 4x4 maps: image pairs per K-step
-    const long long bytes_x = (long long)a->n_img * a->Hs * a->Ws * a->Cs * 2, bytes_dy = (long long)a->n_img * a->Hd * a->Wd * a->Cd * 2;
+    // (a workgroup addresses its own K slice only: at most a chunk)
+    const long long bytes_x = (long long)(imgs_per_block + 2) * a->Hs * a->Ws * a->Cs * 2, bytes_dy = (long long)(imgs_per_block + 2) * a->Hd * a->Wd * a->Cd * 2;
     if (bytes_x >= (1LL << 31) || bytes_dy >= (1LL << 31)) return 0;
     Wgrad3V2Params p;
     p.x = (const char*)a->x; p.dy = (const char*)a->dy; p.out = a->dw_partial;

@@ -59,12 +59,15 @@ class Block:
 
 
 def max_group(plan, chunk, dtype):
-    """Largest chunk group whose biggest activation tensor (NHWC, compute dtype) stays below 2^31 bytes: the LDS-DMA kernels address
-    their operands with 32-bit buffer offsets and hand larger tensors to the slower pointer-based kernels."""
+    """Largest chunk group the fast kernels take.  fp32 storage: the biggest activation tensor (NHWC) stays below 2^31 bytes -- the fp32 LDS-DMA
+    kernels address whole tensors with 32-bit buffer offsets and hand larger ones to the slower pointer-based kernels.  bf16: every kernel
+    bases its descriptors at its own tile / K slice (round 3), so only a sanity limit of 2^35 bytes per tensor remains (the persistent
+    kernels' tile counts are 32-bit)."""
     # (the stem's pre-gathered patches -- 7x7x3 -> 160 values per pixel for the ImageNet stem, the largest tensor by far -- do not count: the two
     # launches that read them are cut into chunk ranges below 2^31 bytes, Engine._stem_ranges; ResNet-152 @224: groups of 10 chunks instead of 4)
     per_image = max(max(L.hout * L.wout * L.cout, L.hin * L.win * (L.cin_pad if L is not plan.stem else 0)) for L in plan.layers)
-    return max(1, ((1 << 31) - 1) // (chunk * per_image * torch.empty((), dtype=dtype).element_size()))
+    limit = (1 << 35) if dtype == torch.bfloat16 and os.environ.get("FB_BIG_GROUPS", "1") != "0" else (1 << 31) - 1
+    return max(1, limit // (chunk * per_image * torch.empty((), dtype=dtype).element_size()))
 
 
 def padded_chunk(plan, chunk):

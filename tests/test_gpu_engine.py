@@ -388,6 +388,48 @@ def test_two_stream_schedule_is_bit_identical_to_one_stream(case, monkeypatch):
             assert torch.equal(a, b), (case, rep, k, float((a - b).abs().max()))
 
 
+def test_chunk_group_beyond_2g_byte_tensors_equals_smaller_groups():
+    """bf16 chunk groups whose activation tensors exceed 2^31 bytes (more than 127 chunks of 128 images at 32 x 32 x 64 channels): every kernel bases
+    its buffer descriptors at its own tile / K slice, so the 32-bit offsets inside stay small.  130 chunks in ONE group (the 64-channel tensors are
+    2.18 GB each) give the losses and BatchNorm statistics of the same chunks in two groups of 65 bit for bit (the forward pass is the same
+    arithmetic) and the same gradients up to the summation order of the BatchNorm-backward reduction, whose partial rows cover 128-1024 pixels
+    depending on the launch's pixel count (fb_bn_bwd_reduce_rows; a different fp32 sum order moves a few bf16 roundings of dx): EVERY chunk's
+    squared gradient norm to 1e-3 (measured 2e-4), the mean gradient to 2e-3 relative L2 (measured 5.7e-4; the bf16 path itself is 6e-3 from fp32).
+    A wrong address anywhere in a 2 GB tensor would be garbage or a chunk off by per cent.  Same K-slice counts: nominal_group = 130 for both."""
+    import gc
+
+    from fullbatchtraining_amd.cfg import compose
+    from fullbatchtraining_amd.engine import Engine, stem_patches
+    from fullbatchtraining_amd.models import construct_model
+
+    pixels, chunk, n_chunks = 32, 128, 130
+    x, y = make_data(chunk * 4, pixels)
+    x, y = x.repeat(n_chunks // 4 + 1, 1, 1, 1)[:chunk * n_chunks], y.repeat(n_chunks // 4 + 1)[:chunk * n_chunks]
+    x = x + 0.01 * torch.arange(chunk * n_chunks).view(-1, 1, 1, 1) / (chunk * n_chunks)       # (no two chunks alike)
+    cfg = compose(["model=resnet18", "model.stem=CIFAR"])
+    out = {}
+    for G in (65, 130):
+        torch.manual_seed(0)
+        model = construct_model(cfg.model, 3, 10)
+        eng = Engine(model, pixels, chunk, G, compute_dtype=torch.bfloat16, nominal_group=130)
+        if G == 130:
+            assert max(t.numel() * t.element_size() for t in (eng.stem_out, eng.plan.blocks[0].out)) > (1 << 31)
+        patches, yd = stem_patches(x.cuda(), eng.plan.stem, torch.bfloat16), y.cuda()
+        loss, correct, sq = eng.full_gradient(patches, yd, 0.1)
+        torch.cuda.synchronize()
+        out[G] = (loss.cpu(), correct.cpu(), sq.cpu(), eng.avg.cpu(), eng.running_mean.cpu(), eng.running_var.cpu())
+        del eng, patches, model
+        gc.collect(), torch.cuda.empty_cache()
+    a, b = out[65], out[130]
+    assert bool(torch.isfinite(b[3]).all())
+    for k in (0, 1, 4, 5):
+        assert torch.equal(a[k], b[k]), (k, float((a[k] - b[k]).abs().max()))
+    assert float(((a[2] - b[2]).abs() / a[2]).max()) < 1e-3
+    err = float((a[3] - b[3]).norm() / a[3].norm())
+    print(f"mean gradient of 130 chunks, one group vs two: rel L2 {err:.2e}")
+    assert err < 2e-3
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, "f16x2+fd"])
 def test_stem_launch_ranges_equal_one_launch(dtype, monkeypatch):
     """The pre-gathered patches of the ImageNet stem (7x7x3 -> 160 values per pixel) are the largest tensor of ResNet-152 @224 and used to cap
