@@ -66,8 +66,17 @@ def max_group(plan, chunk, dtype):
     # (the stem's pre-gathered patches -- 7x7x3 -> 160 values per pixel for the ImageNet stem, the largest tensor by far -- do not count: the two
     # launches that read them are cut into chunk ranges below 2^31 bytes, Engine._stem_ranges; ResNet-152 @224: groups of 10 chunks instead of 4)
     per_image = max(max(L.hout * L.wout * L.cout, L.hin * L.win * (L.cin_pad if L is not plan.stem else 0)) for L in plan.layers)
-    limit = (1 << 35) if dtype == torch.bfloat16 and os.environ.get("FB_BIG_GROUPS", "1") != "0" else (1 << 31) - 1
-    return max(1, limit // (chunk * per_image * torch.empty((), dtype=dtype).element_size()))
+    es = torch.empty((), dtype=dtype).element_size()
+    cap31 = max(1, ((1 << 31) - 1) // (chunk * per_image * es))
+    if dtype != torch.bfloat16 or os.environ.get("FB_BIG_GROUPS", "1") == "0":
+        return cap31
+    # beyond the old limit only as far as the resident activations of a group fit: conv outputs + post-BN activations + block outputs
+    # (+ ReLU masks) per image and ~8 gradient buffers of the largest tensor, against a third of the device (the rest: per-chunk
+    # gradients, patches, other engines)
+    acts = sum(2 * L.hout * L.wout * L.cout for L in plan.layers) + sum(b.convs[-1].hout * b.convs[-1].wout * b.convs[-1].cout for b in plan.blocks)
+    per_image_bytes = (acts * 17 // 16 + 8 * per_image) * es
+    total = torch.cuda.get_device_properties(0).total_memory if torch.cuda.is_available() else 288 << 30
+    return max(cap31, min((1 << 35) // (chunk * per_image * es), (total // 3) // (chunk * per_image_bytes)))
 
 
 def padded_chunk(plan, chunk):

@@ -189,14 +189,23 @@ def test_padded_chunk_sizes():
     assert Plan(model, 32, arena_align=64 * 7).P % 7 == 0 and Plan(model, 32).P % 64 == 0
 
 
-def test_group_cap_keeps_activations_in_32bit_range():
+def test_group_cap_keeps_activations_in_32bit_range(monkeypatch):
+    """fp32 storage: the largest activation tensor of a chunk group stays below 2^31 bytes (32-bit buffer offsets of the fp32 LDS-DMA kernels).
+    bf16: the kernels base their descriptors at their own tile / K slice, so a group may be larger -- as far as a third of the device holds its
+    activations (288 GB assumed without a GPU); FB_BIG_GROUPS=0 keeps the 2^31 rule."""
     from fullbatchtraining_amd.cfg import compose
     from fullbatchtraining_amd.engine import Plan, max_group
     from fullbatchtraining_amd.models import construct_model
 
     plan = Plan(construct_model(compose([]).model, 3, 10), 32)
-    assert max_group(plan, 128, torch.float32) == 63 and max_group(plan, 128, torch.bfloat16) == 127
-    assert max_group(plan, 32, torch.float32) == 255
+    assert max_group(plan, 128, torch.float32) == 63 and max_group(plan, 32, torch.float32) == 255
+    big = max_group(plan, 128, torch.bfloat16)
+    assert 127 < big <= 390 and big * 128 * 4_000_000 < 288 << 30          # (~3.2 MB of activations per image + gradient buffers)
+    monkeypatch.setenv("FB_BIG_GROUPS", "0")
+    assert max_group(plan, 128, torch.bfloat16) == 127
+    deep = Plan(construct_model(compose(["model=resnet152", "model.stem=standard"]).model, 3, 10), 224)
+    monkeypatch.delenv("FB_BIG_GROUPS")
+    assert max_group(deep, 128, torch.bfloat16) == 10 and max_group(deep, 128, torch.float32) == 5          # (memory-bound: as before)
 
 
 def test_optimizer_wrappers_have_the_reference_surface():
