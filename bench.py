@@ -372,6 +372,20 @@ def roofline_objects(args, trainer, launches, launches_iso, sec_per_step, world,
         out["hbm"] = {"bytes_per_step": total, "tb_per_s": round(total / sec_per_step / 1e12, 3), "peak_tb_per_s": PEAK_HBM_GBS / 1e3,
                       "frac": round(total / sec_per_step / 1e9 / PEAK_HBM_GBS, 4), "source": "profiles/hbm_traffic.json: " + pmc["command"],
                       "by_kernel_gb_per_step": {k: round(v["bytes_per_launch"] * v["launches"] / 1e9, 2) for k, v in sorted(pmc["kernels"].items(), key=lambda kv: -kv[1]["bytes_per_launch"] * kv[1]["launches"])[:12]}}
+    if profiled:            # MFMA utilisation from the hardware counters (tools/pmc_mfma.sh), quoted next to the algorithmic fraction when the file is there
+        path = os.path.join(ROOT, "profiles", "mfma_util.json")
+        if os.path.isfile(path):
+            with open(path) as handle:
+                mu = json.load(handle)
+            hits = [v for k, v in mu["kernels"].items() if dom in k]
+            w = sum(v["ms_per_step"] for v in hits)
+            out["mfma_util_pmc"] = {
+                "step_serialized": round(mu["mfma_util"], 4), "step_frac_of_peak_over_kernel_time": round(mu["frac_of_2p5_pflops_over_kernel_time"], 4),
+                "executed_mfma_tflop_per_step": round(mu["executed_mfma_tflop_per_step"], 2),
+                "algorithmic_tflop_per_step": round(flop_img * passes * trainer.datapoints / 1e12, 2),
+                "dominant_kernel": round(sum(v["mfma_util"] * v["ms_per_step"] for v in hits) / w, 4) if w else None,
+                "source": "profiles/mfma_util.json: " + mu["command"],
+                "note": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), kernels one at a time"}
     return out
 
 
