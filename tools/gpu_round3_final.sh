@@ -6,6 +6,7 @@ out=gpurun_out/r3final; mkdir -p $out
 timeout 1200 python bench.py > $out/bench_default.json 2> $out/bench_default.err; head -c 400 $out/bench_default.json; echo
 bash tools/profile_bench.sh r3final --no-kernel-timing > $out/profile.log 2>&1; tail -3 $out/profile.log | cut -c1-300
 bash tools/pmc_bench.sh r3final > $out/pmc.log 2>&1; tail -6 $out/pmc.log | cut -c1-200
+bash tools/pmc_mfma.sh r3final > $out/pmc_mfma.log 2>&1; tail -3 $out/pmc_mfma.log | cut -c1-300; cp gpurun_out/pmcmfma_r3final/summary.md $out/mfma_util.md; cp gpurun_out/pmcmfma_r3final/mfma_util.json $out/mfma_util.json
 python tools/roofline_table.py gpurun_out/prof_r3final gpurun_out/pmcbench_r3final 3 > $out/roofline_per_kernel.md 2>&1; head -14 $out/roofline_per_kernel.md | cut -c1-200
 FB_WGRAD_STREAM=0 python tools/step_breakdown.py bf16 98 > $out/breakdown_bf16.md 2>&1; tail -14 $out/breakdown_bf16.md
 FB_WGRAD_STREAM=0 python tools/step_breakdown.py bf16 8 resnet152 standard 224 128 > $out/breakdown_r152.md 2>&1; tail -16 $out/breakdown_r152.md
