@@ -21,6 +21,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.helpers import make_data  # noqa: E402
 
 
+FD = float(os.environ.get("FB_PROBE_FD", "0"))       # block_strength of the finite-difference regulariser (fp32 passes, per-chunk weight sets)
+
+
 def build(pixels, chunk, G, dtype):
     from fullbatchtraining_amd.cfg import compose
     from fullbatchtraining_amd.engine import Engine, stem_patches
@@ -29,7 +32,7 @@ def build(pixels, chunk, G, dtype):
     cfg = compose(["model=resnet18", "model.stem=CIFAR"])
     torch.manual_seed(0)
     model = construct_model(cfg.model, 3, 10)
-    return Engine(model, pixels, chunk, G, compute_dtype=dtype), stem_patches
+    return Engine(model, pixels, chunk, G, compute_dtype=dtype, fd_sets=1 if FD else 0), stem_patches
 
 
 TWICE = []
@@ -94,7 +97,7 @@ def run(x, y, pixels, chunk, G, dtype, steps, lrs):
     patches, yd = stem_patches(x.cuda(), eng.plan.stem, dtype), y.cuda()
     trace = []
     for step in range(steps):
-        loss, correct, sq = eng.full_gradient(patches, yd, lrs[step])
+        loss, correct, sq = eng.full_gradient(patches, yd, lrs[step], block_strength=FD)
         avg = eng.avg.clone()
         eng.grad_and_param_sqnorm()
         eng.sgd_step(lrs[step], 5e-4, 0.9, 0.0, True, grad_clip=0.25)
