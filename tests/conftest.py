@@ -22,7 +22,7 @@ def golden():
     with open(os.path.join(here, "meta.json")) as handle:
         meta = json.load(handle)
     data = dict(np.load(os.path.join(here, "scenarios.npz")))
-    for tag in ("extra", "n4", "a9", "r2", "r3"):                            # scenarios added later (make_golden.py --extra / --n4 / --a9)
+    for tag in ("extra", "n4", "a9", "r2", "r3", "r3b"):                            # scenarios added later (make_golden.py --extra / --n4 / --a9)
         extra = os.path.join(here, f"scenarios_{tag}.npz")
         if os.path.isfile(extra):
             data.update(np.load(extra))

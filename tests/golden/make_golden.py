@@ -174,7 +174,12 @@ SCENARIOS_R3 = {
     "fb_real_gradreg": (512, 32, ["hyp=fb1", "hyp.steps=2", "hyp.warmup=0", "hyp.grad_reg.block_strength=0.5", "data.batch_size=128",
                                   "hyp.sub_batch=128"], 57),
 }
-ALL_SCENARIOS = {**SCENARIOS, **SCENARIOS_EXTRA, **SCENARIOS_N4, **SCENARIOS_A9, **SCENARIOS_R2, **SCENARIOS_R3}
+# (files scenarios_r3b.npz / meta_r3b.json, `--r3b`): the all-50 000-images variant of the benchmark (bench.py configs.k400) at its real shape --
+# chunks of 125 images at 32 x 32 (stored padded to 128 by the engine), clip + warm-up
+SCENARIOS_R3B = {
+    "fb_real_k125": (500, 32, ["hyp=fbclip", "hyp.steps=2", "hyp.warmup=1", "data.batch_size=125", "hyp.sub_batch=125"], 59),
+}
+ALL_SCENARIOS = {**SCENARIOS, **SCENARIOS_EXTRA, **SCENARIOS_N4, **SCENARIOS_A9, **SCENARIOS_R2, **SCENARIOS_R3, **SCENARIOS_R3B}
 
 
 def run_scenario(fullbatch, compose, scen, out, dtype=torch.float):
@@ -569,6 +574,22 @@ def main_r3():
     print("wrote", os.path.join(HERE, "scenarios_r3.npz"), os.path.join(HERE, "meta_r3.json"))
 
 
+def main_r3b():
+    torch.set_num_threads(8)
+    fullbatch = import_reference()
+    from fullbatchtraining_amd.cfg import compose
+
+    out = {}
+    for name in SCENARIOS_R3B:
+        run_scenario(fullbatch, compose, name, out)
+        run_scenario(fullbatch, compose, name, out, dtype=torch.double)
+    meta = dict(scenarios={k: dict(n=v[0], pixels=v[1], overrides=v[2], model_seed=v[3]) for k, v in SCENARIOS_R3B.items()})
+    np.savez_compressed(os.path.join(HERE, "scenarios_r3b.npz"), **out)
+    with open(os.path.join(HERE, "meta_r3b.json"), "w") as handle:
+        json.dump(meta, handle, indent=1)
+    print("wrote", os.path.join(HERE, "scenarios_r3b.npz"), os.path.join(HERE, "meta_r3b.json"))
+
+
 def main():
     torch.set_num_threads(8)
     fullbatch = import_reference()
@@ -597,7 +618,9 @@ def main():
 
 
 if __name__ == "__main__":
-    if "--r3" in sys.argv:
+    if "--r3b" in sys.argv:
+        main_r3b()
+    elif "--r3" in sys.argv:
         main_r3()
     elif "--r2" in sys.argv:
         main_r2()

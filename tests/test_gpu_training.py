@@ -71,7 +71,10 @@ def _run(meta, name, extra=(), tmp_path=None, valid_full=False):
                                             ("fb_ragged_gradreg", 8e-3, 2), ("fb_r50_gradreg", 8e-3, 2),
                                             # round 3: the benchmark's real shapes (32 px, chunks of 128), 8 chunks in three chunk groups with clip + warm-up;
                                             # 4 chunks with the regulariser (f16x2 passes)
-                                            ("fb_real_clip", 2e-4, 3), ("fb_real_gradreg", 3e-3, 2)])
+                                            ("fb_real_clip", 2e-4, 3), ("fb_real_gradreg", 3e-3, 2),
+                                            # ... and the all-50 000-images variant of the benchmark (bench.py configs.k400): chunks of 125 images at 32 x 32,
+                                            # stored padded to 128 (scenarios_r3b.npz)
+                                            ("fb_real_k125", 3e-3, 2)])
 def test_train_matches_reference_run_f32(golden, name, tol, group, tmp_path):
     data, meta = golden
     cfg, model, stats = _run(meta, name, [f"impl.engine.chunk_group={group}"], tmp_path)
@@ -207,6 +210,21 @@ def test_train_bf16_at_the_benchmark_shape_tracks_the_reference(golden, tmp_path
     err = rel_err(summarise(ordered)[1], data[f"{name}@f64/final_sample"])
     print(f"bf16 final state vs the reference's float64 run: {err:.2e}")
     assert err < 2e-3
+
+
+def test_train_bf16_chunks_of_125_at_the_benchmark_shape_track_the_reference(golden, tmp_path):
+    """bench.py's configs.k400 arithmetic (bf16, chunks of 125 images stored padded to 128, 32 x 32) against a run of the REFERENCE: `fb_real_k125`
+    (4 chunks of 125, clip + warm-up, 2 steps; tests/golden/make_golden.py --r3b).  Four chunks average less bf16 noise away than the eight of
+    `fb_real_clip`: gradient norms to 0.1, losses and parameter norms to 5e-3 / 1e-3, accuracy to two predictions."""
+    data, meta = golden
+    name = "fb_real_k125"
+    cfg, model, stats = _run(meta, name, ["impl.mixed_precision=True", "impl.engine.chunk_group=3"], tmp_path)
+    for key, tol in (("train_loss", 5e-3), ("full_loss", 5e-3), ("param_norm", 1e-3), ("grad_norm", 0.1), ("preclip_gradnorm", 0.15)):
+        r64 = data[f"{name}@f64/stat/{key}"]
+        print(f"bf16 k125 {key}: engine {np.array(stats[key])} ref64 {r64}")
+        assert np.allclose(stats[key], r64, rtol=tol), key
+    assert np.all(np.abs(np.array(stats["train_acc"]) - data[f"{name}@f64/stat/train_acc"]) <= 2.0 / 500 + 1e-9)
+    assert stats["clipped_step"] == list(data[f"{name}@f64/stat/clipped_step"])
 
 
 @pytest.mark.parametrize("mixed", [False, True])
