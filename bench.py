@@ -460,7 +460,9 @@ def main():
         if share:
             torch.distributed.init_process_group("gloo")
         else:
-            torch.distributed.init_process_group("nccl", device_id=device)
+            import datetime
+            # (a collective that never completes fails the run after five minutes instead of holding the node for the default ten-minute watchdog + retries)
+            torch.distributed.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=300))
 
     from fullbatchtraining_amd import lib
     from fullbatchtraining_amd.cfg import compose
