@@ -4,7 +4,8 @@ ALL chunks (390 x 128 = 49 920 images, the reference's drop_last behaviour) + cl
 
     python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-Prints ONE JSON line (rank 0): whole-job images/s (value), steps/s, ms/step, plus
+Prints ONE JSON line (rank 0, < 4 KB; tables, notes and sources go to gpurun_out/bench_detail.json): whole-job images/s (value), steps/s,
+ms/step, plus
   roofline     : dominant MFMA kernel class -- algorithmic FLOP per launch / mean launch duration measured with HIP events on
                  the launch stream inside the timed region (libfbengine's fb_profile_*), against the dense bf16 MFMA peak
   cpu_baseline : the CPU oracle (restatement of the reference path, oracle/fb_oracle.py) timed on this box's host cores on a
@@ -44,7 +45,7 @@ def conv_flops(plan, n_img):
 def cpu_baseline(budget_s=24.0):
     """The CPU restatement of the reference path (oracle/fb_oracle.py, pinned to reference runs in tests/) timed on this box's host
     cores: fp32, chunks of 128 images, gradient through torch autograd (the way the reference computes it, training.py:76-83 -- the
-    explicit-backward form is slower on CPU).  Thread counts 8 / 16 / 32 / 64 / all are probed on one chunk each, the best one is then
+    explicit-backward form is slower on CPU).  Thread counts 8 / 16 / 32 are probed on one chunk each, the best one is then
     timed on a bounded sample with the regulariser off and on.  SURVEY section 6 measured the REAL reference in the build container at
     ~122 images/s (8 threads, grad_reg off) / ~50 images/s (on)."""
     from fullbatchtraining_amd.cfg import compose
@@ -70,7 +71,7 @@ def cpu_baseline(budget_s=24.0):
     avail = os.cpu_count() or 8
     probe = {}
     saved = torch.get_num_threads()
-    for t in sorted({min(c, avail) for c in (8, 16, 32, 64, avail)}):
+    for t in sorted({min(c, avail) for c in (8, 16, 32)}):          # (more threads only lose: 64: 64 img/s, 256: 1 img/s on the r3 box -- minutes of probing)
         torch.set_num_threads(t)
         one(0, False)                                   # warm-up at this thread count
         t0 = time.perf_counter()
@@ -89,6 +90,7 @@ def cpu_baseline(budget_s=24.0):
     torch.set_num_threads(saved)
     (k0, d0), (k1, d1) = out[False], out[True]
     return {"value": round(k0 * CHUNK / d0, 2), "unit": "images/s", "cores": best, "kind": "port",
+            "sample_short": f"{k0} chunks x {CHUNK} images fwd+bwd fp32 oracle (torch autograd), {d0:.1f} s",
             "sample": f"{k0} chunks of {CHUNK} images, fwd+bwd via torch autograd of the fp32 oracle forward, grad_reg off, {d0:.1f} s "
                       f"(one full step = 390 chunks ~ {390 * d0 / k0:.0f} s); thread sweep on one chunk each: "
                       + ", ".join(f"{t}: {v:.0f} img/s" for t, v in probe.items()),
@@ -347,31 +349,38 @@ def roofline_objects(args, trainer, launches, launches_iso, sec_per_step, world,
     table = iso or in_region
     conv_rows = [r for r in table if r["flop_per_launch"] > 0]
     flop_img = 3328997376 if headline else sum(conv_flops(eng.plan, 1).values())
-    out = {"roofline": {
+    # fp32 storage: a product costs 6 (bf16x6) / 3 (f16x2) 16-bit MFMAs -- `achieved` / `frac` are ALGORITHMIC FLOP over the bf16 peak, and
+    # `mfma_per_product` says how many executed MFMAs stand behind one of them
+    per_product = 1 if trainer.dtype == torch.bfloat16 else (3 if eng.f32_split == "f16x2" else 6)
+    line = {"roofline": {
         "bound": "mfma", "kernel": dom, "achieved": k_in[dom]["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": k_in[dom]["frac_mfma"],
-        "traffic": traffic_of(dom), "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": ("profiles/hbm_traffic.json: " + pmc["command"]) if pmc else None,
-        "flop_per_launch": k_in[dom]["flop_per_launch"], "avg_launch_us": k_in[dom]["avg_launch_us"], "launches_per_step": k_in[dom]["launches_per_step"],
-        "algorithmic_bytes_per_launch": k_in[dom]["bytes_per_launch"],
+        "traffic": traffic_of(dom), "algorithmic_bytes_per_launch": k_in[dom]["bytes_per_launch"], "flop_per_launch": k_in[dom]["flop_per_launch"],
+        "avg_launch_us": k_in[dom]["avg_launch_us"], "launches_per_step": k_in[dom]["launches_per_step"], "mfma_per_product": per_product,
+        "frac_isolated": k_iso[dom]["frac_mfma"] if k_iso else None,
+        "step_mfma_frac": round(flop_img * passes * trainer.datapoints / sec_per_step / world / (PEAK_BF16_TFLOPS * 1e12), 4)}}
+    detail = {"roofline": {
+        "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": ("profiles/hbm_traffic.json: " + pmc["command"]) if pmc else None,
         "measured": "HIP events on the launch stream around every launch, over a repetition of the timed steps in the production schedule (weight-gradient "
                     "kernels on a second stream beside these launches); `isolated` = one more step with one stream: every kernel alone on the device",
-        "achieved_isolated": k_iso[dom]["tflops"] if k_iso else None, "frac_isolated": k_iso[dom]["frac_mfma"] if k_iso else None,
-        "step_mfma_frac": round(flop_img * passes * trainer.datapoints / sec_per_step / world / (PEAK_BF16_TFLOPS * 1e12), 4),
+        "achieved_isolated": k_iso[dom]["tflops"] if k_iso else None,
         "per_kernel": {k: {f: v[f] for f in ("ms_per_step", "launches_per_step", "avg_launch_us", "tflops", "frac_mfma", "gbs_algorithmic", "frac_hbm")} for k, v in basis.items()},
         "per_kernel_in_region": {k: {f: v[f] for f in ("ms_per_step", "tflops", "frac_mfma")} for k, v in k_in.items() if v["flop_per_launch"] > 0},
         "worst_mfma_launch": worst(conv_rows, "frac_mfma"),
         "worst_launch_vs_both_ceilings": worst([dict(r, best=max(r["frac_mfma"], r["frac_hbm"])) for r in conv_rows], "best"),
         "per_shape": [{k: r[k] for k in ("kernel", "class", "shape", "launches_per_step", "ms_per_step", "avg_launch_us", "tflops", "gbs_algorithmic", "frac_mfma", "frac_hbm")}
-                      for r in table[:48]]}}
+                      for r in table]}}
     if dom_h is not None:
-        out["roofline_hbm"] = {"bound": "hbm", "kernel": dom_h, "achieved": k_in[dom_h]["gbs_algorithmic"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                               "frac": k_in[dom_h]["frac_hbm"], "achievable": 6290.0, "frac_of_achievable": round(k_in[dom_h]["gbs_algorithmic"] / 6290.0, 4),
-                               "traffic": traffic_of(dom_h), "algorithmic_bytes_per_launch": k_in[dom_h]["bytes_per_launch"], "avg_launch_us": k_in[dom_h]["avg_launch_us"],
-                               "achieved_isolated": k_iso[dom_h]["gbs_algorithmic"] if k_iso else None}
+        line["roofline_hbm"] = {"bound": "hbm", "kernel": dom_h, "achieved": k_in[dom_h]["gbs_algorithmic"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                "frac": k_in[dom_h]["frac_hbm"], "traffic": traffic_of(dom_h), "algorithmic_bytes_per_launch": k_in[dom_h]["bytes_per_launch"],
+                                "avg_launch_us": k_in[dom_h]["avg_launch_us"], "frac_of_achievable_6290": round(k_in[dom_h]["gbs_algorithmic"] / 6290.0, 4)}
+        detail["roofline_hbm"] = {"achieved_isolated": k_iso[dom_h]["gbs_algorithmic"] if k_iso else None}
     if pmc is not None:
         total = pmc["total_bytes_per_step"]
-        out["hbm"] = {"bytes_per_step": total, "tb_per_s": round(total / sec_per_step / 1e12, 3), "peak_tb_per_s": PEAK_HBM_GBS / 1e3,
-                      "frac": round(total / sec_per_step / 1e9 / PEAK_HBM_GBS, 4), "source": "profiles/hbm_traffic.json: " + pmc["command"],
-                      "by_kernel_gb_per_step": {k: round(v["bytes_per_launch"] * v["launches"] / 1e9, 2) for k, v in sorted(pmc["kernels"].items(), key=lambda kv: -kv[1]["bytes_per_launch"] * kv[1]["launches"])[:12]}}
+        # (PMC bytes come from the committed rocprofv3 passes -- counters cannot be read from inside this process; the division by THIS run's step time is live)
+        line["hbm"] = {"bytes_per_step": total, "tb_per_s": round(total / sec_per_step / 1e12, 3), "frac": round(total / sec_per_step / 1e9 / PEAK_HBM_GBS, 4),
+                       "source": "profiles/hbm_traffic.json"}
+        detail["hbm"] = {"source": "profiles/hbm_traffic.json: " + pmc["command"], "peak_tb_per_s": PEAK_HBM_GBS / 1e3,
+                         "by_kernel_gb_per_step": {k: round(v["bytes_per_launch"] * v["launches"] / 1e9, 2) for k, v in sorted(pmc["kernels"].items(), key=lambda kv: -kv[1]["bytes_per_launch"] * kv[1]["launches"])}}
     if profiled:            # MFMA utilisation from the hardware counters (tools/pmc_mfma.sh), quoted next to the algorithmic fraction when the file is there
         path = os.path.join(ROOT, "profiles", "mfma_util.json")
         if os.path.isfile(path):
@@ -379,14 +388,73 @@ def roofline_objects(args, trainer, launches, launches_iso, sec_per_step, world,
                 mu = json.load(handle)
             hits = [v for k, v in mu["kernels"].items() if dom in k]
             w = sum(v["ms_per_step"] for v in hits)
-            out["mfma_util_pmc"] = {
-                "step_serialized": round(mu["mfma_util"], 4), "step_frac_of_peak_over_kernel_time": round(mu["frac_of_2p5_pflops_over_kernel_time"], 4),
-                "executed_mfma_tflop_per_step": round(mu["executed_mfma_tflop_per_step"], 2),
-                "algorithmic_tflop_per_step": round(flop_img * passes * trainer.datapoints / 1e12, 2),
-                "dominant_kernel": round(sum(v["mfma_util"] * v["ms_per_step"] for v in hits) / w, 4) if w else None,
-                "source": "profiles/mfma_util.json: " + mu["command"],
-                "note": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), kernels one at a time"}
-    return out
+            line["mfma_util_pmc"] = {"step": round(mu["mfma_util"], 4), "dominant_kernel": round(sum(v["mfma_util"] * v["ms_per_step"] for v in hits) / w, 4) if w else None,
+                                     "executed_mfma_tflop_per_step": round(mu["executed_mfma_tflop_per_step"], 2), "source": "profiles/mfma_util.json"}
+            detail["mfma_util_pmc"] = {"step_frac_of_peak_over_kernel_time": round(mu["frac_of_2p5_pflops_over_kernel_time"], 4),
+                                       "algorithmic_tflop_per_step": round(flop_img * passes * trainer.datapoints / 1e12, 2),
+                                       "source": "profiles/mfma_util.json: " + mu["command"],
+                                       "note": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), kernels one at a time"}
+    return line, detail
+
+
+MAX_LINE_BYTES = 4096
+
+
+def compact_side(side):
+    """The numbers of side_configs() that go into the one JSON line (everything else: bench_detail.json)."""
+    keep = ("value", "unit", "ms_per_step", "dtype", "steps", "arithmetic")
+    configs = {}
+    for name, c in side["configs"].items():
+        configs[name] = {k: c[k] for k in keep if k in c}
+        if "roofline" in c:
+            configs[name]["roofline"] = {k: c["roofline"][k] for k in ("bound", "achieved", "peak", "frac", "mfma_per_product")}
+    parity = {}
+    for name, p in side["parity"].items():
+        if "bit_identical" in p:
+            parity[name] = p["bit_identical"]
+        elif "rel_l2" in p:
+            parity[name] = {k: p[k] for k in ("rel_l2", "cosine", "chunks")}
+        else:
+            parity[name] = {k: v["bit_identical"] for k, v in p.items()}
+    return {"configs": configs, "parity": parity}
+
+
+def compact_cpu_baseline(cpu):
+    return {"value": cpu["value"], "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"], "sample": cpu["sample_short"],
+            "grad_reg_on": {"value": cpu["grad_reg_on"]["value"]}}
+
+
+DETAIL_PATH = os.path.join("gpurun_out", "bench_detail.json")
+
+
+def write_detail(detail):
+    """Per-shape / per-kernel tables, notes and sources: a file next to the run, named in the line."""
+    path = os.path.join(ROOT, DETAIL_PATH)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as handle:
+        json.dump(detail, handle, indent=1)
+
+
+def assemble_line(base, extra, roof=None, side=None, cpu=None):
+    """(the ONE JSON line rank 0 prints, the detail document).  ``roof`` = roofline_objects(), ``side`` = side_configs(), ``cpu`` =
+    cpu_baseline().  The driver parses the last stdout line out of a bounded tail: a line above MAX_LINE_BYTES is an error here, not there."""
+    out, detail = dict(base), dict(base, **extra)
+    if roof is not None:
+        line_part, detail_part = roof
+        out.update(line_part)
+        for k, v in line_part.items():
+            detail[k] = dict(v, **detail_part.get(k, {}))
+    if side is not None:
+        detail.update(side)
+        out.update(compact_side(side))
+    if cpu is not None:
+        detail["cpu_baseline"] = cpu
+        out["cpu_baseline"] = compact_cpu_baseline(cpu)
+    out["detail"] = DETAIL_PATH
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) > MAX_LINE_BYTES:
+        raise RuntimeError(f"bench line is {len(line)} bytes (> {MAX_LINE_BYTES}); move fields to {DETAIL_PATH}")
+    return line, detail
 
 
 def self_launch(n_gpus):
@@ -558,24 +626,28 @@ def main():
             "vs_baseline": None, "dtype": "bf16" if trainer.dtype == torch.bfloat16 else ("f32" if eng.f32_split != "f16x2" else "f32-22bit"), "data": "synthetic",
             "config": {"workload": f"{'ResNet-18 CIFAR-10' if headline else args.model + ' ' + str(args.pixels) + 'px'} full-batch GD step, {trainer.n_chunks} chunks x {trainer.chunk} = {images_per_step} "
                                    f"images/step (drop_last), grad_reg block_strength={args.grad_reg}, fp32 master/accumulate",
-                       "chunk_group": eng.G, "parallelism": f"dp{world} (contiguous chunk ranges, reduce-scatter + all-gather)",
-                       "launches": "native command lists (one host call per chunk group)" if eng.use_replay else "one ctypes call per launch (FB_REPLAY=0)"},
+                       "chunk_group": eng.G, "parallelism": f"dp{world} (contiguous chunk ranges, reduce-scatter + all-gather)"},
             "train_loss_last": loss_last,
             # host time from the start of a step until its last kernel is queued (mean over the timed steps): launch overhead that the
             # GPU hides as long as it stays below ms_per_step
             "host_enqueue_ms_per_step": enqueue_ms,
-            "outside_the_step": "the dataset is resident in HBM and the stem's im2col patches (fb_stem_patches, 3.3 GB bf16, ~3 ms) are "
-                                "gathered once before the timed region (static, un-augmented dataset); inside: weight prep, all chunk "
-                                "forward/backward passes, running mean, clip + SGD update, statistics read-back",
         }
+        extra = {"config": dict(out["config"], launches="native command lists (one host call per chunk group)" if eng.use_replay else "one ctypes call per launch (FB_REPLAY=0)"),
+                 "outside_the_step": "the dataset is resident in HBM and the stem's im2col patches (fb_stem_patches, 3.3 GB bf16, ~3 ms) are gathered once before the "
+                                     "timed region (static, un-augmented dataset); inside: weight prep, all chunk forward/backward passes, running mean, clip + SGD "
+                                     "update, statistics read-back"}
+        roof = side = cpu = None
         if launches is not None:
             out["ms_per_step_with_kernel_events"] = round(1000 * elapsed_ev / args.steps, 2)
-            out.update(roofline_objects(args, trainer, launches, launches_iso, elapsed / args.steps, world, headline, passes))
+            roof = roofline_objects(args, trainer, launches, launches_iso, elapsed / args.steps, world, headline, passes)
         if world == 1 and headline and args.grad_reg == 0 and trainer.dtype == torch.bfloat16 and not args.no_side_configs:
-            out.update(side_configs(args, device, X, Y, trainer))
+            side = side_configs(args, device, X, Y, trainer)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+            cpu = cpu_baseline()
+        line, detail = assemble_line(out, extra, roof, side, cpu)
+        write_detail(detail)
+        sys.stdout.flush()
+        print(line, flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -80,6 +80,7 @@ extern "C" int32_t fb_event_new(void) {
     g_events.push_back(e);
     return (int32_t)g_events.size() - 1;
 }
+extern "C" int32_t fb_event_count(void) { return (int32_t)g_events.size(); }
 extern "C" int fb_event_record(int32_t ev, void* stream) {
     if (ev < 0 || ev >= (int32_t)g_events.size()) FB_FAIL(FB_ERR_ARG, "fb_event_record: unknown event %d", ev);
     if (hipEventRecord(g_events[ev], (hipStream_t)stream) != hipSuccess) FB_FAIL(FB_ERR_LAUNCH, "fb_event_record: hipEventRecord failed");

@@ -58,7 +58,7 @@ class Block:
         self.convs, self.shortcut, self.stride, self.cin, self.hin, self.win = convs, shortcut, stride, cin, hin, win
 
 
-def max_group(plan, chunk, dtype):
+def max_group(plan, chunk, dtype, device=None):
     """Largest chunk group the fast kernels take.  fp32 storage: the biggest activation tensor (NHWC) stays below 2^31 bytes -- the fp32 LDS-DMA
     kernels address whole tensors with 32-bit buffer offsets and hand larger ones to the slower pointer-based kernels.  bf16: every kernel
     bases its descriptors at its own tile / K slice (round 3), so only a sanity limit of 2^35 bytes per tensor remains (the persistent
@@ -75,7 +75,8 @@ def max_group(plan, chunk, dtype):
     # gradients, patches, other engines)
     acts = sum(2 * L.hout * L.wout * L.cout for L in plan.layers) + sum(b.convs[-1].hout * b.convs[-1].wout * b.convs[-1].cout for b in plan.blocks)
     per_image_bytes = (acts * 17 // 16 + 8 * per_image) * es
-    total = torch.cuda.get_device_properties(0).total_memory if torch.cuda.is_available() else 288 << 30
+    # (the engine's OWN device: ranks other than local rank 0, heterogeneous boxes)
+    total = torch.cuda.get_device_properties(torch.device(device if device is not None else "cuda")).total_memory if torch.cuda.is_available() else 288 << 30
     return max(cap31, min((1 << 35) // (chunk * per_image * es), (total // 3) // (chunk * per_image_bytes)))
 
 
@@ -183,15 +184,20 @@ def stem_patches(x_nchw, layer, dtype, aug=None, out=None):
 class _Events:
     """Cross-stream ordering through the library's event table (``fb_event_*``): the same events order eager launches and the launches
     of replayed command lists.  Eager code draws ids from a ring (re-recording an event whose waits have been issued is safe: a wait
-    binds to the record that precedes it in host order); a recording gets fresh ids that stay with its list."""
+    binds to the record that precedes it in host order); a recording gets ids of its own that stay with its list -- fresh ones, or the
+    ids of lists the engine has dropped (``release``): library events live as long as the process, so they are reused, never leaked."""
     RING = 1024
 
     def __init__(self):
-        self.ring, self.pos = [], 0
+        self.ring, self.pos, self.free = [], 0, []
+
+    def release(self, ids):
+        self.free.extend(ids)
 
     def record(self, stream=None):
         if lib.recording():
-            ev = lib.event_new()
+            ev = self.free.pop() if self.free else lib.event_new()
+            lib.current_recorder().events.append(ev)
         elif len(self.ring) < self.RING:
             ev = lib.event_new()
             self.ring.append(ev)
@@ -314,7 +320,8 @@ class Engine:
         # native launch executor (csrc/cmdlist.cpp): the launches of one chunk group's forward + backward (and of the weight preparation) are a
         # static sequence -- recorded the first time, replayed with one host call afterwards (FB_REPLAY=0: every launch through ctypes)
         self.use_replay = os.environ.get("FB_REPLAY", "1") != "0"
-        self.cmdlists, self.replays, self.MAX_CMDLISTS = {}, 0, 96
+        self.cmdlists, self.replays, self.MAX_CMDLISTS = {}, 0, int(os.environ.get("FB_MAX_CMDLISTS", "256"))
+        self.cmd_evictions, self.record_new = 0, True
         self.masks = {}
         self.fuse_bwd_stat = os.environ.get("FB_FUSED_BWD_STAT", "0") != "0"     # BN-backward reduction in the input-gradient epilogues: built, parity-tested,
         # measured SLOWER at step level (profiles/r2_notes.md: the separate HBM-bound reduction overlaps the weight-gradient stream) -> off
@@ -842,13 +849,25 @@ class Engine:
         if not self.use_replay:
             return body()
         streams = [torch.cuda.current_stream(), self.wstream]
-        cl = self.cmdlists.get(key)
+        # (the list holds stream INDICES: a list recorded with a weight-gradient stream must not be replayed without one, or on another pair)
+        key = key + (streams[0].cuda_stream, None if self.wstream is None else self.wstream.cuda_stream)
+        cl = self.cmdlists.pop(key, None)
         if cl is not None:
+            self.cmdlists[key] = cl                      # most recently used last
             cl.replay(streams)
             self.replays += 1
             return
-        if len(self.cmdlists) >= self.MAX_CMDLISTS:      # (keys that never repeat, e.g. a dataset re-gathered into new buffers every step)
-            self.cmdlists.pop(next(iter(self.cmdlists)))
+        if not self.record_new:
+            return body()
+        if len(self.cmdlists) >= self.MAX_CMDLISTS:
+            # Keys that never repeat (buffers re-allocated every step) or a working set beyond the cache: the least recently used list goes, its
+            # event ids are handed to the next recordings -- and once a whole cache worth of lists has been dropped recording stops paying
+            # (cyclic access over more keys than slots misses every time): misses run through the interpreter from then on, hits still replay
+            old = self.cmdlists.pop(next(iter(self.cmdlists)))
+            self.events.release(old.events)
+            self.cmd_evictions += 1
+            if self.cmd_evictions >= self.MAX_CMDLISTS:
+                self.record_new = False
         with lib.Recorder(streams) as rec:
             body()
         self.cmdlists[key] = rec.finish()

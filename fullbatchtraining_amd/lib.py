@@ -80,7 +80,7 @@ _SIGS = {
 }
 EXPORTS = tuple(_SIGS) + ("fb_last_error_string", "fb_abi_version", "fb_profile_enable", "fb_profile_read", "fb_ws_conv_stat_floats",
                           "fb_ws_wgrad_slab_floats", "fb_ws_bn_partial_floats", "fb_ws_mt_floats", "fb_bn_bwd_reduce_rows", "fb_conv_masked_addend_supported", "fb_conv_bwd_stat_supported",
-                          "fb_bn_apply_can_pool", "fb_ws_bn_amax_floats", "fb_profile_read_launches", "fb_cmd_fn_id", "fb_cmd_fn_nargs", "fb_event_new",
+                          "fb_bn_apply_can_pool", "fb_ws_bn_amax_floats", "fb_profile_read_launches", "fb_cmd_fn_id", "fb_cmd_fn_nargs", "fb_event_new", "fb_event_count",
                           "fb_event_record", "fb_event_wait", "fb_cmdlist_create", "fb_cmdlist_destroy", "fb_cmdlist_size", "fb_cmdlist_add_call",
                           "fb_cmdlist_add_event", "fb_cmdlist_replay")
 PROF_CLASSES = ("igemm_fwd", "igemm_dgrad", "wgrad", "bn_apply", "bn_bwd_reduce", "bn_bwd_apply")
@@ -157,6 +157,7 @@ def load():
         lib.fb_cmd_fn_id.argtypes, lib.fb_cmd_fn_id.restype = [C.c_char_p], c_int
         lib.fb_cmd_fn_nargs.argtypes, lib.fb_cmd_fn_nargs.restype = [c_int], c_int
         lib.fb_event_new.argtypes, lib.fb_event_new.restype = [], c_int
+        lib.fb_event_count.argtypes, lib.fb_event_count.restype = [], c_int
         lib.fb_event_record.argtypes, lib.fb_event_record.restype = [c_int, c_void_p], c_int
         lib.fb_event_wait.argtypes, lib.fb_event_wait.restype = [c_int, c_void_p], c_int
         lib.fb_cmdlist_create.argtypes, lib.fb_cmdlist_create.restype = [], c_void_p
@@ -203,6 +204,10 @@ def recording():
     return _recorder is not None
 
 
+def current_recorder():
+    return _recorder
+
+
 def _check(status, what):
     if status != 0:
         raise EngineError(f"{what} failed ({status}): {load().fb_last_error_string().decode()}")
@@ -213,6 +218,10 @@ def event_new():
     if ev < 0:
         raise EngineError(load().fb_last_error_string().decode())
     return ev
+
+
+def event_count():
+    return int(load().fb_event_count())
 
 
 def event_record(ev, stream=None):
@@ -255,14 +264,17 @@ def _pack_words(name, args):
 class CommandList:
     """A recorded sequence of library calls and event operations (``Recorder``); ``replay`` issues it natively."""
 
-    def __init__(self, handle, n_streams, keep):
-        self.handle, self.n_streams, self.keep = handle, n_streams, keep
+    def __init__(self, handle, n_streams, keep, events=()):
+        self.handle, self.n_streams, self.keep, self.events = handle, n_streams, keep, list(events)     # events: the ids recorded INTO this list
+        self.used_streams = frozenset()
 
     def __len__(self):
         return int(load().fb_cmdlist_size(self.handle))
 
     def replay(self, streams):
         """``streams``: torch streams in the order the recorder was given them (None entries are allowed where the recording did not use them)."""
+        if any(s is None and i in self.used_streams for i, s in enumerate(streams)):
+            raise EngineError("CommandList.replay: the list has commands for a stream index that is None now")
         arr = (c_void_p * self.n_streams)(*[None if s is None else s.cuda_stream for s in streams])
         _check(load().fb_cmdlist_replay(self.handle, arr, self.n_streams), "fb_cmdlist_replay")
 
@@ -285,6 +297,7 @@ class Recorder:
         self.handles = [None if s is None else s.cuda_stream for s in self.streams]
         self.handle = load().fb_cmdlist_create()
         self.kept = []
+        self.events, self.used = [], set()
         self._fn_ids = {}
 
     def __enter__(self):
@@ -318,14 +331,17 @@ class Recorder:
             if fn < 0:
                 raise EngineError(f"Recorder: {name} cannot be part of a command list")
         words, blob = _pack_words(name, args)
+        self.used.add(self._stream_index(st))
         _check(load().fb_cmdlist_add_call(self.handle, fn, words, len(words), self._stream_index(st), C.addressof(blob) if blob is not None else None,
                                           C.sizeof(blob) if blob is not None else 0), "fb_cmdlist_add_call")
 
     def add_event(self, kind, ev, st):
+        self.used.add(self._stream_index(st))
         _check(load().fb_cmdlist_add_event(self.handle, kind, ev, self._stream_index(st)), "fb_cmdlist_add_event")
 
     def finish(self):
-        out = CommandList(self.handle, len(self.streams), self.kept)
+        out = CommandList(self.handle, len(self.streams), self.kept, self.events)
+        out.used_streams = frozenset(self.used)
         self.handle = None
         return out
 

@@ -405,6 +405,12 @@ class FullBatchTrainer:
         self.cfg, self.model = cfg, model
         self.device = torch.device(setup["device"]) if not isinstance(setup["device"], torch.device) else setup["device"]
         self.optimizer, self.scheduler = optim_interface(model, cfg.hyp)
+        # the engine applies the update on its arena (fb_mt_clip_sgd); the torch optimizer is the state container the checkpoint layout wants.
+        # Tell the scheduler that updates do happen, or it warns "lr_scheduler.step() before optimizer.step()" on its first step
+        opt = self.optimizer
+        while opt is not None:
+            opt._opt_called = True
+            opt = getattr(opt, "optim", None) or getattr(opt, "base_optimizer", None)
         self.loss_fn = get_loss_fn(cfg.hyp, cfg.data.batch_size)
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
         self.rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
@@ -442,7 +448,7 @@ class FullBatchTrainer:
         # chunk sizes that do not fill whole 128-pixel statistics blocks (data.batch_size=125: all 50 000 images in 400 chunks,
         # reference data_preparation.py:64-72) are stored padded with zero images (label -1)
         self.chunk_pad = padded_chunk(plan, self.chunk)
-        want, cap = int(cfg.impl.get("engine", {}).get("chunk_group", 98)), max_group(plan, self.chunk_pad, self.dtype)
+        want, cap = int(cfg.impl.get("engine", {}).get("chunk_group", 98)), max_group(plan, self.chunk_pad, self.dtype, self.device)
         G = group_size(self.shard.count, want, cap=cap)
         # K-slice counts of the weight gradients are sized for the group of the WHOLE problem on one GPU -- the same number on every rank, so
         # that a chunk's summation order (hence its gradient, bit for bit) does not depend on the number of GPUs
@@ -639,7 +645,8 @@ class FullBatchTrainer:
         mine = idx[lo:hi]
         if hi > lo:
             self._gather_patches(self._all_images.index_select(0, mine))
-            self.labels = self._pad_labels(self._all_labels.index_select(0, mine))
+            # (into the resident buffer: the recorded launches of a chunk group are keyed by -- and hold -- its address)
+            self.labels.copy_(self._pad_labels(self._all_labels.index_select(0, mine)))
 
     def _regather_augmented(self):
         """A fresh RandomCrop offset / flip per image and step (the reference draws them in its DataLoader workers once per epoch =

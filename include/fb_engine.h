@@ -61,6 +61,7 @@ int64_t fb_profile_read_launches(int32_t* info, float* ms, int64_t cap);
 int32_t fb_cmd_fn_id(const char* name);          /* -1: this entry point cannot be recorded */
 int32_t fb_cmd_fn_nargs(int32_t fn);             /* arguments including the stream */
 int32_t fb_event_new(void);                      /* -1 on failure */
+int32_t fb_event_count(void);                    /* events created so far (they live as long as the process: hosts REUSE the ids of lists they drop) */
 int fb_event_record(int32_t ev, void* stream);
 int fb_event_wait(int32_t ev, void* stream);
 void* fb_cmdlist_create(void);

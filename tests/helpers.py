@@ -121,3 +121,34 @@ class DictLMDB:
     @classmethod
     def open(cls, path, **kwargs):
         return cls(cls._stores.setdefault(str(path), {}))
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+PG_TIMEOUT_S = 120       # every process group of the tests: a collective that never completes fails after two minutes, not thirty
+
+
+def pg_timeout():
+    import datetime
+    return datetime.timedelta(seconds=PG_TIMEOUT_S)
+
+
+def spawn_bounded(fn, args, nprocs, timeout=150.0):
+    """``torch.multiprocessing.spawn(fn, args, nprocs)`` with a wall-clock cap: the ranks are fresh `spawn` children (never a re-exec of a
+    process that touched the GPU); the parent polls them, and when the cap passes it KILLS every child that is still alive and fails the
+    calling test.  An exception in a rank surfaces as torch's ProcessRaisedException, as with ``join=True``."""
+    import time
+
+    import torch.multiprocessing as mp
+
+    ctx = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
+    deadline = time.monotonic() + timeout
+    try:
+        while not ctx.join(timeout=2.0):
+            if time.monotonic() > deadline:
+                raise TimeoutError(f"{getattr(fn, '__name__', fn)} with {nprocs} rank(s) still running after {timeout:.0f} s: ranks killed")
+    finally:
+        for proc in ctx.processes:
+            if proc.is_alive():
+                proc.kill()
+        for proc in ctx.processes:
+            proc.join(10)

@@ -275,7 +275,8 @@ def _worker(rank, world, port, K, P, out_dir, bucketed=False):
     from fullbatchtraining_amd.parallel import (ShardOps, ShardPlan, all_gather_chunk_stats, combine_running_stats,
                                                 reduce_scatter_update_all_gather)
 
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    from tests.helpers import pg_timeout
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, timeout=pg_timeout())
     torch.manual_seed(0)                      # identical "dataset" on every rank
     g = torch.randn(K, P)                     # per-chunk (regularised) gradients
     theta = torch.randn(P)
@@ -334,7 +335,8 @@ def test_sharded_step_matches_single_process(tmp_path, bucketed, K, world):
 
     P = 64 * 6
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, K, P, str(tmp_path), bucketed), nprocs=world, join=True)
+    from tests.helpers import spawn_bounded
+    spawn_bounded(_worker, (world, port, K, P, str(tmp_path), bucketed), world, timeout=180)
     torch.manual_seed(0)
     g, theta, mom, stats = torch.randn(K, P), torch.randn(P), torch.randn(P) * 0.1, torch.rand(K)
     bn_mean = torch.randn(K, 2, 5)
@@ -359,3 +361,42 @@ def test_sharded_step_matches_single_process(tmp_path, bucketed, K, world):
             assert torch.allclose(o["mom_shard"][lo:lo + n], momentum[0][lo:lo + n], rtol=1e-5, atol=1e-6)
     for o in outs[1:]:
         assert torch.equal(outs[0]["theta"], o["theta"])
+
+
+def test_bench_line_stays_below_4k_on_a_canned_run():
+    """The driver parses the LAST stdout line of bench.py out of a bounded tail (round 3's 23 KB line came back ``parsed: null``): the line is
+    assembled by bench.assemble_line, which keeps numbers only and moves tables / notes / sources to gpurun_out/bench_detail.json.  Canned input:
+    round 3's full line (profiles/r3_final_bench_line.json) split back into the objects bench.py hands to the assembler."""
+    import json
+
+    import bench
+
+    with open(os.path.join(REPO, "profiles", "r3_final_bench_line.json")) as handle:
+        full = json.load(handle)
+    base = {k: full[k] for k in ("metric", "value", "unit", "steps_per_sec", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                 "dtype", "data", "train_loss_last", "host_enqueue_ms_per_step", "ms_per_step_with_kernel_events")}
+    base["config"] = {k: full["config"][k] for k in ("workload", "chunk_group", "parallelism")}
+    line_keys = {"roofline": ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "flop_per_launch", "avg_launch_us",
+                              "launches_per_step", "frac_isolated", "step_mfma_frac"),
+                 "roofline_hbm": ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_us")}
+    line_part = {name: {k: full[name][k] for k in keys} for name, keys in line_keys.items()}
+    line_part["roofline"]["mfma_per_product"] = 1
+    line_part["hbm"] = {"bytes_per_step": full["hbm"]["bytes_per_step"], "tb_per_s": full["hbm"]["tb_per_s"], "frac": full["hbm"]["frac"], "source": "profiles/hbm_traffic.json"}
+    line_part["mfma_util_pmc"] = {"step": 0.4012, "dominant_kernel": 0.5123, "executed_mfma_tflop_per_step": 166.25, "source": "profiles/mfma_util.json"}
+    detail_part = {"roofline": {k: v for k, v in full["roofline"].items() if k not in line_keys["roofline"]}}
+    side = {"configs": full["configs"], "parity": full["parity"]}
+    cpu = dict(full["cpu_baseline"], sample_short="17 chunks x 128 images fwd+bwd fp32 oracle (torch autograd), 12.3 s")
+    line, detail = bench.assemble_line(base, {"outside_the_step": full["outside_the_step"]}, (line_part, detail_part), side, cpu)
+    assert len(line) < 4096 and "\n" not in line, len(line)
+    out = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in out, key
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(out["roofline"])
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(out["cpu_baseline"])
+    assert out["detail"] == bench.DETAIL_PATH and "model" not in out["config"]
+    assert set(out["configs"]) == set(full["configs"]) and out["parity"]["two_streams_vs_one"] is True
+    # nothing is lost: the tables live in the detail document
+    assert len(detail["roofline"]["per_shape"]) == len(full["roofline"]["per_shape"]) and "note" in detail["parity"]["bf16_vs_f32"]
+    # and a line that would not fit is refused by the assembler itself
+    with pytest.raises(RuntimeError, match="bench line is"):
+        bench.assemble_line(dict(base, padding="x" * 4096), {}, (line_part, detail_part), side, cpu)

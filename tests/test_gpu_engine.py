@@ -341,6 +341,59 @@ def test_replayed_command_lists_equal_interpreted_launches(dtype, fd, monkeypatc
     assert a[5] == b[5]
 
 
+def test_command_list_cache_is_bounded_and_stops_recording_when_it_thrashes(monkeypatch):
+    """More (group, pass) keys than the cache holds, visited cyclically -- the shape of ResNet-152 with the regulariser on one GPU (~196 keys), or
+    of a feed that re-allocates its buffers every step: the least recently used list is dropped, its library events are REUSED by the next
+    recording (the process-wide event table stops growing), after one cache worth of evictions the engine stops recording (misses go through
+    the interpreter, hits still replay), and the arithmetic is bit-identical to the interpreted launches throughout."""
+    from fullbatchtraining_amd import lib
+    pixels, chunk, G, n_chunks = 16, 32, 1, 7
+    x, y = make_data(chunk * n_chunks, pixels)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FB_REPLAY", mode)
+        monkeypatch.setenv("FB_MAX_CMDLISTS", "4")
+        cfg, model, eng, stem_patches = _build(18, pixels, chunk, G, torch.bfloat16)
+        patches, yd = stem_patches(x.cuda(), eng.plan.stem, torch.bfloat16), y.cuda()
+        counts = []
+        for step in range(6):
+            eng.full_gradient(patches, yd, 0.1)
+            eng.grad_and_param_sqnorm()
+            eng.sgd_step(0.1, 5e-4, 0.9, 0.0, True, grad_clip=0.25)
+            counts.append(lib.event_count())
+        torch.cuda.synchronize()
+        if mode == "1":
+            assert len(eng.cmdlists) <= 4 and eng.cmd_evictions >= 4 and not eng.record_new
+            # 8 keys cycle through 4 slots: recordings reuse the ids of dropped lists; once recording has stopped the interpreted launches
+            # draw from the engine's ring of 1024 eager events, and the table stops growing altogether
+            from fullbatchtraining_amd.engine import _Events
+            assert counts[-1] == counts[-2] and counts[-1] <= counts[0] + _Events.RING, counts
+        out[mode] = (eng.theta.clone(), eng.running_mean.clone())
+    assert torch.equal(out["0"][0], out["1"][0]) and torch.equal(out["0"][1], out["1"][1])
+
+
+def test_replayed_list_refuses_a_missing_stream(monkeypatch):
+    """A list recorded with the weight-gradient stream holds stream INDICES; the stream pair is part of the cache key (dropping the stream
+    records a new list instead of replaying the old one into the default stream), and CommandList.replay itself raises on a None stream it needs."""
+    from fullbatchtraining_amd.lib import EngineError
+    pixels, chunk, G = 16, 32, 2
+    x, y = make_data(chunk * G, pixels)
+    cfg, model, eng, stem_patches = _build(18, pixels, chunk, G, torch.bfloat16)
+    patches, yd = stem_patches(x.cuda(), eng.plan.stem, torch.bfloat16), y.cuda()
+    eng.full_gradient(patches, yd, 0.1)
+    two = eng.avg.clone()
+    n_lists = len(eng.cmdlists)
+    group_list = next(cl for key, cl in eng.cmdlists.items() if key[0] == "group")
+    with pytest.raises(EngineError, match="stream index that is None"):
+        group_list.replay([torch.cuda.current_stream(), None])
+    saved, eng.wstream = eng.wstream, None
+    eng.running_mean.zero_(), eng.running_var.fill_(1.0)
+    eng.full_gradient(patches, yd, 0.1)
+    torch.cuda.synchronize()
+    assert len(eng.cmdlists) == 2 * n_lists and torch.equal(eng.avg, two)
+    eng.wstream = saved
+
+
 @pytest.mark.parametrize("case", ["r18-bf16", "r18-fd-f16x2", "r18-fd-bf16x6", "r50-bf16", "r152-bf16"])
 def test_two_stream_schedule_is_bit_identical_to_one_stream(case, monkeypatch):
     """The schedule bench.py runs (weight gradients and the running-mean pass on a second stream, recorded launches replayed natively) gives bit

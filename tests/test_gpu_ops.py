@@ -830,3 +830,89 @@ def test_bn_apply_fused_avgpool_is_bit_identical(C, W):
     ref = torch.relu(x.float() * scale.repeat_interleave(ipg, 0)[:, None, None, :] + shift.repeat_interleave(ipg, 0)[:, None, None, :] + res.float())
     ref = ref.bfloat16().float().view(n, W // 2, 2, W // 2, 2, C).mean(dim=(2, 4))
     assert float((pooled.float() - ref).abs().max()) < 2e-2 * float(ref.abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Entry points whose only check used to be an end-to-end training scenario (round 3 verdict): each against a plain torch restatement
+# of the reference lines it implements.
+def test_chunk_clip_and_fd_combine_vs_torch():
+    """fb_mt_fd_combine: g[j] += cf * (ga[j] - gb[j]) / eps_n[j] (reference modules.py:232-240 without the average);
+    fb_mt_chunk_clip: _clip_gradient_list with p = 2 (reference training/utils.py:4-19): norm > clip -> g *= clip / (norm + 1e-6)."""
+    lib = _lib()
+    torch.manual_seed(21)
+    P, G = 50_001, 9                 # odd length: the vector tail; padded group stride
+    stride = (P + 63) // 64 * 64
+    g, ga, gb = (torch.randn(G, stride) for _ in range(3))
+    for t in (g, ga, gb):
+        t[:, P:] = 0
+    eps_n = torch.rand(G) * 1e-2 + 1e-3
+    gd, gad, gbd, ed = g.cuda(), ga.cuda(), gb.cuda(), eps_n.cuda()
+    lib.call("fb_mt_fd_combine", gd.data_ptr(), gad.data_ptr(), gbd.data_ptr(), stride, G, P, ed.data_ptr(), 0.025)
+    ref = g[:, :P] + 0.025 * ((ga[:, :P] - gb[:, :P]) / eps_n[:, None])
+    assert torch.allclose(gd[:, :P].cpu(), ref, rtol=1e-6, atol=1e-6)
+    assert float(gd[:, P:].abs().max()) == 0                       # the alignment padding of the arena rows is not touched
+    # per-chunk clip: scale rows so that about half of them exceed the clip; one row sits exactly AT the clip norm (not clipped: strict >)
+    rows = ref.clone()
+    norms = rows.double().norm(dim=1)
+    clip = float(norms.sort().values[G // 2])
+    gd2 = torch.zeros(G, stride)
+    gd2[:, :P] = rows
+    gd2 = gd2.cuda()
+    sq = torch.zeros(G, device="cuda")
+    ws = torch.zeros(max(G, 2) * lib.MT_BLOCKS, device="cuda")
+    lib.call("fb_mt_sqnorm", gd2.data_ptr(), stride, G, P, 1.0, None, 0.0, sq.data_ptr(), ws.data_ptr())
+    clipped = torch.full((G,), -1.0, device="cuda")
+    lib.call("fb_mt_chunk_clip", gd2.data_ptr(), stride, G, P, sq.data_ptr(), clip, clipped.data_ptr())
+    norm32 = sq.cpu().sqrt()
+    want_flag = (norm32 > clip).float()
+    assert torch.equal(clipped.cpu(), want_flag) and 0 < int(want_flag.sum()) < G
+    coef = torch.where(norm32 > clip, clip / (norm32 + 1e-6), torch.ones(G))
+    assert torch.allclose(gd2[:, :P].cpu(), rows * coef[:, None], rtol=1e-6, atol=1e-8)
+    # against torch's own clip on the same rows (the reference's call): clipped rows end up at the clip norm
+    after = gd2[:, :P].cpu().double().norm(dim=1)
+    assert torch.allclose(after[want_flag.bool()], torch.full((int(want_flag.sum()),), clip, dtype=torch.float64), rtol=1e-5)
+    # `clipped` is optional (the pre-pass passes NULL)
+    lib.call("fb_mt_chunk_clip", gd2.data_ptr(), stride, G, P, sq.data_ptr(), 1e9, None)
+
+
+@pytest.mark.parametrize("C", [64, 2048, 100])
+def test_bn_eval_coeffs_vs_torch_batchnorm_eval(C):
+    """fb_bn_eval_coeffs: y = x * scale + shift must be torch's BatchNorm2d in eval mode (reference training.py:343-347 model.eval())."""
+    lib = _lib()
+    torch.manual_seed(C)
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C)), bn.bias.copy_(torch.randn(C))
+        bn.running_mean.copy_(torch.randn(C)), bn.running_var.copy_(torch.rand(C) * 3 + 1e-3)
+    bn.eval()
+    scale, shift = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    lib.call("fb_bn_eval_coeffs", bn.weight.detach().cuda().data_ptr(), bn.bias.detach().cuda().data_ptr(), bn.running_mean.cuda().data_ptr(),
+             bn.running_var.cuda().data_ptr(), bn.eps, scale.data_ptr(), shift.data_ptr(), C)
+    x = torch.randn(5, C, 3, 3)
+    got = x * scale.cpu()[None, :, None, None] + shift.cpu()[None, :, None, None]
+    with torch.no_grad():
+        want = bn(x)
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-5)
+    ref_scale = bn.weight.detach().double() / (bn.running_var.double() + bn.eps).sqrt()
+    assert torch.allclose(scale.cpu().double(), ref_scale, rtol=2e-6)
+    assert torch.allclose(shift.cpu().double(), bn.bias.detach().double() - bn.running_mean.double() * ref_scale, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("n,classes", [(257, 10), (64, 1000), (1, 10)])
+def test_head_tta_vs_reference_formula(n, classes):
+    """fb_head_tta: the reference's test-time-flip epilogue (training.py:370-373): outputs = softmax(z_a) + softmax(z_b); the loss function is
+    applied to those SUMMED PROBABILITIES as if they were logits (CrossEntropyLoss(outputs, labels)), predictions = argmax(outputs)."""
+    lib = _lib()
+    torch.manual_seed(n + classes)
+    za, zb = torch.randn(n, classes) * 3, torch.randn(n, classes) * 3
+    y = torch.randint(0, classes, (n,))
+    zb[: n // 2] = za[: n // 2] + 0.1 * torch.randn(n // 2, classes)        # (the mirror of an image mostly agrees with it)
+    ws = torch.zeros(2 * n + 2, device="cuda")
+    lib.call("fb_head_tta", za.cuda().data_ptr(), zb.cuda().data_ptr(), y.cuda().data_ptr(), n, classes, ws.data_ptr(), ws.data_ptr() + 8 * n,
+             ws.data_ptr() + 8 * n + 4)
+    outputs = torch.softmax(za.double(), 1) + torch.softmax(zb.double(), 1)
+    loss_sum = torch.nn.functional.cross_entropy(outputs, y, reduction="sum")
+    correct = (outputs.argmax(1) == y).sum()
+    got_loss, got_correct = ws[2 * n:].tolist()
+    assert abs(got_loss - float(loss_sum)) < 1e-5 * max(1.0, float(loss_sum)), (got_loss, float(loss_sum))
+    assert got_correct == float(correct)

@@ -8,10 +8,12 @@ import socket
 import numpy as np
 import pytest
 import torch
-import torch.multiprocessing as mp
+
+from tests.helpers import pg_timeout, spawn_bounded
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SPAWN_CAP_S = 150        # wall-clock cap of one spawned run (measured: 12-20 s); tests/helpers.spawn_bounded kills the ranks and fails the test
 
 OVERRIDES = ["hyp=fbclip", "hyp.steps=3", "hyp.warmup=1", "data.batch_size=32", "hyp.sub_batch=32", "data.pixels=16",
              "impl.validate_every_nth_step=1000", "impl.engine.chunk_group=2"]
@@ -42,7 +44,7 @@ def _run(rank, world, port, out_dir, grad_reg, backend="gloo", tag=None):
     over = list(OVERRIDES) + extra[grad_reg]
     if world > 1 or backend == "nccl":
         kw = dict(device_id=torch.device("cuda", dev)) if backend == "nccl" else {}
-        torch.distributed.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, **kw)
+        torch.distributed.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, timeout=pg_timeout(), **kw)
         over.append("impl/setup=distributed")
     cfg = compose(over, original_cwd=out_dir, name="sharded")
     torch.manual_seed(SEED)
@@ -65,20 +67,124 @@ def _run(rank, world, port, out_dir, grad_reg, backend="gloo", tag=None):
         torch.distributed.destroy_process_group()
 
 
+def _single(out, mode, tag=None):
+    """The 1-process run the sharded ones are compared with: in THIS process (no process group; saves an interpreter + HIP start-up per test)."""
+    _run(0, 1, 0, out, mode, "gloo", tag)
+
+
+def _ranks(world, out, mode, backend="gloo", tag=None):
+    spawn_bounded(_run, (world, _free_port(), out, mode, backend, tag), world, timeout=SPAWN_CAP_S)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
 
 
+def _compare(got, ref, grad_reg=False):
+    for key in ("train_loss", "train_acc", "param_norm", "grad_norm", "full_loss", "preclip_gradnorm", "clipped_step"):
+        atol = 1.01 / N if key == "train_acc" else 1e-6
+        assert np.allclose(got["stats"][key], ref["stats"][key], rtol=2e-4 if grad_reg is False else 5e-3, atol=atol), (key, got["stats"][key], ref["stats"][key])
+    for name, t in ref["state"].items():
+        if t.is_floating_point():
+            scale = max(float(t.abs().max()), 2e-2)
+            assert float((got["state"][name] - t).abs().max()) < 1e-3 * scale + 1e-6, name
+        else:
+            assert torch.equal(got["state"][name], t), name
+
+
+def test_rccl_collectives_one_rank(tmp_path, monkeypatch):
+    """The RCCL branch of the exchange (`reduce_scatter_tensor`, `all_gather_into_tensor`, the norm all-reduce) through the `nccl`
+    backend with a process group of ONE rank on cuda:0 (FB_FORCE_DIST=1 routes the step through the sharded path): on a 1-GPU box this
+    is the only way to execute those calls; the arithmetic must equal the plain 1-process step bit for bit."""
+    out = str(tmp_path)
+    # "onegroup*": the late bucket's asynchronous reduce-scatter starts on the side stream, from inside the last backward pass; "+poison": the
+    # local values of that bucket are overwritten with NaN behind the collective (FB_EXCHANGE_POISON) -- any consumer of the stale slice
+    # (a launch ordered on the wrong stream, an update reading ``avg`` instead of the reduced shard) would poison the step
+    for mode in (False, "onegroup", "onegroup_gradreg", "onegroup+poison", "onegroup_gradreg+poison"):
+        poison = mode is not False and mode.endswith("+poison")
+        mode = mode[:-len("+poison")] if poison else mode
+        monkeypatch.delenv("FB_FORCE_DIST", raising=False)
+        monkeypatch.delenv("FB_EXCHANGE_POISON", raising=False)
+        _single(out, mode)
+        monkeypatch.setenv("FB_FORCE_DIST", "1")
+        if poison:
+            monkeypatch.setenv("FB_EXCHANGE_POISON", "1")
+        _ranks(1, out, mode, "nccl", "rccl1")
+        ref, got = torch.load(os.path.join(out, "w1_r0.pt")), torch.load(os.path.join(out, "rccl1_r0.pt"))
+        _compare(got, ref, mode)
+        for key in ("train_loss", "param_norm"):
+            assert got["stats"][key] == ref["stats"][key], (mode, key)
+        # (with an early bucket |g_k|^2 is the sum of two partial sums: last-bit differences in the recorded chunk norms only)
+        assert np.allclose(got["stats"]["grad_norm"], ref["stats"]["grad_norm"], rtol=0 if mode is False else 1e-6), mode
+        # p.grad = the CLIPPED mean gradient: the clip norm is the sum of the exchange's two bucket norms here and one reduction over the
+        # whole arena in the plain step -- the same number up to the association of the last addition, i.e. the scale may differ by one ulp
+        for a, b in zip(got["grads"], ref["grads"]):
+            assert torch.allclose(a, b, rtol=5e-7, atol=0), mode
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL wants one device per rank")
+@pytest.mark.parametrize("grad_reg", [False, True])
+def test_two_rank_rccl_run_equals_single_process(tmp_path, grad_reg):
+    """Two ranks on two GPUs over RCCL (reduce-scatter + sharded update + all-gather over xGMI) == the 1-process run."""
+    out = str(tmp_path)
+    _single(out, grad_reg)
+    _ranks(2, out, grad_reg, "nccl", "rccl2")
+    ref = torch.load(os.path.join(out, "w1_r0.pt"))
+    for r in range(2):
+        _compare(torch.load(os.path.join(out, f"rccl2_r{r}.pt")), ref, grad_reg)
+
+
+def test_sharded_checkpoint_holds_whole_momentum(tmp_path):
+    """Rank 0 of a 2-rank run saves the checkpoint: its momentum buffers (each rank updates only its shard) and the exposed p.grad
+    must be the whole vectors -- equal to the 1-process run's -- and a 2-rank run resumed from it continues like the 1-process run
+    resumed from its own checkpoint (reference workflow: train_distributed_with_checkpoints.sh)."""
+    out1, out2 = str(tmp_path / "one"), str(tmp_path / "two")
+    os.makedirs(out1), os.makedirs(out2)
+    _single(out1, "ckpt")
+    _ranks(2, out2, "ckpt")
+    c1 = torch.load(os.path.join(out1, "checkpoints", "sharded.pth"), weights_only=False)
+    c2 = torch.load(os.path.join(out2, "checkpoints", "sharded.pth"), weights_only=False)
+    assert c1[4] == c2[4] == 3
+    worst = 0.0
+    for idx, st in c1[0]["state"].items():
+        a, b = st["momentum_buffer"], c2[0]["state"][idx]["momentum_buffer"]
+        # zeros / stale values outside rank 0's shard would be off by the tensor's own scale; the two runs themselves differ by fp32
+        # chunk-gradient noise (the ranks sum the full-batch gradient in another order), ~1e-3 of a typical momentum entry (1e-2)
+        scale = max(float(a.abs().max()), 2e-2)
+        worst = max(worst, float((a - b).abs().max()) / scale)
+        assert float((a - b).abs().max()) < 1e-2 * scale, idx
+        assert float(b.abs().max()) > 0.2 * float(a.abs().max()), idx         # not zeros
+    print(f"momentum buffers of the 2-rank checkpoint vs the 1-process one: worst relative difference {worst:.2e}")
+    ref = torch.load(os.path.join(out1, "w1_r0.pt"))
+    for r in range(2):
+        got = torch.load(os.path.join(out2, f"w2_r{r}.pt"))
+        for a, b in zip(got["grads"], ref["grads"]):      # p.grad of the last step, whole on every rank (fp32 chunk-gradient noise apart)
+            assert float((a - b).abs().max()) < 1e-2 * max(float(b.abs().max()), 2e-2)
+            assert float(a.abs().max()) > 0.2 * float(b.abs().max())
+    # resume both runs from their own checkpoints for two more steps
+    _single(out1, "ckpt_resume", "resumed")
+    _ranks(2, out2, "ckpt_resume", tag="resumed")
+    ref = torch.load(os.path.join(out1, "resumed_r0.pt"))
+    assert len(ref["stats"]["train_loss"]) == 2
+    for r in range(2):
+        got = torch.load(os.path.join(out2, f"resumed_r{r}.pt"))
+        for key in ("train_loss", "grad_norm", "param_norm", "full_loss"):
+            # steps 4-5 of the run: the ranks sum the full-batch gradient in another order than one process, and fp32 chunk-gradient noise
+            # has grown to ~2e-3 by step 5 (a resumed shard without its momentum would be off by tens of per cent)
+            assert np.allclose(got["stats"][key], ref["stats"][key], rtol=1e-2), (key, got["stats"][key], ref["stats"][key])
+
+
+# (the 2-rank gloo matrix comes AFTER the RCCL and checkpoint cases: on a slow box those are not the first casualties)
 @pytest.mark.parametrize("grad_reg", [False, True, "options", "acc", "shuffle", "onegroup", "onegroup_gradreg", "onegroup_central"])
 def test_two_rank_run_equals_single_process(tmp_path, grad_reg):
     """plain step and regulariser: sharded update (reduce-scatter / all-gather); "options": SAM + L-infinity clip + norm bias +
     per-tensor weight decay + gradient noise (rank 0's draw, broadcast), which all-reduce the gradient and replicate the 1-process update; "acc": the acc_strength pre-pass
     (its own all-reduce and BN recombination inside the closure)."""
     out = str(tmp_path)
-    mp.spawn(_run, args=(1, 0, out, grad_reg), nprocs=1, join=True)
-    mp.spawn(_run, args=(2, _free_port(), out, grad_reg), nprocs=2, join=True)
+    _single(out, grad_reg)
+    _ranks(2, out, grad_reg)
     ref = torch.load(os.path.join(out, "w1_r0.pt"))
     for r in range(2):
         got = torch.load(os.path.join(out, f"w2_r{r}.pt"))
@@ -112,100 +218,6 @@ def test_two_rank_run_equals_single_process(tmp_path, grad_reg):
                 assert torch.equal(got["state"][name], t), name
 
 
-def _compare(got, ref, grad_reg=False):
-    for key in ("train_loss", "train_acc", "param_norm", "grad_norm", "full_loss", "preclip_gradnorm", "clipped_step"):
-        atol = 1.01 / N if key == "train_acc" else 1e-6
-        assert np.allclose(got["stats"][key], ref["stats"][key], rtol=2e-4 if grad_reg is False else 5e-3, atol=atol), (key, got["stats"][key], ref["stats"][key])
-    for name, t in ref["state"].items():
-        if t.is_floating_point():
-            scale = max(float(t.abs().max()), 2e-2)
-            assert float((got["state"][name] - t).abs().max()) < 1e-3 * scale + 1e-6, name
-        else:
-            assert torch.equal(got["state"][name], t), name
-
-
-def test_rccl_collectives_one_rank(tmp_path, monkeypatch):
-    """The RCCL branch of the exchange (`reduce_scatter_tensor`, `all_gather_into_tensor`, the norm all-reduce) through the `nccl`
-    backend with a process group of ONE rank on cuda:0 (FB_FORCE_DIST=1 routes the step through the sharded path): on a 1-GPU box this
-    is the only way to execute those calls; the arithmetic must equal the plain 1-process step bit for bit."""
-    out = str(tmp_path)
-    # "onegroup*": the late bucket's asynchronous reduce-scatter starts on the side stream, from inside the last backward pass; "+poison": the
-    # local values of that bucket are overwritten with NaN behind the collective (FB_EXCHANGE_POISON) -- any consumer of the stale slice
-    # (a launch ordered on the wrong stream, an update reading ``avg`` instead of the reduced shard) would poison the step
-    for mode in (False, "onegroup", "onegroup_gradreg", "onegroup+poison", "onegroup_gradreg+poison"):
-        poison = mode is not False and mode.endswith("+poison")
-        mode = mode[:-len("+poison")] if poison else mode
-        monkeypatch.delenv("FB_FORCE_DIST", raising=False)
-        monkeypatch.delenv("FB_EXCHANGE_POISON", raising=False)
-        mp.spawn(_run, args=(1, 0, out, mode), nprocs=1, join=True)
-        monkeypatch.setenv("FB_FORCE_DIST", "1")
-        if poison:
-            monkeypatch.setenv("FB_EXCHANGE_POISON", "1")
-        mp.spawn(_run, args=(1, _free_port(), out, mode, "nccl", "rccl1"), nprocs=1, join=True)
-        ref, got = torch.load(os.path.join(out, "w1_r0.pt")), torch.load(os.path.join(out, "rccl1_r0.pt"))
-        _compare(got, ref, mode)
-        for key in ("train_loss", "param_norm"):
-            assert got["stats"][key] == ref["stats"][key], (mode, key)
-        # (with an early bucket |g_k|^2 is the sum of two partial sums: last-bit differences in the recorded chunk norms only)
-        assert np.allclose(got["stats"]["grad_norm"], ref["stats"]["grad_norm"], rtol=0 if mode is False else 1e-6), mode
-        # p.grad = the CLIPPED mean gradient: the clip norm is the sum of the exchange's two bucket norms here and one reduction over the
-        # whole arena in the plain step -- the same number up to the association of the last addition, i.e. the scale may differ by one ulp
-        for a, b in zip(got["grads"], ref["grads"]):
-            assert torch.allclose(a, b, rtol=5e-7, atol=0), mode
-
-
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL wants one device per rank")
-@pytest.mark.parametrize("grad_reg", [False, True])
-def test_two_rank_rccl_run_equals_single_process(tmp_path, grad_reg):
-    """Two ranks on two GPUs over RCCL (reduce-scatter + sharded update + all-gather over xGMI) == the 1-process run."""
-    out = str(tmp_path)
-    mp.spawn(_run, args=(1, 0, out, grad_reg), nprocs=1, join=True)
-    mp.spawn(_run, args=(2, _free_port(), out, grad_reg, "nccl", "rccl2"), nprocs=2, join=True)
-    ref = torch.load(os.path.join(out, "w1_r0.pt"))
-    for r in range(2):
-        _compare(torch.load(os.path.join(out, f"rccl2_r{r}.pt")), ref, grad_reg)
-
-
-def test_sharded_checkpoint_holds_whole_momentum(tmp_path):
-    """Rank 0 of a 2-rank run saves the checkpoint: its momentum buffers (each rank updates only its shard) and the exposed p.grad
-    must be the whole vectors -- equal to the 1-process run's -- and a 2-rank run resumed from it continues like the 1-process run
-    resumed from its own checkpoint (reference workflow: train_distributed_with_checkpoints.sh)."""
-    out1, out2 = str(tmp_path / "one"), str(tmp_path / "two")
-    os.makedirs(out1), os.makedirs(out2)
-    mp.spawn(_run, args=(1, 0, out1, "ckpt"), nprocs=1, join=True)
-    mp.spawn(_run, args=(2, _free_port(), out2, "ckpt"), nprocs=2, join=True)
-    c1 = torch.load(os.path.join(out1, "checkpoints", "sharded.pth"), weights_only=False)
-    c2 = torch.load(os.path.join(out2, "checkpoints", "sharded.pth"), weights_only=False)
-    assert c1[4] == c2[4] == 3
-    worst = 0.0
-    for idx, st in c1[0]["state"].items():
-        a, b = st["momentum_buffer"], c2[0]["state"][idx]["momentum_buffer"]
-        # zeros / stale values outside rank 0's shard would be off by the tensor's own scale; the two runs themselves differ by fp32
-        # chunk-gradient noise (the ranks sum the full-batch gradient in another order), ~1e-3 of a typical momentum entry (1e-2)
-        scale = max(float(a.abs().max()), 2e-2)
-        worst = max(worst, float((a - b).abs().max()) / scale)
-        assert float((a - b).abs().max()) < 1e-2 * scale, idx
-        assert float(b.abs().max()) > 0.2 * float(a.abs().max()), idx         # not zeros
-    print(f"momentum buffers of the 2-rank checkpoint vs the 1-process one: worst relative difference {worst:.2e}")
-    ref = torch.load(os.path.join(out1, "w1_r0.pt"))
-    for r in range(2):
-        got = torch.load(os.path.join(out2, f"w2_r{r}.pt"))
-        for a, b in zip(got["grads"], ref["grads"]):      # p.grad of the last step, whole on every rank (fp32 chunk-gradient noise apart)
-            assert float((a - b).abs().max()) < 1e-2 * max(float(b.abs().max()), 2e-2)
-            assert float(a.abs().max()) > 0.2 * float(b.abs().max())
-    # resume both runs from their own checkpoints for two more steps
-    mp.spawn(_run, args=(1, 0, out1, "ckpt_resume", "gloo", "resumed"), nprocs=1, join=True)
-    mp.spawn(_run, args=(2, _free_port(), out2, "ckpt_resume", "gloo", "resumed"), nprocs=2, join=True)
-    ref = torch.load(os.path.join(out1, "resumed_r0.pt"))
-    assert len(ref["stats"]["train_loss"]) == 2
-    for r in range(2):
-        got = torch.load(os.path.join(out2, f"resumed_r{r}.pt"))
-        for key in ("train_loss", "grad_norm", "param_norm", "full_loss"):
-            # steps 4-5 of the run: the ranks sum the full-batch gradient in another order than one process, and fp32 chunk-gradient noise
-            # has grown to ~2e-3 by step 5 (a resumed shard without its momentum would be off by tens of per cent)
-            assert np.allclose(got["stats"][key], ref["stats"][key], rtol=1e-2), (key, got["stats"][key], ref["stats"][key])
-
-
 def test_bench_two_ranks_spawn_and_tear_down_on_one_gpu(tmp_path):
     """`python bench.py --gpus 2` as the driver calls it: the parent (which has not touched the GPU) starts two ranks through
     torch.distributed.run, every rank takes its chunk range, runs warm-up + timed + event-instrumented steps, rank 0 prints ONE JSON line, the
@@ -216,7 +228,7 @@ def test_bench_two_ranks_spawn_and_tear_down_on_one_gpu(tmp_path):
     import sys
     env = dict(os.environ, FB_BENCH_SHARE_DEVICE="1")
     res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--images", "2048", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
-                         env=env, capture_output=True, text=True, timeout=900)
+                         env=env, capture_output=True, text=True, timeout=200)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
