@@ -291,10 +291,13 @@ class Engine:
         self.unbias = self._unbias_for(self.valid)
         # fp32 convolutions: "f16x2" (two scaled fp16 pieces per operand, three MFMAs per product; needs the largest magnitude of every
         # operand tensor: fb_absmax, cached per tensor below), "bf16x6" (three bf16 pieces, six MFMAs); FB_F32_EXACT=1 in the library: exact f32
-        # Default: f16x2 for the finite-difference regulariser (its own truncation error, 3.5e-2 in fp32, hides the 2^-22 operand rounding:
-        # the float64 oracle with 22-bit operands gives 3.7e-2), bf16x6 for plain fp32 training (held to the tighter fp32-vs-float64 traces)
-        # (``f32_split``: the caller's choice where the environment does not say otherwise -- the standalone GradRegularizer object asks for bf16x6)
-        self.f32_split = os.environ.get("FB_F32_SPLIT", f32_split or ("f16x2" if fd_sets else "bf16x6")) if compute_dtype == torch.float32 else None
+        # Default: bf16x6 everywhere -- the reference runs the regulariser's passes in fp32 (modules.py:226-240) and bf16x6 keeps every product
+        # exact to 2^-23.  f16x2 (22-bit operands) is an explicit opt-in: ``f32_split="f16x2"`` (the trainer passes impl.engine.fd_arithmetic) or
+        # FB_F32_SPLIT=f16x2; the regulariser's own truncation error (3.5e-2 in fp32) hides its operand rounding (float64 oracle with 22-bit
+        # operands: 3.7e-2), at 0.6x the step time
+        self.f32_split = os.environ.get("FB_F32_SPLIT", f32_split or "bf16x6") if compute_dtype == torch.float32 else None
+        if self.f32_split not in (None, "bf16x6", "f16x2"):
+            raise lib.EngineError(f"fp32 arithmetic {self.f32_split!r}: bf16x6 or f16x2")
         self._alloc_activations()
         self.mt_ws = torch.zeros(lib.load().fb_ws_mt_floats(self.G), **f32)
         self.sq = torch.zeros(self.G, **f32)

@@ -453,7 +453,8 @@ class FullBatchTrainer:
         # K-slice counts of the weight gradients are sized for the group of the WHOLE problem on one GPU -- the same number on every rank, so
         # that a chunk's summation order (hence its gradient, bit for bit) does not depend on the number of GPUs
         self.engine = Engine(model, X.shape[-1], self.chunk_pad, G, compute_dtype=self.dtype, device=self.device, fd_sets=fd_sets,
-                             arena_align=64 * self.world, chunk_valid=self.chunk, nominal_group=group_size(self.n_chunks, want, cap=cap))
+                             arena_align=64 * self.world, chunk_valid=self.chunk, nominal_group=group_size(self.n_chunks, want, cap=cap),
+                             f32_split=str(cfg.impl.get("engine", {}).get("fd_arithmetic", "bf16x6")) if fd else None)
         self.engine.label_smoothing = getattr(self.loss_fn, "smoothing", 0.0)
         self.engine.only_incorrect = getattr(self.loss_fn, "only_incorrect", False)
         stem = self.engine.plan.stem
@@ -471,7 +472,7 @@ class FullBatchTrainer:
         if mine is not None and self.augment is None:
             self._gather_patches(mine)
         del mine
-        self.labels = self._pad_labels(Y[lo:hi].to(self.device))
+        self.labels = self._pad_labels(Y[lo:hi].to(self.device)).clone()      # (a buffer of its own: a shuffling feed rewrites it every step)
         # a validation DataLoader is read once through a private loader (its generator untouched); every validation pass then advances
         # that generator by the one base-seed draw the reference's pass over it makes (keeps shared generators aligned)
         self._valid_loader = validloader if isinstance(validloader, torch.utils.data.DataLoader) else None

@@ -203,9 +203,9 @@ def cross_entropy_fwd_bwd(logits, labels, smoothing=0.0, only_incorrect=False):
     lse = z.exp().sum(dim=1, keepdim=True).log()
     logp = z - lse
     weight = torch.full_like(logits, smoothing / (classes - 1.0))
-    weight[torch.arange(n), labels] = 1.0 - smoothing
+    weight[torch.arange(n, device=logits.device), labels] = 1.0 - smoothing
     hit = logits.argmax(dim=-1) == labels
-    keep = (~hit).to(logits.dtype) if only_incorrect else torch.ones(n, dtype=logits.dtype)
+    keep = (~hit).to(logits.dtype) if only_incorrect else torch.ones(n, dtype=logits.dtype, device=logits.device)
     loss = ((-weight * logp).sum(dim=-1) * keep).mean()
     dlogits = (logp.exp() - weight) * keep[:, None] / n
     correct = hit.float().sum()  # reference training.py:80
@@ -539,7 +539,7 @@ def _gradient_evaluation(spec, params, buffers, X, Y, hyp, lr, stats, chunk, q=i
                 g.sub_(a)
                 a.add_(g, alpha=1 / (counter + 1))
     avg = [torch.zeros_like(p) for p in params.values()]
-    grad_norms = torch.zeros(n_chunks, dtype=avg[0].dtype)
+    grad_norms = torch.zeros(n_chunks, dtype=avg[0].dtype, device=avg[0].device)
     step_loss, step_preds, datapoints, clipped_batches = 0.0, 0.0, 0, 0
     ks = range(n_chunks) if chunk_range is None else chunk_range
     for counter, k in enumerate(ks):

@@ -152,3 +152,29 @@ def spawn_bounded(fn, args, nprocs, timeout=150.0):
                 proc.kill()
         for proc in ctx.processes:
             proc.join(10)
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# Where the float64 oracle's tensors live in the `-m gpu` tests.  oracle/fb_oracle.py is a restatement in plain torch ops and does not
+# care: on the host cores of a GPU box one float64 chunk gradient of ResNet-18 (128 images, 32 px) takes 29 s, with its tensors on the
+# device 0.5 s, and the two agree to 2e-14 (tools/scratch/oracle_on_gpu.py; asserted by tests/test_gpu_engine.py::
+# test_oracle_on_the_device_equals_the_oracle_on_the_host).  The convolutions then run in torch's own GPU kernels -- independent of
+# libfbengine either way.  FB_ORACLE_DEVICE=cpu puts it back on the host; the `-m "not gpu"` tests always run it there.
+def oracle_device():
+    import os
+    want = os.environ.get("FB_ORACLE_DEVICE", "cuda")
+    return torch.device(want if (want == "cpu" or torch.cuda.is_available()) else "cpu")
+
+
+def oracle_state(model, dtype=torch.float64, device=None):
+    """(params, buffers) of the oracle from a parameter container, in ``dtype`` on the oracle's device."""
+    from oracle import fb_oracle as orc
+    device = oracle_device() if device is None else device
+    state = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.detach().clone()).to(device) for k, v in model.state_dict().items()}
+    return orc.split_state(state)
+
+
+def to_oracle(*tensors, dtype=torch.float64):
+    dev = oracle_device()
+    out = tuple(t.to(dev, dtype) if t.is_floating_point() else t.to(dev) for t in tensors)
+    return out[0] if len(out) == 1 else out

@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import make_data
+from tests.helpers import make_data, oracle_state, to_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -36,7 +36,8 @@ def _nchw(t):
 
 
 def _close(got_nhwc, ref_nchw, what, report):
-    got, ref = _nchw(got_nhwc), ref_nchw.double()
+    ref = ref_nchw.double()
+    got = _nchw(got_nhwc).to(ref.device)
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     diff = (got - ref).abs()
     rms = float(ref.pow(2).mean().sqrt())
@@ -48,7 +49,8 @@ def _close(got_nhwc, ref_nchw, what, report):
 
 
 def _close_f32(got, ref, what, report, tol=1e-3):
-    got, ref = got.double().cpu().reshape(-1), ref.double().reshape(-1)
+    ref = ref.double().reshape(-1)
+    got = got.double().to(ref.device).reshape(-1)
     rel = float((got - ref).norm() / max(float(ref.norm()), 1e-30))
     report.append((what, rel, 0.0))
     assert np.isfinite(rel) and rel < tol, f"{what}: relative L2 {rel:.3e} (limit {tol:.1e})"
@@ -57,7 +59,7 @@ def _close_f32(got, ref, what, report, tol=1e-3):
 def _mask_bytes(positive_nchw):
     """ReLU bitmask in the layout fb_bn_apply writes: one byte per 16-byte vector (8 bf16 channels) of the NHWC tensor, bit k = element k > 0"""
     bits = positive_nchw.permute(0, 2, 3, 1).contiguous().reshape(-1, 8).to(torch.int32)
-    weights = (2 ** torch.arange(8, dtype=torch.int32))
+    weights = (2 ** torch.arange(8, dtype=torch.int32, device=bits.device))
     return (bits * weights).sum(1).to(torch.uint8).cuda()
 
 
@@ -78,10 +80,10 @@ def test_resnet18_bf16_kernels_layer_by_layer_against_the_oracle():
     x, y = make_data(chunk, pixels)
     q = lambda t: t.to(torch.bfloat16).to(t.dtype)          # noqa: E731  (orc.bf16_round returns float32; the walk runs in float64)
     spec = orc.Spec(18)
-    state = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
-    params, buffers = orc.split_state(state)
-    logits_o, tape = orc.forward(spec, params, buffers, x.double(), q, update_bn=False, train=True)
-    loss_o, correct_o, dlogits_o = orc.cross_entropy_fwd_bwd(logits_o, y)
+    params, buffers = oracle_state(model)                  # the walk runs on the oracle's device (tests/helpers.oracle_device)
+    xo, yo = to_oracle(x, y)
+    logits_o, tape = orc.forward(spec, params, buffers, xo, q, update_bn=False, train=True)
+    loss_o, correct_o, dlogits_o = orc.cross_entropy_fwd_bwd(logits_o, yo)
     report = []
     gout = eng.g
     gout.zero_()

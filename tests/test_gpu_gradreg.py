@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import make_data, rel_err, summarise
+from tests.helpers import make_data, oracle_state, rel_err, summarise, to_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -24,8 +24,7 @@ def test_gradreg_object_matches_reference(golden, name):
     x, y = make_data(sc["n"], sc["pixels"])
     chunk = min(cfg.data.batch_size, cfg.hyp.sub_batch)
     # raw chunk gradients from the float64 oracle (the object under test is the regulariser, not the first pass)
-    state = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
-    params, buffers = orc.split_state(state)
+    params, buffers = oracle_state(model)
     spec = orc.Spec(18)
     model = model.cuda()
     optimizer = torch.optim.SGD(model.parameters(), lr=0.1)
@@ -33,10 +32,11 @@ def test_gradreg_object_matches_reference(golden, name):
     assert greg.create_graph is False
     for k in range(2):
         xk, yk = x[k * chunk:(k + 1) * chunk], y[k * chunk:(k + 1) * chunk]
-        raw, _, _ = orc.chunk_gradient(spec, params, buffers, xk.double(), yk)          # also advances the oracle's BN buffers
+        xo, yo = to_oracle(xk, yk)
+        raw, _, _ = orc.chunk_gradient(spec, params, buffers, xo, yo)          # also advances the oracle's BN buffers
         grads = [g.float().cuda() for g in raw]
         # keep the oracle's parameters/buffers in step with what the reference probe did (its own FD pass)
-        orc.gradreg(spec, params, buffers, [g.clone() for g in raw], xk.double(), yk, 0.1, cfg.hyp.grad_reg.block_strength,
+        orc.gradreg(spec, params, buffers, [g.clone() for g in raw], xo, yo, 0.1, cfg.hyp.grad_reg.block_strength,
                     cfg.hyp.grad_reg.eps, cfg.hyp.grad_reg.implementation)
         out = greg(grads, xk.cuda(), yk.cuda(), None)
         assert out is grads
@@ -70,12 +70,12 @@ def test_gradreg_object_with_pre_grads(implementation, block_strength):
     torch.manual_seed(21)
     model = construct_model(cfg.model, 3, 10)
     x, y = make_data(64, 16)
-    state = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
-    params, buffers = orc.split_state(state)
+    params, buffers = oracle_state(model)
     spec = orc.Spec(18)
-    raw, _, _ = orc.chunk_gradient(spec, params, buffers, x[:32].double(), y[:32])
-    pre, _, _ = orc.chunk_gradient(spec, params, buffers, x[32:].double(), y[32:])       # any other gradient-shaped list
-    want = orc.gradreg(spec, params, buffers, [g.clone() for g in raw], x[:32].double(), y[:32], 0.1, block_strength, 1e-2, implementation,
+    xo, yo = to_oracle(x, y)
+    raw, _, _ = orc.chunk_gradient(spec, params, buffers, xo[:32], yo[:32])
+    pre, _, _ = orc.chunk_gradient(spec, params, buffers, xo[32:], yo[32:])       # any other gradient-shaped list
+    want = orc.gradreg(spec, params, buffers, [g.clone() for g in raw], xo[:32], yo[:32], 0.1, block_strength, 1e-2, implementation,
                        acc_strength=0.25, pre_grads=pre)
     # the model on the GPU: parameters as at init, BN buffers as the oracle had them BEFORE its FD pass (after the two first passes)
     model = model.cuda()
@@ -86,7 +86,7 @@ def test_gradreg_object_with_pre_grads(implementation, block_strength):
     out = greg(grads, x[:32].cuda(), y[:32].cuda(), [g.float().cuda() for g in pre])
     assert out is grads
     a = torch.cat([g.reshape(-1).double().cpu() for g in grads])
-    t = torch.cat([g.reshape(-1) for g in want])
+    t = torch.cat([g.reshape(-1).cpu() for g in want])
     err = float((a - t).norm() / t.norm())
     print(f"{implementation} with pre_grads: GradRegularizer-vs-oracle64 {err:.2e}")
     assert err < 2e-2          # same class as the pre_grads-free variants above (fp32 finite differences of a cancelling sum)
