@@ -523,12 +523,24 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # FB_FORCE_DIST=1 with --gpus 1: the sharded step (reduce-scatter on the side stream under the last backward pass, shard-local clip + SGD,
+    # all-gather) through RCCL with a process group of ONE rank -- what a 1-GPU box can measure of the exchange: does the collective's kernel
+    # get onto the device while the persistent convolutions hold the CUs (`exchange` in the line; FB_CU_RESERVE leaves CUs free for it)
+    force_dist = world == 1 and os.environ.get("FB_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share:
-            torch.distributed.init_process_group("gloo")
+        if force_dist:
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                port = sock.getsockname()[1]
+            os.environ["FB_EXCHANGE_TIMING"] = "1"
+            torch.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device,
+                                                 timeout=datetime.timedelta(seconds=300))
+        elif share:
+            torch.distributed.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
         else:
-            import datetime
             # (a collective that never completes fails the run after five minutes instead of holding the node for the default ten-minute watchdog + retries)
             torch.distributed.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=300))
 
@@ -546,7 +558,7 @@ def main():
         overrides += ["hyp=gradreg", "hyp.warmup=0", f"hyp.steps={n_sched}", f"hyp.grad_reg.block_strength={args.grad_reg}"]
     if args.chunk != CHUNK:
         overrides += [f"data.batch_size={args.chunk}", f"hyp.sub_batch={args.chunk}"]
-    if world > 1:
+    if world > 1 or force_dist:
         overrides += ["impl/setup=distributed"]
     headline = (args.model, args.stem, args.pixels) == ("resnet18", "CIFAR", 32)
     if not headline:
@@ -636,11 +648,17 @@ def main():
                  "outside_the_step": "the dataset is resident in HBM and the stem's im2col patches (fb_stem_patches, 3.3 GB bf16, ~3 ms) are gathered once before the "
                                      "timed region (static, un-augmented dataset); inside: weight prep, all chunk forward/backward passes, running mean, clip + SGD "
                                      "update, statistics read-back"}
+        if force_dist and getattr(trainer, "_last_exchange", None) is not None:
+            torch.cuda.synchronize()
+            buckets = trainer._last_exchange.timing_summary()
+            late = [b for b in buckets if b["lead_ms"] > 0]
+            out["exchange"] = {"ranks": 1, "backend": "rccl", "cu_reserve": int(os.environ.get("FB_CU_RESERVE", "0") or 0), "buckets": buckets,
+                               "overlap_frac": late[0]["overlap_frac"] if late else 0.0}
         roof = side = cpu = None
         if launches is not None:
             out["ms_per_step_with_kernel_events"] = round(1000 * elapsed_ev / args.steps, 2)
             roof = roofline_objects(args, trainer, launches, launches_iso, elapsed / args.steps, world, headline, passes)
-        if world == 1 and headline and args.grad_reg == 0 and trainer.dtype == torch.bfloat16 and not args.no_side_configs:
+        if world == 1 and headline and args.grad_reg == 0 and trainer.dtype == torch.bfloat16 and not args.no_side_configs and not force_dist:
             side = side_configs(args, device, X, Y, trainer)
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
@@ -648,7 +666,7 @@ def main():
         write_detail(detail)
         sys.stdout.flush()
         print(line, flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         torch.distributed.destroy_process_group()
 
 

@@ -287,6 +287,8 @@ __device__ __forceinline__ f32x4_t mma_planes3h(const uint4 (&a)[2], const uint4
 }
 // FB_F32_EXACT=1 (environment, read once): fp32 convolutions on the exact-f32 MFMA instead of the split path (A/B and reference)
 bool fb_f32_split_enabled();
+// CUs the persistent kernels size their grids for (runtime.cpp: the device's CU count minus FB_CU_RESERVE)
+int fb_persistent_cus();
 
 // 128-bit buffer stores with an SGPR offset: keep the four data registers alive for a few wait states after the store.
 // The register allocator likes to reuse a data register in the instruction right behind such a store (seen: v_cndmask writing the next

@@ -109,12 +109,7 @@ int fb_try_conv1x1_k32(const fb_conv_args* a, hipStream_t st) {
     const long long M = (long long)a->n_img * a->Hd * a->Wd;
     const long long n_blocks = (M + 127) / 128;
     if (n_blocks >= (1LL << 31)) return 0;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-            n_cu = 256;
-    }
+    const int n_cu = fb_persistent_cus();
     const int grid = (int)(n_blocks < 8LL * n_cu ? n_blocks : 8LL * n_cu);
     hipLaunchKernelGGL(conv1x1_k32_kernel, dim3(grid), dim3(256), 0, st, (const uint4*)a->src, (const uint4*)a->wgt, (char*)a->dst, a->stat_partial, M,
                        (int)n_blocks, (int)n_blocks);

@@ -250,11 +250,7 @@ int fb_try_conv1x1_stream(const fb_conv_args* a, hipStream_t st) {
     p.n_co = a->Cd / (NWC * CW);
     p.n_mblocks = (int)((M + 127) / 128);
     const long long n_units = (M + unit - 1) / unit;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = fb_persistent_cus();
     long long workers = ((nw == 8 ? 1LL : 2LL) * n_cu) / p.n_co;
     if (workers < 1) workers = 1;
     if (workers > n_units) workers = n_units;

@@ -565,12 +565,7 @@ int fb_try_conv3x3_halo4(const fb_conv_args* a, hipStream_t st) {
     const bool wide = variant == 2;
     const int W = a->Ws, EB = a->dtype == FB_F32 ? 4 : 2;
     const int imgs_per_wset = a->imgs_per_wset > 0 ? a->imgs_per_wset : a->n_img;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-            n_cu = 256;
-    }
+    const int n_cu = fb_persistent_cus();
     Halo4Params p;
     p.src = (const char*)a->src; p.wgt = (const char*)a->wgt; p.dst = (char*)a->dst; p.addend = (const char*)a->addend;
     p.stat = a->stat_partial;

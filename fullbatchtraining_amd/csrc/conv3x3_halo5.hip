@@ -352,12 +352,7 @@ int fb_conv3x3_halo5_takes(const fb_conv_args* a) {
 
 int fb_try_conv3x3_halo5(const fb_conv_args* a, hipStream_t st) {
     if (!fb_conv3x3_halo5_takes(a)) return 0;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-            n_cu = 256;
-    }
+    const int n_cu = fb_persistent_cus();
     Halo5Params p;
     p.src = (const char*)a->src; p.wgt = (const char*)a->wgt; p.dst = (char*)a->dst; p.addend = (const char*)a->addend;
     p.stat = (a->mode == 0 || a->bst_x) ? a->stat_partial : nullptr;

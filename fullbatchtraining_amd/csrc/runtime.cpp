@@ -21,6 +21,22 @@ extern "C" int64_t fb_ws_wgrad_slab_floats(const fb_wgrad_args* a) {
 extern "C" int64_t fb_ws_bn_partial_floats(int64_t n_pixels, int32_t C) { return 2 * ((n_pixels + 127) / 128) * C; }
 extern "C" int64_t fb_ws_mt_floats(int32_t n_groups) { return (int64_t)(n_groups > 2 ? n_groups : 2) * FB_MT_BLOCKS; }
 
+// CUs the persistent kernels size their grids for: the device's, minus FB_CU_RESERVE (default 0).  With one or two resident workgroups of a
+// persistent convolution on EVERY CU a kernel of another stream (the gradient exchange's RCCL kernels under the last backward pass) only gets
+// a slot when a whole launch ends; a reserve leaves that many CUs' worth of slots open (measured: bench.py `exchange`).
+int fb_persistent_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        const char* r = getenv("FB_CU_RESERVE");
+        const int reserve = r ? atoi(r) : 0;
+        n = cus - (reserve > 0 ? reserve : 0);
+        if (n < 8) n = 8;
+    }
+    return n;
+}
+
 bool fb_f32_split_enabled() {
     static const bool on = getenv("FB_F32_EXACT") == nullptr || getenv("FB_F32_EXACT")[0] == '0';
     return on;

@@ -83,6 +83,20 @@ class BucketExchange:
         for lo, hi in zip(self.bounds, self.bounds[1:]):
             assert (hi - lo) % plan.world == 0 and lo % 4 == 0, "bucket bounds must be multiples of lcm(4, world)"
         self.pending = {}
+        # FB_EXCHANGE_TIMING=1: device timestamps around every bucket's reduce-scatter (on the stream it was started from) and at the point
+        # where the main stream comes to wait for it -- how much of the exchange the backward pass hides (``timing_summary``)
+        self.timed = os.environ.get("FB_EXCHANGE_TIMING") == "1" and avg.is_cuda
+        self.stamps = {}
+
+    def timing_summary(self):
+        """After a device synchronisation: per bucket the duration of its reduce-scatter, how long before the main stream needed the result
+        it had started (``lead_ms``) and the part of it that ran hidden under the backward pass (``overlap_frac``)."""
+        out = []
+        for i, (t0, t1, tm) in sorted(self.stamps.items()):
+            rs, lead = t0.elapsed_time(t1), t0.elapsed_time(tm)
+            out.append(dict(bucket=i, elements=self.bounds[i + 1] - self.bounds[i], reduce_scatter_ms=round(rs, 3), lead_ms=round(lead, 3),
+                            exposed_ms=round(max(0.0, rs - max(lead, 0.0)), 3), overlap_frac=round(min(max(lead, 0.0), rs) / rs, 4) if rs > 0 else None))
+        return out
 
     def ranges(self):
         """This rank's (lo, n) range of every bucket."""
@@ -98,12 +112,22 @@ class BucketExchange:
         part = self.avg[lo:hi]
         self.ops.scale(part, self.plan.count / self.plan.n_chunks)
         shard = torch.empty(n, device=part.device, dtype=part.dtype)
+        t0 = t1 = None
+        if self.timed:
+            t0 = torch.cuda.Event(enable_timing=True)
+            t0.record()
         if dist.get_backend(self.group) == "gloo":          # no reduce_scatter in gloo: all-reduce, keep the local part
             dist.all_reduce(part, group=self.group)
             shard.copy_(part[self.plan.rank * n:(self.plan.rank + 1) * n])
             work = None
         else:
             work = dist.reduce_scatter_tensor(shard, part, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if self.timed:
+            if work is not None:
+                work.wait()                                 # (the stream this bucket was started from waits: nothing else is queued on it)
+            t1 = torch.cuda.Event(enable_timing=True)
+            t1.record()
+            self.stamps[i] = [t0, t1, None]
         if os.environ.get("FB_EXCHANGE_POISON") == "1":
             # test switch: once the bucket has left, nothing may read this rank's LOCAL values of it again (finish() consumes ``shard``; the
             # ranges of ``avg`` a rank does not own are undefined until gather_sharded_state()).  Overwrite them with NaN behind the
@@ -115,10 +139,16 @@ class BucketExchange:
 
     def finish(self):
         n_buckets = len(self.bounds) - 1
+        tm = None
+        if self.timed:                                      # here the main stream turns to the exchange (buckets started below hide nothing)
+            tm = torch.cuda.Event(enable_timing=True)
+            tm.record()
         for i in reversed(range(n_buckets)):               # late buckets first: the order every rank issues its collectives in, whether or
             if i not in self.pending:                      # not it started a bucket early
                 self.start(i)
         gnorm2 = None
+        for st in self.stamps.values():
+            st[2] = tm
         for i, (lo_r, n) in enumerate(self.ranges()):
             shard, work, ev = self.pending[i]
             if ev is not None:

@@ -514,6 +514,7 @@ class FullBatchTrainer:
             from .parallel import BucketExchange, exchange_bounds, shard_ops
             exchange = BucketExchange(eng.avg, eng.theta, self.shard, shard_ops(self, lr, 0.0 if mod in ("LARS", "LARC") else None),
                                       exchange_bounds(self))
+            self._last_exchange = exchange
             if self.shard.count > 0 and os.environ.get("FB_EXCHANGE_OVERLAP", "1") != "0":
                 late = (exchange.bounds[1], lambda: exchange.start(1))
 

@@ -120,8 +120,15 @@ def test_rccl_collectives_one_rank(tmp_path, monkeypatch):
         assert np.allclose(got["stats"]["grad_norm"], ref["stats"]["grad_norm"], rtol=0 if mode is False else 1e-6), mode
         # p.grad = the CLIPPED mean gradient: the clip norm is the sum of the exchange's two bucket norms here and one reduction over the
         # whole arena in the plain step -- the same number up to the association of the last addition, i.e. the scale may differ by one ulp
-        for a, b in zip(got["grads"], ref["grads"]):
-            assert torch.allclose(a, b, rtol=5e-7, atol=0), mode
+        if "gradreg" not in str(mode):
+            for a, b in zip(got["grads"], ref["grads"]):
+                assert torch.allclose(a, b, rtol=5e-7, atol=0), mode
+        else:
+            # ... and with the regulariser that ulp is in theta after the first real update (step 2), and the finite-difference quotient of step 3
+            # amplifies it by 1 / eps_n ~ 1e4 (tools/scratch/rccl1_probe.py: 1.1e-2 on p.grad with bf16x6 whatever the overlap / replay / stream
+            # switches; bit-identical when the two clip norms happen to round alike, as they do with f16x2).  NaN from a poisoned slice fails either way
+            a, b = (torch.cat([t.reshape(-1) for t in side["grads"]]).double() for side in (got, ref))
+            assert bool(torch.isfinite(a).all()) and float((a - b).norm() / b.norm()) < 3e-2, mode
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL wants one device per rank")
