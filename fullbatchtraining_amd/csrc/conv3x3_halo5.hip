@@ -55,6 +55,10 @@ constexpr int H5_W = 32, H5_TH = 8, H5_PITCH = 34, H5_ROWS = (H5_TH + 2) * H5_PI
 constexpr int H5_NGRP = (H5_ROWS + 7) / 8;                                             // 43 groups of 1 KiB
 constexpr int H5_HALO_BYTES = H5_NGRP * 1024, H5_WT_BYTES = 64 * 128, H5_WGT_BYTES = 9 * H5_WT_BYTES;
 constexpr int H5_KH = (H5_NGRP + 3) / 4;                                               // halo pieces per wave (11; wave 3: 10)
+#ifndef FB_H5_ADD_DEPTH
+#define FB_H5_ADD_DEPTH 3                                   // epilogue operands (addend / BST x) are requested this many pixel fragments ahead
+#endif
+constexpr int H5_AD = FB_H5_ADD_DEPTH, H5_ADN = H5_AD + 1; // ring of H5_ADN register sets
 }  // namespace
 
 // MODE 0: forward (BN partial sums), MODE 1: input gradient (flipped taps; ADD 1: + addend of the same shape, ADD 2: + addend where
@@ -146,30 +150,30 @@ __global__ __launch_bounds__(256) void conv3x3s1_c64_halo5_kernel(const Halo5Par
     float ssum[2][4], ssq[2][4];
     // addend (input gradient of the residual branch): loaded three pixel fragments (six batches) ahead of its use -- a load issued
     // where it is consumed would stall the whole in-order stream for an HBM round trip
-    h5_u32x2 ad[4][2];
-    unsigned adm[4];                                        // ADD == 2: the four mask bytes of this lane's pixel and channel half
-    h5_u32x2 bx[4][2];                                      // BST: x of the consuming BatchNorm, same positions as the outputs
-    unsigned bxm[4];
+    h5_u32x2 ad[H5_ADN][2];
+    unsigned adm[H5_ADN];                                   // ADD == 2: the four mask bytes of this lane's pixel and channel half
+    h5_u32x2 bx[H5_ADN][2];                                 // BST: x of the consuming BatchNorm, same positions as the outputs
+    unsigned bxm[H5_ADN];
     auto ad_issue = [&](auto jc, const int Lp) {
         constexpr int J = decltype(jc)::value;
         if constexpr (BST != 0 && J < 8) {
             const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bst_x + (long long)Lp * 256 * 128), 0, 256 * 128, 0x00020000);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) bx[J & 3][i] = __builtin_amdgcn_raw_buffer_load_b64(rsrcX, voffD + i * 32, J * 2048, 0);
+            for (int i = 0; i < 2; ++i) bx[J % H5_ADN][i] = __builtin_amdgcn_raw_buffer_load_b64(rsrcX, voffD + i * 32, J * 2048, 0);
             const __amdgpu_buffer_rsrc_t rsrcN = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bst_mask + (long long)Lp * 256 * 8), 0, 256 * 8, 0x00020000);
-            bxm[J & 3] = __builtin_amdgcn_raw_buffer_load_b32(rsrcN, ((ph * 128 + t) * 8 + ch * 4), J * 128, 0);
+            bxm[J % H5_ADN] = __builtin_amdgcn_raw_buffer_load_b32(rsrcN, ((ph * 128 + t) * 8 + ch * 4), J * 128, 0);
         }
         if constexpr (ADD != 0 && J < 8) {
             const __amdgpu_buffer_rsrc_t rsrcE = __builtin_amdgcn_make_buffer_rsrc((void*)(p.addend + (long long)Lp * 256 * 128), 0, 256 * 128, 0x00020000);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) ad[J & 3][i] = __builtin_amdgcn_raw_buffer_load_b64(rsrcE, voffD + i * 32, J * 2048, 0);
+            for (int i = 0; i < 2; ++i) ad[J % H5_ADN][i] = __builtin_amdgcn_raw_buffer_load_b64(rsrcE, voffD + i * 32, J * 2048, 0);
             if constexpr (ADD == 2) {
                 const __amdgpu_buffer_rsrc_t rsrcM = __builtin_amdgcn_make_buffer_rsrc((void*)(p.addend_mask + (long long)Lp * 256 * 8), 0, 256 * 8, 0x00020000);
-                adm[J & 3] = __builtin_amdgcn_raw_buffer_load_b32(rsrcM, ((ph * 128 + t) * 8 + ch * 4), J * 128, 0);
+                adm[J % H5_ADN] = __builtin_amdgcn_raw_buffer_load_b32(rsrcM, ((ph * 128 + t) * 8 + ch * 4), J * 128, 0);
             }
         }
     };
-    auto epi_prefetch = [&](const int Lp) { h5_static_for<0, 3>([&](auto jc) { ad_issue(jc, Lp); }); };
+    auto epi_prefetch = [&](const int Lp) { h5_static_for<0, H5_AD>([&](auto jc) { ad_issue(jc, Lp); }); };
     auto epi_slice = [&](auto sc, f32x4_t (&accp)[2][8], const int Lp) {
         constexpr int S = decltype(sc)::value;
         if constexpr (S < 16) {
@@ -190,11 +194,11 @@ __global__ __launch_bounds__(256) void conv3x3s1_c64_halo5_kernel(const Halo5Par
                 for (int i = 0; i < 2; ++i) {
                     float v[4] = {accp[i][J][0], accp[i][J][1], accp[i][J][2], accp[i][J][3]};
                     if constexpr (ADD != 0) {
-                        h5_u32x2 a = ad[J & 3][i];
+                        h5_u32x2 a = ad[J % H5_ADN][i];
                         if constexpr (ADD == 2) {
                             // mask byte k = 2i + (g >> 1) of the loaded word covers channels 8k..8k+7 of this wave's 32; this lane's
                             // four channels are its low (g even) or high (g odd) nibble.  v_bfe_i32 turns a bit into an all-ones mask.
-                            const unsigned bits = adm[J & 3] >> ((2 * i + (g >> 1)) * 8 + (g & 1) * 4);
+                            const unsigned bits = adm[J % H5_ADN] >> ((2 * i + (g >> 1)) * 8 + (g & 1) * 4);
                             const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 0, 1), m1 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 1, 1);
                             const unsigned m2 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 2, 1), m3 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 3, 1);
                             a[0] &= (m0 & 0x0000ffffu) | (m1 & 0xffff0000u);
@@ -206,10 +210,10 @@ __global__ __launch_bounds__(256) void conv3x3s1_c64_halo5_kernel(const Halo5Par
                     pk[i][0] = pack_bf16x2(v[0], v[1]); pk[i][1] = pack_bf16x2(v[2], v[3]);
                     if constexpr (BST != 0) {
                         // g = the STORED bf16 value where the consuming BatchNorm's ReLU passed; sums of g and of g * x
-                        const unsigned bits = bxm[J & 3] >> ((2 * i + (g >> 1)) * 8 + (g & 1) * 4);
+                        const unsigned bits = bxm[J % H5_ADN] >> ((2 * i + (g >> 1)) * 8 + (g & 1) * 4);
                         const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 0, 1), m1 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 1, 1);
                         const unsigned m2 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 2, 1), m3 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 3, 1);
-                        const h5_u32x2 xv = bx[J & 3][i];
+                        const h5_u32x2 xv = bx[J % H5_ADN][i];
                         const float g0 = __uint_as_float((pk[i][0] << 16) & m0), g1 = __uint_as_float(pk[i][0] & 0xffff0000u & m1);
                         const float g2 = __uint_as_float((pk[i][1] << 16) & m2), g3 = __uint_as_float(pk[i][1] & 0xffff0000u & m3);
                         ssum[i][0] += g0; ssum[i][1] += g1; ssum[i][2] += g2; ssum[i][3] += g3;
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(256) void conv3x3s1_c64_halo5_kernel(const Halo5Par
                 const h5_u32x4 outv = {lo[0], hi[0], lo[1], hi[1]};
                 __builtin_amdgcn_raw_buffer_store_b128(outv, rsrcD, voffS, J * 2048, 0);
                 store_b128_guard(outv);
-                ad_issue(std::integral_constant<int, J + 3>{}, Lp);
+                ad_issue(std::integral_constant<int, J + H5_AD>{}, Lp);
             }
         } else if constexpr (S == 16) {
             if constexpr (MODE == 0 || BST != 0) {

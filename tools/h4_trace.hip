@@ -5,6 +5,7 @@ long long* g_h4_trace = nullptr;
 #include "../fullbatchtraining_amd/csrc/conv3x3_halo4.hip"
 thread_local char fb_err_buf[512] = "";                    // (the library's runtime.cpp is not linked into this tool)
 bool fb_f32_split_enabled() { return true; }
+int fb_persistent_cus() { return 256; }
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
