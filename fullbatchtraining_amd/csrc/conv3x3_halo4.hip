@@ -585,7 +585,11 @@ int fb_try_conv3x3_halo4(const fb_conv_args* a, hipStream_t st) {
     extern long long* g_h4_trace;
     p.trace = g_h4_trace;
 #endif
-    dim3 grid(p.n_tiles < 2 * n_cu ? p.n_tiles : 2 * n_cu);
+    // (FB_H4_WG_PER_CU=1: one resident workgroup per CU instead of two -- leaves half of every CU's registers and LDS to a kernel of another
+    // stream; A/B switch of the co-scheduling experiments, profiles/r4_notes.md)
+    static const int wg_per_cu = getenv("FB_H4_WG_PER_CU") ? atoi(getenv("FB_H4_WG_PER_CU")) : 2;
+    const int slots = (wg_per_cu == 1 ? 1 : 2) * n_cu;
+    dim3 grid(p.n_tiles < slots ? p.n_tiles : slots);
     if (a->bst_x) {
         dim3 grid1(p.n_tiles < n_cu ? p.n_tiles : n_cu);
         if (wide && W == 16) hipLaunchKernelGGL((conv3x3s1_halo4_kernel<bf16_tag, 16, 8, true>), grid1, dim3(256), 0, st, p);

@@ -57,6 +57,15 @@ def main():
     cases = {"conv 256->256 8x8 fwd": conv_case(256, 256, 8), "conv 128->128 16x16 fwd": conv_case(128, 128, 16), "conv 512->512 4x4 fwd": conv_case(512, 512, 4),
              "conv 64->64 32x32 fwd": conv_case(64, 64, 32), "wgrad 256 8x8": wgrad_case(256, 8), "wgrad 128 16x16": wgrad_case(128, 16)}
     bns = {"bn_apply C64 32x32": bn_case(64, 32), "bn_apply C128 16x16": bn_case(128, 16)}
+    if os.environ.get("PROBE_CONVS"):
+        cases = {k: v for k, v in cases.items() if k.startswith("conv") and "64->64" not in k}
+        # two convolutions on two streams (what two half-group lanes would run when both are in an MFMA-bound kernel)
+        c1, c2 = conv_case(128, 128, 16), conv_case(128, 128, 16)
+        for f in (c1, c2):
+            f()
+        ta = region([c1], [s1], 10)
+        tab = region([c1, c2], [s1, s2], 10)
+        print(f"two conv 128->128 16x16 fwd on two streams: alone {ta:.0f} us, pair {tab:.0f} us (2 x alone = {2 * ta:.0f})")
     print("| MFMA-side kernel | alone us | HBM-side kernel | alone us | both, per pair us | sum | hidden |\n|---|---|---|---|---|---|---|")
     for cn, cf in cases.items():
         for bn, bf in bns.items():
