@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 enum { FB_PROF_IGEMM_FWD = 0, FB_PROF_IGEMM_DGRAD = 1, FB_PROF_WGRAD = 2, FB_PROF_BN_APPLY = 3, FB_PROF_BN_BWD_REDUCE = 4, FB_PROF_BN_BWD_APPLY = 5,
-       FB_PROF_CLASSES = 6 };
+       FB_PROF_BN_BWD_FUSED = 6, FB_PROF_CLASSES = 7 };
 // shape words filed with a launch (fb_profile_read_launches): convolutions {n_img, Hs, Ws, Cs, Hd, Wd, Cd, R, stride, flags, kernel};
 // BatchNorm passes {pixels / 128, C, pixels_per_group / 128, dtype, residual?, mask?, dy_out?, pooled?, 0, 0, kernel}
 enum { FB_PROF_INFO = 11 };

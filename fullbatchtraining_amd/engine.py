@@ -329,6 +329,15 @@ class Engine:
         self.fuse_bwd_stat = os.environ.get("FB_FUSED_BWD_STAT", "0") != "0"     # BN-backward reduction in the input-gradient epilogues: built, parity-tested,
         # measured SLOWER at step level (profiles/r2_notes.md: the separate HBM-bound reduction overlaps the weight-gradient stream) -> off
         self.bst_done = False
+        # BatchNorm backward in one pass over (dout, x) with a chunk's operands held in registers by a resident cluster of workgroups
+        # (csrc/bn_bwd_fused.hip): built, parity-tested, and measured SLOWER than reduce -> finalize -> apply (2.1 vs 1.27 ms on the 64-channel layer:
+        # eight waves per CU pulling 128 KiB bursts reach 2.8 TB/s even without the waits -- profiles/r4_notes.md) -> off; FB_BN_BWD_FUSED=1 selects it
+        self.bn_fused = os.environ.get("FB_BN_BWD_FUSED", "0") == "1"
+        # partial rows: (vectors of the tensor / 4096) x 2C floats, whatever the grouping -- sized for the largest layer of a full group
+        es = torch.empty((), dtype=self.dt).element_size()
+        self.bnf_ws = torch.empty(max((self.G * chunk * L.hout * L.wout * L.cout * es // 16 // 4096 * 2 + 4 * self.G) * L.cout for L in self.plan.layers) + 64,
+                                  device=self.device, dtype=torch.float32)
+        self.bnf_sync = torch.zeros(int(lib.load().fb_ws_bn_bwd_fused_ints(self.G)), device=self.device, dtype=torch.int32)
         # weight gradients depend on nothing downstream in the backward chain: they run on their own stream, overlapping the
         # HBM-bound BN backward kernels and the dgrad convolutions of the main stream (FB_WGRAD_STREAM=0: same stream)
         self.wstream = torch.cuda.Stream(device=self.device) if os.environ.get("FB_WGRAD_STREAM", "1") != "0" else None
@@ -684,6 +693,18 @@ class Engine:
         ppg = self.chunk * L.hout * L.wout
         bits = self.masks.get(mask.data_ptr()) if mask is not None else None      # bitmask written by the forward bn_apply
         y = None if bits is not None else mask
+        dx = self.pool.get((n, L.hout, L.wout, L.cout))
+        dy = self.pool.get((n, L.hout, L.wout, L.cout)) if want_dy else None
+        if (not reduced and y is None and self.bn_fused and self.f32_split != "f16x2"
+                and lib.load().fb_bn_bwd_fused_supported(px, L.cout, ppg, self.dtc)):
+            # one pass over (dout, x): a resident cluster of workgroups holds a chunk's operands in registers between the reduction and the
+            # apply step (csrc/bn_bwd_fused.hip) -- 3 tensor passes instead of the 5 of reduce -> finalize -> apply below
+            if int(lib.load().fb_ws_bn_bwd_fused_floats(px, L.cout, ppg, self.dtc)) > self.bnf_ws.numel():
+                raise lib.EngineError("fb_bn_bwd_fused: partial-row scratch too small for this launch")
+            call("fb_bn_bwd_fused", dout.data_ptr(), _ptr(bits), L.x.data_ptr(), self.mean_tab[pidx].data_ptr(), L.invstd.data_ptr(), L.scale.data_ptr(),
+                 self.plan.ch_total, L.ch_off, gout.data_ptr() + 4 * L.g_off, gout.data_ptr() + 4 * L.b_off, self.plan.P, L.coef.data_ptr(),
+                 dx.data_ptr(), _ptr(dy), px, L.cout, ppg, float(self.valid * L.hout * L.wout), self.dtc, self.bnf_ws.data_ptr(), self.bnf_sync.data_ptr())
+            return dx, dy
         if reduced:
             n_mblocks = px // 128
         else:
@@ -693,8 +714,6 @@ class Engine:
         call("fb_bn_bwd_finalize", self.stat_ws.data_ptr(), n_mblocks, G, L.cout, float(self.valid * L.hout * L.wout), L.scale.data_ptr(),
              self.mean_tab[pidx].data_ptr(), L.invstd.data_ptr(), self.plan.ch_total, L.ch_off,
              gout.data_ptr() + 4 * L.g_off, gout.data_ptr() + 4 * L.b_off, self.plan.P, L.coef.data_ptr(), 1 if reduced else 0)
-        dx = self.pool.get((n, L.hout, L.wout, L.cout))
-        dy = self.pool.get((n, L.hout, L.wout, L.cout)) if want_dy else None
         call("fb_bn_bwd_apply", dout.data_ptr(), _ptr(y), _ptr(bits), L.x.data_ptr(), L.coef.data_ptr(), dx.data_ptr(), _ptr(dy), px, L.cout, ppg,
              self.dtc, *((self._amax_slot(dx, px * L.cout), self.amax_ws.data_ptr()) if self.f32_split == "f16x2" else (None, None)))
         return dx, dy
@@ -1067,6 +1086,13 @@ class Engine:
         if overlap:
             torch.cuda.current_stream().wait_stream(self.wstream)
         return loss_all, correct_all, sq_all
+
+    def check_device_errors(self):
+        """Raises if a kernel left its sticky error word (fb_bn_bwd_fused: a cluster waited ~2 s for workgroups that never became resident)."""
+        if int(self.bnf_sync[-1]) != 0:
+            self.bnf_sync[-1] = 0
+            raise lib.EngineError("fb_bn_bwd_fused: a workgroup cluster timed out waiting for its reduction (results of that launch are invalid); "
+                                  "FB_BN_BWD_FUSED=0 selects the two-pass BatchNorm backward")
 
     def grad_and_param_sqnorm(self):
         """Device tensor [|avg|^2, |theta|^2] (clip norm, reference training.py:202-204; param_norm, :92)."""

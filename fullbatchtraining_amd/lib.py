@@ -47,6 +47,8 @@ _SIGS = {
     "fb_bn_bwd_finalize": [c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                            c_i64, c_void_p, c_int, c_void_p],
     "fb_bn_bwd_apply": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_void_p, c_void_p, c_void_p],
+    "fb_bn_bwd_fused": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p,
+                        c_i64, c_int, c_i64, c_double, c_int, c_void_p, c_void_p, c_void_p],
     "fb_stem_patches": [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                         C.POINTER(c_float), c_int, c_void_p],
     "fb_avgpool2_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
@@ -80,10 +82,10 @@ _SIGS = {
 }
 EXPORTS = tuple(_SIGS) + ("fb_last_error_string", "fb_abi_version", "fb_profile_enable", "fb_profile_read", "fb_ws_conv_stat_floats",
                           "fb_ws_wgrad_slab_floats", "fb_ws_bn_partial_floats", "fb_ws_mt_floats", "fb_bn_bwd_reduce_rows", "fb_conv_masked_addend_supported", "fb_conv_bwd_stat_supported",
-                          "fb_bn_apply_can_pool", "fb_ws_bn_amax_floats", "fb_profile_read_launches", "fb_cmd_fn_id", "fb_cmd_fn_nargs", "fb_event_new", "fb_event_count",
+                          "fb_bn_apply_can_pool", "fb_ws_bn_amax_floats", "fb_profile_read_launches", "fb_cmd_fn_id", "fb_cmd_fn_nargs", "fb_event_new", "fb_event_count", "fb_bn_bwd_fused_supported", "fb_ws_bn_bwd_fused_floats", "fb_ws_bn_bwd_fused_ints",
                           "fb_event_record", "fb_event_wait", "fb_cmdlist_create", "fb_cmdlist_destroy", "fb_cmdlist_size", "fb_cmdlist_add_call",
                           "fb_cmdlist_add_event", "fb_cmdlist_replay")
-PROF_CLASSES = ("igemm_fwd", "igemm_dgrad", "wgrad", "bn_apply", "bn_bwd_reduce", "bn_bwd_apply")
+PROF_CLASSES = ("igemm_fwd", "igemm_dgrad", "wgrad", "bn_apply", "bn_bwd_reduce", "bn_bwd_apply", "bn_bwd_fused")
 PROF_INFO = 11
 PROF_KERNELS = {0: "?", 1: "conv_igemm_kernel (register-staged)", 2: "conv_igemm_v3_kernel", 3: "conv3x3s1_halo4_kernel", 4: "conv3x3s1_c64_halo5_kernel",
                 5: "conv3x3s2_dgrad_quad_kernel", 6: "conv1x1_k32_kernel", 7: "conv1x1_stream_kernel", 8: "conv3x3s2_fwd_kernel",
@@ -154,6 +156,9 @@ def load():
         lib.fb_conv_bwd_stat_supported.argtypes, lib.fb_conv_bwd_stat_supported.restype = [C.POINTER(ConvArgs)], c_int
         lib.fb_ws_bn_amax_floats.argtypes, lib.fb_ws_bn_amax_floats.restype = [c_i64, c_int, c_i64], c_i64
         lib.fb_bn_apply_can_pool.argtypes, lib.fb_bn_apply_can_pool.restype = [c_int, c_int, c_i64, c_int], c_int
+        lib.fb_bn_bwd_fused_supported.argtypes, lib.fb_bn_bwd_fused_supported.restype = [c_i64, c_int, c_i64, c_int], c_int
+        lib.fb_ws_bn_bwd_fused_floats.argtypes, lib.fb_ws_bn_bwd_fused_floats.restype = [c_i64, c_int, c_i64, c_int], c_i64
+        lib.fb_ws_bn_bwd_fused_ints.argtypes, lib.fb_ws_bn_bwd_fused_ints.restype = [c_i64], c_i64
         lib.fb_cmd_fn_id.argtypes, lib.fb_cmd_fn_id.restype = [C.c_char_p], c_int
         lib.fb_cmd_fn_nargs.argtypes, lib.fb_cmd_fn_nargs.restype = [c_int], c_int
         lib.fb_event_new.argtypes, lib.fb_event_new.restype = [], c_int

@@ -697,6 +697,8 @@ class FullBatchTrainer:
                 done.synchronize()
                 self._finish_record(host, lr, train_time)
                 self._pinned.append(host)
+            if keep == 0:
+                self.engine.check_device_errors()
         finally:
             self._flushing = False
 

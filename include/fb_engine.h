@@ -200,6 +200,22 @@ int fb_bn_bwd_finalize(const float* partial, int32_t n_mblocks, int32_t n_groups
 int fb_bn_bwd_apply(const void* dout, const void* y, const void* mask, const void* x, const float* coef, void* dx, void* dy_out,
                     int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t dtype, float* amax_out, float* amax_ws, void* stream);
 
+/* The three calls above in ONE pass over (dout, x) (csrc/bn_bwd_fused.hip; autograd's native_batch_norm_backward + threshold_backward behind
+ * resnets.py:214-230): a cluster of workgroups that is resident as a whole keeps a statistics group's operands in registers between the
+ * reduction and the apply step -- 3 tensor passes instead of 5.  Same arithmetic as reduce / finalize / apply (fp32 sums per thread, partial
+ * rows added in fixed order in double, dx = c_dy*dy + c_x*x + c_0); the result does not depend on how many groups a launch holds.
+ * fb_bn_bwd_fused_supported(): 0 where the shape is not for it (a group's vectors must tile 4096-vector slices and its cluster must fit the
+ * device's 2 x #CU resident workgroups) -- the caller then takes the three-call form.  `partial`: fb_ws_bn_bwd_fused_floats() floats;
+ * `sync`: fb_ws_bn_bwd_fused_ints(n_groups) int32, ZEROED once by the caller (the last word is a sticky error flag: a wait of ~2 s -- a
+ * cluster that never became resident -- sets it instead of hanging the device). */
+int32_t fb_bn_bwd_fused_supported(int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t dtype);
+int64_t fb_ws_bn_bwd_fused_floats(int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t dtype);
+int64_t fb_ws_bn_bwd_fused_ints(int64_t n_groups);
+int fb_bn_bwd_fused(const void* dout, const void* mask, const void* x, const float* mean_tab, const float* invstd, const float* scale,
+                    int32_t ch_total, int32_t ch_off, float* dgamma, float* dbeta, int64_t grad_group_stride, float* coef, void* dx,
+                    void* dy_out, int64_t n_pixels, int32_t C, int64_t pixels_per_group, double count, int32_t dtype, float* partial,
+                    int32_t* sync, void* stream);
+
 /* ---------------------------------------------------------------- data path --------------------------------------- */
 /* Stem patch gather: images [n_img][C][H][W] fp32 (device) -> patches [n_img][Ho][Wo][cin_pad] in `dtype`, element tap*C + c
  * (tap-major like the KRSC weights), zero beyond k*k*C and outside the image (the convolution's own zero padding); the stem

@@ -918,3 +918,67 @@ def test_head_tta_vs_reference_formula(n, classes):
     got_loss, got_correct = ws[2 * n:].tolist()
     assert abs(got_loss - float(loss_sum)) < 1e-5 * max(1.0, float(loss_sum)), (got_loss, float(loss_sum))
     assert got_correct == float(correct)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,hw,imgs,G", [(64, 16, 32, 5), (128, 8, 64, 3), (512, 2, 128, 4), (64, 32, 128, 3)])
+def test_bn_bwd_fused_equals_the_two_pass_form(dtype, C, hw, imgs, G):
+    """fb_bn_bwd_fused (one pass over (dout, x): a resident cluster of workgroups keeps a statistics group's operands in registers between the
+    reduction and the apply step; off by default -- it measured slower, profiles/r4_notes.md) against fb_bn_bwd_reduce -> finalize -> apply on
+    the same inputs: same masked gradient bit for bit, dx / dgamma / dbeta to fp32 rounding (the pixel partition of the sums differs), and
+    against torch's native_batch_norm_backward through autograd."""
+    lib = _lib()
+    handle = lib.load()
+    dtc = lib.dtype_code(dtype)
+    n = G * imgs
+    px, ppg = n * hw * hw, imgs * hw * hw
+    if not handle.fb_bn_bwd_fused_supported(px, C, ppg, dtc):
+        pytest.skip("shape not for the cluster kernel")
+    torch.manual_seed(C + hw)
+    eb = 4 if dtype == torch.float32 else 2
+    x = torch.randn(n, hw, hw, C, device="cuda").to(dtype)
+    dout = torch.randn(n, hw, hw, C, device="cuda").to(dtype)
+    gamma = torch.rand(C, device="cuda") + 0.5
+    xg = x.float().view(G, imgs * hw * hw, C)
+    mean, var = xg.mean(1), xg.var(1, unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    scale = gamma[None] * invstd
+    y = (xg - mean[:, None]) * scale[:, None] + 0.1                                  # the forward output whose ReLU mask the backward uses
+    keep = (y > 0)
+    bits = (keep.reshape(-1, 8).to(torch.int32) * (2 ** torch.arange(8, device="cuda", dtype=torch.int32))).sum(1).to(torch.uint8) if eb == 2 else \
+        (keep.reshape(-1, 4).to(torch.int32) * (2 ** torch.arange(4, device="cuda", dtype=torch.int32))).sum(1).to(torch.uint8)
+    out = {}
+    for mode in ("two-pass", "fused"):
+        dx, dy = torch.empty_like(x), torch.empty_like(x)
+        gout = torch.zeros(G, 2 * C, device="cuda")
+        coef = torch.zeros(G, C, 3, device="cuda")
+        if mode == "two-pass":
+            rows = handle.fb_bn_bwd_reduce_rows(px, ppg)
+            ws = torch.zeros(int(handle.fb_ws_bn_partial_floats(px, C)), device="cuda")
+            lib.call("fb_bn_bwd_reduce", dout.data_ptr(), None, bits.data_ptr(), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), C, 0, ws.data_ptr(), px, C, ppg, dtc)
+            lib.call("fb_bn_bwd_finalize", ws.data_ptr(), rows, G, C, float(ppg), scale.data_ptr(), mean.data_ptr(), invstd.data_ptr(), C, 0,
+                     gout.data_ptr(), gout.data_ptr() + 4 * C, 2 * C, coef.data_ptr(), 0)
+            lib.call("fb_bn_bwd_apply", dout.data_ptr(), None, bits.data_ptr(), x.data_ptr(), coef.data_ptr(), dx.data_ptr(), dy.data_ptr(), px, C, ppg, dtc, None, None)
+        else:
+            ws = torch.zeros(int(handle.fb_ws_bn_bwd_fused_floats(px, C, ppg, dtc)), device="cuda")
+            sync = torch.zeros(int(handle.fb_ws_bn_bwd_fused_ints(G)), device="cuda", dtype=torch.int32)
+            for _ in range(2):                                                       # (a second launch on the same workspace: counters and flags are re-armed)
+                lib.call("fb_bn_bwd_fused", dout.data_ptr(), bits.data_ptr(), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), C, 0,
+                         gout.data_ptr(), gout.data_ptr() + 4 * C, 2 * C, coef.data_ptr(), dx.data_ptr(), dy.data_ptr(), px, C, ppg, float(ppg), dtc,
+                         ws.data_ptr(), sync.data_ptr())
+            torch.cuda.synchronize()
+            assert int(sync[-1]) == 0, "a cluster timed out"
+        torch.cuda.synchronize()
+        out[mode] = (dx.float(), dy.float(), gout.clone())
+    a, b = out["fused"], out["two-pass"]
+    assert torch.equal(a[1], b[1])
+    tol = 1e-5 if dtype == torch.float32 else 6e-3                                   # bf16: one output rounding where a coefficient differs in its last bit
+    assert rel(a[0], b[0]) < tol and rel(a[2], b[2]) < 1e-5, (rel(a[0], b[0]), rel(a[2], b[2]))
+    # torch: d/dx and d/dgamma, d/dbeta of  relu-masked BatchNorm  with the same upstream gradient
+    xt = x.float().view(G, -1, C).clone().requires_grad_(True)
+    gm, bt = gamma.clone().requires_grad_(True), torch.full((C,), 0.1, device="cuda", requires_grad=True)
+    for g in range(G):
+        yt = torch.nn.functional.batch_norm(xt[g].t().reshape(1, C, -1), None, None, gm, bt, True, 0.0, 1e-5)
+        (yt * (dout.float().view(G, -1, C)[g] * keep[g]).t().reshape(1, C, -1)).sum().backward()
+    want = xt.grad.view_as(a[0])
+    assert rel(a[0], want) < (1e-4 if dtype == torch.float32 else 8e-3), rel(a[0], want)
