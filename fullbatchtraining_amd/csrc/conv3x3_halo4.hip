@@ -187,6 +187,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
         }
     };
 
+#ifdef FB_H4_BNFOLD_TIMING
+    // TIMING-ONLY experiment (round-4 verdict item 4; tools/build_variant.py bnfold -DFB_H4_BNFOLD_TIMING; the OUTPUT IS NOT the convolution of
+    // the normalised input: scale / shift are whatever p.stat holds): what BatchNorm + ReLU of the producing layer costs when it is applied to the
+    // staged halo slice in LDS, once per nine taps -- thread (row = tid / 8 + 32 k, octet = tid % 8) rewrites the 16-byte piece of its channel
+    // octet in every row that lies inside the image (zero padding must stay zero), 8 scale + 8 shift values per slice from global memory
+    constexpr int KF = (G::ROWS + 31) / 32;
+    unsigned bfA[KF];
+    if constexpr (std::is_same<T, bf16_tag>::value) {
+#pragma unroll
+        for (int k = 0; k < KF; ++k) {
+            const int row = (tid >> 3) + 32 * k, o = tid & 7;
+            const int rr = row % G::IMG_ROWS, hy = rr / PITCH, hx = rr % PITCH;
+            const bool ok = row < G::ROWS && hx >= 1 && hx <= W && hy >= 1 && hy <= G::TH;      // (W = 32: top / bottom rows of edge tiles ignored here)
+            bfA[k] = ok ? lds0 + row * 128 + ((o ^ (hx & 7)) * 16) : 0xffffffffu;
+        }
+    }
+    auto bn_fold = [&](int cc, int n0) {
+        if constexpr (std::is_same<T, bf16_tag>::value) {
+            const float* sp = (const float*)p.stat + ((n0 >> 7) & 1) * 2 * p.Cs + cc * 64 + (tid & 7) * 8;   // (per-chunk table in the real thing)
+            float sc[8], sh[8];
+            const float4 a0 = *(const float4*)sp, a1 = *(const float4*)(sp + 4), b0 = *(const float4*)(sp + p.Cs), b1 = *(const float4*)(sp + p.Cs + 4);
+            sc[0] = a0.x; sc[1] = a0.y; sc[2] = a0.z; sc[3] = a0.w; sc[4] = a1.x; sc[5] = a1.y; sc[6] = a1.z; sc[7] = a1.w;
+            sh[0] = b0.x; sh[1] = b0.y; sh[2] = b0.z; sh[3] = b0.w; sh[4] = b1.x; sh[5] = b1.y; sh[6] = b1.z; sh[7] = b1.w;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { sc[i] = 1.f + 1e-30f * fminf(fabsf(sc[i]), 1.f); sh[i] = 1e-30f * fminf(fabsf(sh[i]), 1.f); }   // (loaded values kept live; ~ReLU of the input)
+            h4_static_for<0, KF>([&](auto kc) {
+                constexpr int K = decltype(kc)::value;
+                if (bfA[K] != 0xffffffffu) {
+                    const uint4 v = h4_read16<0>(bfA[K]);
+                    h4_wait_lgkmcnt<0>();
+                    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+                    unsigned o[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float lo = fmaxf(fmaf(__uint_as_float(w[q] << 16), sc[2 * q], sh[2 * q]), 0.f);
+                        const float hi = fmaxf(fmaf(__uint_as_float(w[q] & 0xffff0000u), sc[2 * q + 1], sh[2 * q + 1]), 0.f);
+                        o[q] = pack_bf16x2(lo, hi);
+                    }
+                    h4_write16(bfA[K], make_uint4(o[0], o[1], o[2], o[3]));
+                }
+            });
+            h4_wait_lgkmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+        }
+    };
+#define H4_BN_FOLD(cc, n0) do { if (p.mode == 0 && p.stat != nullptr) bn_fold(cc, n0); } while (0)
+#else
+#define H4_BN_FOLD(cc, n0) do { } while (0)
+#endif
+
     // ---- tile bookkeeping (scalar; descriptors are rebuilt where they are needed to keep SGPR pressure low) ----------------
     auto decode = [&](int L) {
         H4Tile t;
@@ -267,6 +317,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
         h4_wait_vmcnt<0>();                                // halo slice 0 + weight taps 0, 1 (and the previous tile's stores)
         __builtin_amdgcn_s_barrier();
         convert_halo();
+        H4_BN_FOLD(0, cur.n0);
         H4_STAMP(2);
 
         f32x4_t acc[FI][4];
@@ -362,6 +413,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
                         h4_wait_vmcnt<0>();
                         __builtin_amdgcn_s_barrier();
                         convert_halo();
+                        H4_BN_FOLD(cc + 1, cur.n0);
                     } else if (has_next) {
                         halo_issue(nxt, 0);               // lands during the epilogue; the loop top waits for it
                     }
