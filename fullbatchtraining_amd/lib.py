@@ -10,7 +10,7 @@ import struct
 import torch
 
 FB_F32, FB_BF16 = 0, 1
-EXPECTED_ABI = 10         # fb_abi_version() the ctypes structs / signatures below were written for
+EXPECTED_ABI = 11         # fb_abi_version() the ctypes structs / signatures below were written for
 MT_BLOCKS = 1024
 _LIB_PATH = os.environ.get("FB_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libfbengine.so")     # (FB_LIB_PATH: A/B builds, tools/build_variant.py)
 
