@@ -19,6 +19,7 @@ struct WgradParams {
     int imgs_per_group, split_k, px_per_group, px_per_split;
     long long group_stride;                                 // floats between the slabs of consecutive groups
     const float* amax_x; const float* amax_dy;              // f32h (fp16x2 split): largest magnitudes of the two operand tensors
+    const char* bn_x; const unsigned char* bn_mask; const float* bn_coef;   // BNF: BatchNorm backward apply inside the dy loader
 };
 
 template <typename T> struct WG;
@@ -51,7 +52,9 @@ template <> __device__ __forceinline__ void load_frag_t<float>(const char* tile,
     out[1] = make_uint4(v[4], v[5], v[6], v[7]);
 }
 
-template <typename T, int WM, int WN, int WK, int KREP, int NJ>
+// BNF (bf16): the A operand is computed in the loader from (dout, x, ReLU bitmask, coefficients) -- the dx of fb_bn_bwd_apply, same fp32
+// expression, same rounding to bf16 -- instead of being read from memory (fb_wgrad_args.bn_x)
+template <typename T, int WM, int WN, int WK, int KREP, int NJ, bool BNF = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     constexpr int EB = ET<T>::EB;
     constexpr int TM = 64 * WM, TN = 16 * NJ * WN;     // block tile (co x ci); wave tile 64 x 16*NJ
@@ -97,13 +100,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     uint4 ra[LD_A], rb[LD_B];
+    uint4 rx[BNF ? LD_A : 1];                               // BNF: the BatchNorm input at the same positions
+    unsigned rm[BNF ? LD_A : 1];
+    float cf[BNF ? 24 : 1];                                 // BNF: three coefficients for each of this thread's 8 channels (one 16-byte chunk: tid % CH_A)
+    if constexpr (BNF) {
+        static_assert(EB == 2 && 256 % CH_A == 0, "BNF: bf16, fixed channel chunk per thread");
+        const float* c = p.bn_coef + ((long long)group * p.Cd + tile_m * TM + (tid % CH_A) * 8) * 3;
+#pragma unroll
+        for (int q = 0; q < 24; ++q) cf[q] = c[q];
+    }
     auto gload = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < LD_A; ++i) {
             const int id = tid + 256 * i, row = id / CH_A, ch = id % CH_A;
             const int k = k0 + row;
             ra[i] = make_uint4(0, 0, 0, 0);
-            if (k < k_end) ra[i] = *(const uint4*)(p.dy + ((gp0 + k) * p.Cd + tile_m * TM) * EB + ch * 16);
+            if constexpr (BNF) { rx[i] = make_uint4(0, 0, 0, 0); rm[i] = 0x100u; }       // (bit 8: a row beyond the slice contributes exactly zero)
+            if (k < k_end) {
+                const long long e = ((gp0 + k) * p.Cd + tile_m * TM) * EB + ch * 16;
+                ra[i] = *(const uint4*)(p.dy + e);
+                if constexpr (BNF) { rx[i] = *(const uint4*)(p.bn_x + e); rm[i] = p.bn_mask ? p.bn_mask[e >> 4] : 0xffu; }
+            }
         }
 #pragma unroll
         for (int i = 0; i < LD_B; ++i) {
@@ -139,7 +156,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
             }
         } else {
 #pragma unroll
-        for (int i = 0; i < LD_A; ++i) { const int id = tid + 256 * i, row = id / CH_A, ch = id % CH_A; *(uint4*)(tileA + row * ROW_A + ch * 16) = ra[i]; }
+        for (int i = 0; i < LD_A; ++i) {
+            const int id = tid + 256 * i, row = id / CH_A, ch = id % CH_A;
+            if constexpr (BNF) {                                 // dx = c_dy * dy + c_x * x + c_0 (fb_bn_bwd_apply), bf16
+                float d[8], xv[8], o[8];
+                ET<bf16_tag>::unpack(ra[i], d); ET<bf16_tag>::unpack(rx[i], xv);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float dy = ((rm[i] >> q) & 1u) ? d[q] : 0.f;
+                    o[q] = cf[3 * q] * dy + cf[3 * q + 1] * xv[q] + cf[3 * q + 2];
+                    if (rm[i] & 0x100u) o[q] = 0.f;
+                }
+                ra[i] = ET<bf16_tag>::pack(o);
+            }
+            *(uint4*)(tileA + row * ROW_A + ch * 16) = ra[i];
+        }
 #pragma unroll
         for (int i = 0; i < LD_B; ++i) { const int id = tid + 256 * i, row = id / CH_B, ch = id % CH_B; *(uint4*)(tileB + row * ROW_B + ch * 16) = rb[i]; }
         }
@@ -236,8 +267,16 @@ int fb_try_wgrad3x3(const fb_wgrad_args* a, hipStream_t st);      // conv_wgrad3
 int fb_try_wgrad3x3_v2(const fb_wgrad_args* a, hipStream_t st);   // conv_wgrad3x3_v2.hip
 int fb_try_wgrad1x1(const fb_wgrad_args* a, hipStream_t st);      // conv_wgrad1x1.hip
 
+// BatchNorm backward apply inside the loader: bf16, 1x1, the 64 x 32-channel tiles of the stem (register-staged operands)
+extern "C" int32_t fb_wgrad_bn_fused_supported(const fb_wgrad_args* a) {
+    static const bool disabled = getenv("FB_DISABLE_WGRAD_BNF") != nullptr;
+    return !disabled && a && a->dtype == FB_BF16 && a->R == 1 && a->S == 1 && a->stride == 1 && a->pad == 0 && a->Cs % 32 == 0 && a->Cs % 64 != 0
+           && a->Cd % 64 == 0 && a->Hs == a->Hd && a->Ws == a->Wd;
+}
+
 extern "C" int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream) {
     if (!a || !a->x || !a->dy || !a->dw_partial) FB_FAIL(FB_ERR_ARG, "fb_conv2d_wgrad: null pointer");
+    if (a->bn_x && (!a->bn_coef || !fb_wgrad_bn_fused_supported(a))) FB_FAIL(FB_ERR_UNSUPPORTED, "fb_conv2d_wgrad: bn_x (BatchNorm apply in the loader) is for bf16 1x1 layers with Cs < 64 and needs bn_coef");
     if (a->Cs % 32 != 0 || a->Cd % 64 != 0) FB_FAIL(FB_ERR_SHAPE, "fb_conv2d_wgrad: Cs=%d must be a multiple of 32, Cd=%d of 64", a->Cs, a->Cd);
     if (a->n_img % a->imgs_per_group != 0) FB_FAIL(FB_ERR_SHAPE, "fb_conv2d_wgrad: n_img %% imgs_per_group != 0");
     if (a->split_k < 1) FB_FAIL(FB_ERR_ARG, "fb_conv2d_wgrad: split_k < 1");
@@ -249,6 +288,7 @@ extern "C" int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream) {
     p.group_stride = a->group_stride ? a->group_stride : (long long)a->split_k * a->Cd * a->R * a->S * a->Cs;
     p.px_per_group = a->imgs_per_group * a->Hd * a->Wd;
     p.amax_x = a->dtype == FB_F32 ? a->amax_x : nullptr; p.amax_dy = a->dtype == FB_F32 ? a->amax_dy : nullptr;
+    p.bn_x = (const char*)a->bn_x; p.bn_mask = (const unsigned char*)a->bn_mask; p.bn_coef = a->bn_coef;
     if ((p.amax_x == nullptr) != (p.amax_dy == nullptr)) FB_FAIL(FB_ERR_ARG, "fb_conv2d_wgrad: amax_x and amax_dy go together");
     const bool hsplit = p.amax_x != nullptr;
     const int n_groups = a->n_img / a->imgs_per_group;
@@ -260,7 +300,10 @@ extern "C" int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream) {
     const bool split = fb_f32_split_enabled();
     const int32_t info[FB_PROF_INFO] = {a->n_img, a->Hs, a->Ws, a->Cs, a->Hd, a->Wd, a->Cd, a->R, a->stride, a->split_k | (a->dtype << 16), FB_K_WGRAD_GENERIC};
     const int prof = fb_prof_begin(FB_PROF_WGRAD, st, info);
-    if (fb_try_wgrad3x3_v2(a, st)) { fb_prof_kernel(prof, FB_K_WGRAD3X3_V2);
+    if (a->bn_x) {
+        dim3 grid((a->Cd / 64) * (a->Cs / 32), taps, n_groups * a->split_k);
+        hipLaunchKernelGGL((conv_wgrad_kernel<bf16_tag, 1, 1, 4, 1, 2, true>), grid, dim3(256), 0, st, p);
+    } else if (fb_try_wgrad3x3_v2(a, st)) { fb_prof_kernel(prof, FB_K_WGRAD3X3_V2);
     } else if (fb_try_wgrad3x3(a, st)) { fb_prof_kernel(prof, FB_K_WGRAD3X3_V1);
     } else if (fb_try_wgrad1x1(a, st)) { fb_prof_kernel(prof, FB_K_WGRAD1X1);
     } else if (big) {

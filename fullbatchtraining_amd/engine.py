@@ -684,18 +684,19 @@ class Engine:
         return a
 
     # ----------------------------------------------------------------------------------------------------- backward --
-    def _bn_bwd(self, L, dout, mask, G, gout, pidx, want_dy, reduced=False):
+    def _bn_bwd(self, L, dout, mask, G, gout, pidx, want_dy, reduced=False, apply=True):
         """BN (+ReLU mask) backward.  Returns (dx, dy_or_None); dgamma/dbeta go to gout[g] at the layer's arena offsets.  ``reduced``: the
         input-gradient convolution that produced ``dout`` has already left the 128-pixel-block sums of dy and dy*x in ``self.stat_ws`` (its
-        fused epilogue, ``_dgrad(bst=...)``), the reduction pass is skipped."""
+        fused epilogue, ``_dgrad(bst=...)``), the reduction pass is skipped.  ``apply=False``: reduction and coefficients only (``L.coef``) --
+        the consumer computes dx itself (``_wgrad(bn=...)``: the stem, whose input gradient nobody needs); returns (None, None)."""
         n = G * self.chunk
         px = n * L.hout * L.wout
         ppg = self.chunk * L.hout * L.wout
         bits = self.masks.get(mask.data_ptr()) if mask is not None else None      # bitmask written by the forward bn_apply
         y = None if bits is not None else mask
-        dx = self.pool.get((n, L.hout, L.wout, L.cout))
+        dx = self.pool.get((n, L.hout, L.wout, L.cout)) if apply else None
         dy = self.pool.get((n, L.hout, L.wout, L.cout)) if want_dy else None
-        if (not reduced and y is None and self.bn_fused and self.f32_split != "f16x2"
+        if (apply and not reduced and y is None and self.bn_fused and self.f32_split != "f16x2"
                 and lib.load().fb_bn_bwd_fused_supported(px, L.cout, ppg, self.dtc)):
             # one pass over (dout, x): a resident cluster of workgroups holds a chunk's operands in registers between the reduction and the
             # apply step (csrc/bn_bwd_fused.hip) -- 3 tensor passes instead of the 5 of reduce -> finalize -> apply below
@@ -714,14 +715,27 @@ class Engine:
         call("fb_bn_bwd_finalize", self.stat_ws.data_ptr(), n_mblocks, G, L.cout, float(self.valid * L.hout * L.wout), L.scale.data_ptr(),
              self.mean_tab[pidx].data_ptr(), L.invstd.data_ptr(), self.plan.ch_total, L.ch_off,
              gout.data_ptr() + 4 * L.g_off, gout.data_ptr() + 4 * L.b_off, self.plan.P, L.coef.data_ptr(), 1 if reduced else 0)
+        if not apply:
+            return None, None
         call("fb_bn_bwd_apply", dout.data_ptr(), _ptr(y), _ptr(bits), L.x.data_ptr(), L.coef.data_ptr(), dx.data_ptr(), _ptr(dy), px, L.cout, ppg,
              self.dtc, *((self._amax_slot(dx, px * L.cout), self.amax_ws.data_ptr()) if self.f32_split == "f16x2" else (None, None)))
         return dx, dy
 
-    def _wgrad(self, L, src, dx, G, gout):
+    def _wgrad_bn_ok(self, L, mask):
+        """Can the weight gradient of L apply the BatchNorm backward of its own output itself (``fb_wgrad_args.bn_x``: no dx tensor)?"""
+        if os.environ.get("FB_WGRAD_BNF", "1") == "0" or self.dt != torch.bfloat16 or self.masks.get(mask.data_ptr()) is None:
+            return False
+        a = lib.WgradArgs(None, None, None, self.chunk, L.hin, L.win, L.cin_pad, L.hout, L.wout, L.cout, L.R, L.S, L.stride, L.pad, self.chunk, 1, self.dtc, 0)
+        return bool(lib.load().fb_wgrad_bn_fused_supported(lib.C.byref(a)))
+
+    def _wgrad(self, L, src, dx, G, gout, bn=None):
         """Weight gradient of layer L into gout[g] (per chunk).  Runs on the weight-gradient stream; the event of its completion
-        is kept in ``self._wgrad_event`` (callers hand it to the pool with ``dx`` and wait for it at the end of backward)."""
+        is kept in ``self._wgrad_event`` (callers hand it to the pool with ``dx`` and wait for it at the end of backward).
+        ``bn = (dout, mask_act)``: ``dx`` is not materialised -- the kernel computes it in its loader from the gradient w.r.t. the BatchNorm +
+        ReLU output, the layer's conv output ``L.x``, the ReLU bitmask and ``L.coef`` (``_bn_bwd(apply=False)`` has just written them)."""
         n = G * self.chunk
+        if bn is not None:
+            dx = bn[0]
         # one K slice and no channel padding: the kernel writes the per-chunk gradients straight into the arena rows
         direct = L.split_k == 1 and L.cin_pad == L.cin_real
         am_x = am_dy = None
@@ -736,7 +750,9 @@ class Engine:
                                                 gout.data_ptr() + 4 * (L.w_off + g0 * self.plan.P) if direct else self.slab_ws.data_ptr(), g_n * self.chunk,
                                                 L.hin, L.win, L.cin_pad, L.hout, L.wout, L.cout, L.R, L.S, L.stride, L.pad, self.chunk, L.split_k, self.dtc,
                                                 self.plan.P if direct else 0, am_x + 4 * g0 if am_x is not None else None,
-                                                am_dy + 4 * g0 if am_dy is not None else None)))
+                                                am_dy + 4 * g0 if am_dy is not None else None,
+                                                *((L.x.data_ptr() + i0 * L.hout * L.wout * L.cout * es, self.masks[bn[1].data_ptr()].data_ptr() + i0 * L.hout * L.wout * L.cout * es // 16,
+                                                   L.coef.data_ptr() + 4 * g0 * L.cout * 3) if bn is not None else (None, None, None)))))
 
         def launch():
             for g0, g_n, a in args:
@@ -857,10 +873,17 @@ class Engine:
             call("fb_maxpool3s2_bwd", self.stem_out.data_ptr(), d.data_ptr(), d_r.data_ptr(), n, S.hout, S.wout, 64, self.dtc)
             pool.put(d)
             d = d_r
-        dx, _ = self._bn_bwd(S, d, self.stem_out, G, gout, pidx, want_dy=False, reduced=d_reduced and not plan.stem_pool)
-        pool.put(d)
-        self._wgrad(S, patches, dx, G, gout)
-        pool.put(dx, event=self._wgrad_event)
+        if self._wgrad_bn_ok(S, self.stem_out) and not (d_reduced and not plan.stem_pool):
+            # the stem's input gradient is needed by nobody: its weight gradient applies the BatchNorm backward in its own loader (no dx tensor:
+            # one write and one read of the largest activation less per group)
+            self._bn_bwd(S, d, self.stem_out, G, gout, pidx, want_dy=False, apply=False)
+            self._wgrad(S, patches, None, G, gout, bn=(d, self.stem_out))
+            pool.put(d, event=self._wgrad_event)
+        else:
+            dx, _ = self._bn_bwd(S, d, self.stem_out, G, gout, pidx, want_dy=False, reduced=d_reduced and not plan.stem_pool)
+            pool.put(d)
+            self._wgrad(S, patches, dx, G, gout)
+            pool.put(dx, event=self._wgrad_event)
         if self.wstream is not None:                     # gout is complete (and the activations are free) after this point
             self.events.wait(self.events.record(self.wstream))
 

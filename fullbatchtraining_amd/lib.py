@@ -29,7 +29,8 @@ class WgradArgs(C.Structure):
     _fields_ = [("x", c_void_p), ("dy", c_void_p), ("dw_partial", c_void_p),
                 ("n_img", c_int), ("Hs", c_int), ("Ws", c_int), ("Cs", c_int), ("Hd", c_int), ("Wd", c_int), ("Cd", c_int),
                 ("R", c_int), ("S", c_int), ("stride", c_int), ("pad", c_int),
-                ("imgs_per_group", c_int), ("split_k", c_int), ("dtype", c_int), ("group_stride", c_i64), ("amax_x", c_void_p), ("amax_dy", c_void_p)]
+                ("imgs_per_group", c_int), ("split_k", c_int), ("dtype", c_int), ("group_stride", c_i64), ("amax_x", c_void_p), ("amax_dy", c_void_p),
+                ("bn_x", c_void_p), ("bn_mask", c_void_p), ("bn_coef", c_void_p)]
 
 
 _SIGS = {
@@ -82,7 +83,7 @@ _SIGS = {
 }
 EXPORTS = tuple(_SIGS) + ("fb_last_error_string", "fb_abi_version", "fb_profile_enable", "fb_profile_read", "fb_ws_conv_stat_floats",
                           "fb_ws_wgrad_slab_floats", "fb_ws_bn_partial_floats", "fb_ws_mt_floats", "fb_bn_bwd_reduce_rows", "fb_conv_masked_addend_supported", "fb_conv_bwd_stat_supported",
-                          "fb_bn_apply_can_pool", "fb_ws_bn_amax_floats", "fb_profile_read_launches", "fb_cmd_fn_id", "fb_cmd_fn_nargs", "fb_event_new", "fb_event_count", "fb_bn_bwd_fused_supported", "fb_ws_bn_bwd_fused_floats", "fb_ws_bn_bwd_fused_ints",
+                          "fb_bn_apply_can_pool", "fb_ws_bn_amax_floats", "fb_profile_read_launches", "fb_cmd_fn_id", "fb_cmd_fn_nargs", "fb_event_new", "fb_event_count", "fb_bn_bwd_fused_supported", "fb_ws_bn_bwd_fused_floats", "fb_ws_bn_bwd_fused_ints", "fb_wgrad_bn_fused_supported",
                           "fb_event_record", "fb_event_wait", "fb_cmdlist_create", "fb_cmdlist_destroy", "fb_cmdlist_size", "fb_cmdlist_add_call",
                           "fb_cmdlist_add_event", "fb_cmdlist_replay")
 PROF_CLASSES = ("igemm_fwd", "igemm_dgrad", "wgrad", "bn_apply", "bn_bwd_reduce", "bn_bwd_apply", "bn_bwd_fused")
@@ -159,6 +160,7 @@ def load():
         lib.fb_bn_bwd_fused_supported.argtypes, lib.fb_bn_bwd_fused_supported.restype = [c_i64, c_int, c_i64, c_int], c_int
         lib.fb_ws_bn_bwd_fused_floats.argtypes, lib.fb_ws_bn_bwd_fused_floats.restype = [c_i64, c_int, c_i64, c_int], c_i64
         lib.fb_ws_bn_bwd_fused_ints.argtypes, lib.fb_ws_bn_bwd_fused_ints.restype = [c_i64], c_i64
+        lib.fb_wgrad_bn_fused_supported.argtypes, lib.fb_wgrad_bn_fused_supported.restype = [C.POINTER(WgradArgs)], c_int
         lib.fb_cmd_fn_id.argtypes, lib.fb_cmd_fn_id.restype = [C.c_char_p], c_int
         lib.fb_cmd_fn_nargs.argtypes, lib.fb_cmd_fn_nargs.restype = [c_int], c_int
         lib.fb_event_new.argtypes, lib.fb_event_new.restype = [], c_int

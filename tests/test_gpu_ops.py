@@ -982,3 +982,43 @@ def test_bn_bwd_fused_equals_the_two_pass_form(dtype, C, hw, imgs, G):
         (yt * (dout.float().view(G, -1, C)[g] * keep[g]).t().reshape(1, C, -1)).sum().backward()
     want = xt.grad.view_as(a[0])
     assert rel(a[0], want) < (1e-4 if dtype == torch.float32 else 8e-3), rel(a[0], want)
+
+
+@pytest.mark.parametrize("cin_pad,hw,imgs,G,split", [(32, 32, 16, 3, 4), (160, 16, 8, 2, 2), (32, 8, 128, 2, 1)])
+def test_wgrad_with_the_batchnorm_apply_in_its_loader(cin_pad, hw, imgs, G, split):
+    """fb_wgrad_args.bn_x: the stem's weight gradient computes dx = c_dy * (dout masked) + c_x * x + c_0 (fb_bn_bwd_apply) in its operand loader
+    instead of reading a materialised dx: the same slabs as fb_bn_bwd_apply -> fb_conv2d_wgrad, bit for bit (same fp32 expression, same bf16
+    rounding), with and without a ReLU bitmask."""
+    lib = _lib()
+    handle = lib.load()
+    dt, dtc, C = torch.bfloat16, lib.dtype_code(torch.bfloat16), 64
+    n = G * imgs
+    px, ppg = n * hw * hw, imgs * hw * hw
+    torch.manual_seed(cin_pad + hw)
+    patches = torch.randn(n, hw, hw, cin_pad, device="cuda").to(dt)
+    x = torch.randn(n, hw, hw, C, device="cuda").to(dt)
+    dout = torch.randn(n, hw, hw, C, device="cuda").to(dt)
+    bits = torch.randint(0, 256, (x.numel() // 8,), device="cuda", dtype=torch.uint8)
+    coef = torch.randn(G, C, 3, device="cuda")
+    for mask in (bits, None):
+        dx = torch.empty_like(x)
+        lib.call("fb_bn_bwd_apply", dout.data_ptr(), None, mask.data_ptr() if mask is not None else None, x.data_ptr(), coef.data_ptr(), dx.data_ptr(), None, px, C, ppg,
+                 dtc, None, None)
+        slabs = []
+        for fused in (False, True):
+            slab = torch.zeros(G * split * C * cin_pad, device="cuda")
+            a = lib.WgradArgs(patches.data_ptr(), (dout if fused else dx).data_ptr(), slab.data_ptr(), n, hw, hw, cin_pad, hw, hw, C, 1, 1, 1, 0, imgs, split, dtc, 0,
+                              None, None, x.data_ptr() if fused else None, (mask.data_ptr() if mask is not None else None) if fused else None,
+                              coef.data_ptr() if fused else None)
+            if fused:
+                assert handle.fb_wgrad_bn_fused_supported(lib.C.byref(a))
+            lib.call("fb_conv2d_wgrad", lib.C.byref(a))
+            torch.cuda.synchronize()
+            slabs.append(slab)
+        assert bool(torch.isfinite(slabs[1]).all()) and float(slabs[0].abs().max()) > 0
+        assert torch.equal(slabs[0], slabs[1]), float((slabs[0] - slabs[1]).abs().max() / slabs[0].abs().max())
+    # a layer the loader form is not for is refused, not silently computed otherwise
+    a = lib.WgradArgs(x.data_ptr(), dout.data_ptr(), slabs[0].data_ptr(), n, hw, hw, 64, hw, hw, C, 1, 1, 1, 0, imgs, 1, dtc, 0, None, None, x.data_ptr(), None, coef.data_ptr())
+    assert not handle.fb_wgrad_bn_fused_supported(lib.C.byref(a))
+    with pytest.raises(lib.EngineError, match="bn_x"):
+        lib.call("fb_conv2d_wgrad", lib.C.byref(a))
