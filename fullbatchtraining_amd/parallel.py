@@ -217,12 +217,11 @@ def combine_running_stats(r0, r_local, plan, updates_per_chunk, momentum=0.1, gr
     s_local = r_local - (keep ** n_r[plan.rank]) * r0
     gathered = torch.empty(plan.world * s_local.numel(), device=s_local.device, dtype=s_local.dtype)
     dist.all_gather_into_tensor(gathered, s_local.reshape(-1).contiguous(), group=group)
-    gathered = gathered.view(plan.world, *s_local.shape)
-    out = (keep ** sum(n_r)) * r0
-    for r in range(plan.world):
-        after = sum(n_r[r + 1:])
-        out = out + (keep ** after) * gathered[r]
-    return out
+    gathered = gathered.view(plan.world, -1)
+    # out = keep^N r0 + sum_r keep^(updates after rank r) S_r : one weighted sum over the rank axis (weights evaluated in float64 on the host;
+    # two elementwise launches instead of 2 x world)
+    weights = torch.tensor([keep ** sum(n_r[r + 1:]) for r in range(plan.world)], dtype=s_local.dtype, device=s_local.device)
+    return (keep ** sum(n_r)) * r0 + (weights[:, None] * gathered).sum(0).view_as(r0)
 
 
 def bn_updates_per_chunk(hyp):
