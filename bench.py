@@ -274,7 +274,8 @@ def _launch_work(cls, w, stem):
     px128, c, _, dtype, res, mask, dy_out, pooled = w[:8]
     eb = 2 if dtype == 1 else 4
     elems = px128 * 128 * c
-    passes = {"bn_apply": 2 + res + 0.25 * pooled, "bn_bwd_reduce": 2, "bn_bwd_apply": 3 + dy_out}[cls]
+    # (backward passes: `res` = 1 marks the two-BatchNorm form -- one more tensor read by the reduction, one more read + one more written by the apply step)
+    passes = {"bn_apply": 2 + res + 0.25 * pooled, "bn_bwd_reduce": 2 + res, "bn_bwd_apply": 3 + dy_out + 2 * res, "bn_bwd_fused": 3 + dy_out}[cls]
     return 0.0, elems * eb * passes + (elems * eb / 16 if mask else 0), f"C{c} {px128 * 128} px", 0
 
 
@@ -284,7 +285,8 @@ def _kernel_table(launches, stem, n_steps):
     rows = {}
     for cls, words, ms in launches:
         flop, byts, shape, kernel = _launch_work(cls, words, stem)
-        name = lib.PROF_KERNELS.get(kernel, "?") if flop else {"bn_apply": "bn_apply_span_kernel", "bn_bwd_reduce": "bn_bwd_reduce_kernel", "bn_bwd_apply": "bn_bwd_apply_span_kernel"}[cls]
+        name = lib.PROF_KERNELS.get(kernel, "?") if flop else {"bn_apply": "bn_apply_span_kernel", "bn_bwd_reduce": "bn_bwd_reduce_kernel", "bn_bwd_apply": "bn_bwd_apply_span_kernel",
+                                                                   "bn_bwd_fused": "bn_bwd_fused_kernel"}[cls]
         r = rows.setdefault((name, cls, shape), [0, 0.0, 0.0, 0.0])
         r[0] += 1
         r[1] += ms

@@ -330,13 +330,17 @@ extern "C" int32_t fb_bn_bwd_reduce_rows(int64_t n_pixels, int64_t pixels_per_gr
     return (int32_t)((n_pixels + pb - 1) / pb);
 }
 
-template <typename T>
+// DUAL: TWO BatchNorms share the incoming gradient and its ReLU mask (a downsampling block: the BatchNorm of conv2 and the one of the shortcut
+// convolution both take the gradient of the block output): one pass over dout reduces for both -- sum dy is common, sum dy * xhat per BatchNorm.
+// Same thread / pixel order as the single form: each BatchNorm's sums are bit-identical to its own fb_bn_bwd_reduce.
+struct BnReduceB { const uint4* x; const float* invstd; float* partial; int ch_off; };
+template <typename T, bool DUAL = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint4* __restrict__ dout, const uint4* __restrict__ y,
                                                             const unsigned char* __restrict__ mask,
                                                             const uint4* __restrict__ x, const float* __restrict__ mean_tab,
                                                             const float* __restrict__ invstd, int ch_total, int ch_off,
                                                             float* __restrict__ partial, long long n_pixels, int C, long long ppg,
-                                                            int n_mblocks, int PB) {
+                                                            int n_mblocks, int PB, const BnReduceB B) {
     constexpr int V = ET<T>::VEC;
     extern __shared__ float sm[];   // [rows][C][2]
     const int cvec = C / V;
@@ -358,9 +362,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint4* __restr
         rows = 256 / cvec;
         const int cv = threadIdx.x % cvec, row = threadIdx.x / cvec, c0 = cv * V;
         float mu[V], is[V], s1[V], s2[V];
+        float muB[DUAL ? V : 1], isB[DUAL ? V : 1], s2B[DUAL ? V : 1];
 #pragma unroll
         for (int k = 0; k < V; ++k) { mu[k] = mean_tab[g * ch_total + ch_off + c0 + k]; is[k] = invstd[g * C + c0 + k]; s1[k] = 0.f; s2[k] = 0.f; }
-        auto one = [&](const uint4& dr, const uint4& xr, unsigned mk) {
+        if constexpr (DUAL) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) { muB[k] = mean_tab[g * ch_total + B.ch_off + c0 + k]; isB[k] = B.invstd[g * C + c0 + k]; s2B[k] = 0.f; }
+        }
+        auto one = [&](const uint4& dr, const uint4& xr, const uint4& xbr, unsigned mk) {
             float d[V], xv[V];
             ET<T>::unpack(dr, d); ET<T>::unpack(xr, xv);
 #pragma unroll
@@ -368,20 +377,36 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint4* __restr
                 const float dy = ((mk >> k) & 1u) ? d[k] : 0.f;
                 s1[k] += dy; s2[k] += dy * ((xv[k] - mu[k]) * is[k]);
             }
+            if constexpr (DUAL) {
+                float xb[V];
+                ET<T>::unpack(xbr, xb);
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    const float dy = ((mk >> k) & 1u) ? d[k] : 0.f;
+                    s2B[k] += dy * ((xb[k] - muB[k]) * isB[k]);
+                }
+            }
         };
         const long long hi = p1 * cvec;
         long long i = p0 * cvec + threadIdx.x;
         for (; i + (BN_SPAN_U - 1) * 256 < hi; i += BN_SPAN_U * 256) {
-            uint4 dr[BN_SPAN_U], xr[BN_SPAN_U];
+            uint4 dr[BN_SPAN_U], xr[BN_SPAN_U], xbr[BN_SPAN_U];
             unsigned mk[BN_SPAN_U];
 #pragma unroll
-            for (int u = 0; u < BN_SPAN_U; ++u) { dr[u] = ld_reduce(dout + i + u * 256); xr[u] = ld_reduce(x + i + u * 256); mk[u] = mask_at(i + u * 256); }
+            for (int u = 0; u < BN_SPAN_U; ++u) {
+                dr[u] = ld_reduce(dout + i + u * 256); xr[u] = ld_reduce(x + i + u * 256); mk[u] = mask_at(i + u * 256);
+                if constexpr (DUAL) xbr[u] = ld_reduce(B.x + i + u * 256); else xbr[u] = xr[u];
+            }
 #pragma unroll
-            for (int u = 0; u < BN_SPAN_U; ++u) one(dr[u], xr[u], mk[u]);
+            for (int u = 0; u < BN_SPAN_U; ++u) one(dr[u], xr[u], xbr[u], mk[u]);
         }
-        for (; i < hi; i += 256) one(dout[i], x[i], mask_at(i));
+        for (; i < hi; i += 256) { if constexpr (DUAL) one(dout[i], x[i], B.x[i], mask_at(i)); else one(dout[i], x[i], x[i], mask_at(i)); }
 #pragma unroll
         for (int k = 0; k < V; ++k) { sm[(row * C + c0 + k) * 2] = s1[k]; sm[(row * C + c0 + k) * 2 + 1] = s2[k]; }
+        if constexpr (DUAL) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) sm[2 * rows * C + row * C + c0 + k] = s2B[k];          // [rows][C] behind the [rows][C][2] table
+        }
     } else {                        // channel counts whose vectors do not divide the workgroup: one sub-row, channel loop
         rows = 256 / cvec > 0 ? 256 / cvec : 1;
         const int lanes = cvec < 256 ? cvec : 256;
@@ -414,6 +439,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint4* __restr
         for (int r = 0; r < rows; ++r) { a += sm[(r * C + c) * 2]; b += sm[(r * C + c) * 2 + 1]; }
         partial[(long long)blockIdx.x * C + c] = a;
         partial[((long long)n_mblocks + blockIdx.x) * C + c] = b;
+        if constexpr (DUAL) {
+            float bb = 0.f;
+            for (int r = 0; r < rows; ++r) bb += sm[2 * rows * C + r * C + c];
+            B.partial[(long long)blockIdx.x * C + c] = a;
+            B.partial[((long long)n_mblocks + blockIdx.x) * C + c] = bb;
+        }
     }
 }
 
@@ -433,12 +464,37 @@ extern "C" int fb_bn_bwd_reduce(const void* dout, const void* y, const void* mas
     const int prof = fb_prof_begin(FB_PROF_BN_BWD_REDUCE, (hipStream_t)stream, info);
     if (dtype == FB_F32)
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<float>), dim3(n_mblocks), dim3(256), smem, (hipStream_t)stream, (const uint4*)dout, (const uint4*)y,
-                           (const unsigned char*)mask, (const uint4*)x, mean_tab, invstd, ch_total, ch_off, partial, (long long)n_pixels, C, (long long)pixels_per_group, n_mblocks, PB);
+                           (const unsigned char*)mask, (const uint4*)x, mean_tab, invstd, ch_total, ch_off, partial, (long long)n_pixels, C, (long long)pixels_per_group, n_mblocks, PB, BnReduceB{});
     else
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_tag>), dim3(n_mblocks), dim3(256), smem, (hipStream_t)stream, (const uint4*)dout, (const uint4*)y,
-                           (const unsigned char*)mask, (const uint4*)x, mean_tab, invstd, ch_total, ch_off, partial, (long long)n_pixels, C, (long long)pixels_per_group, n_mblocks, PB);
+                           (const unsigned char*)mask, (const uint4*)x, mean_tab, invstd, ch_total, ch_off, partial, (long long)n_pixels, C, (long long)pixels_per_group, n_mblocks, PB, BnReduceB{});
     fb_prof_end(prof, (hipStream_t)stream);
     FB_CHECK_LAUNCH("fb_bn_bwd_reduce");
+    return FB_OK;
+}
+
+extern "C" int fb_bn_bwd_reduce2(const void* dout, const void* mask, const void* x_a, const float* invstd_a, int32_t ch_off_a, float* partial_a,
+                                 const void* x_b, const float* invstd_b, int32_t ch_off_b, float* partial_b, const float* mean_tab, int32_t ch_total,
+                                 int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t dtype, void* stream) {
+    if (!dout || !x_a || !x_b || !mean_tab || !invstd_a || !invstd_b || !partial_a || !partial_b) FB_FAIL(FB_ERR_ARG, "fb_bn_bwd_reduce2: null pointer");
+    if (pixels_per_group % 128 != 0) FB_FAIL(FB_ERR_SHAPE, "fb_bn_bwd_reduce2: pixels_per_group=%lld must be a multiple of 128", (long long)pixels_per_group);
+    const int V = dtype == FB_F32 ? 4 : 8;
+    if (C % V != 0 || 256 % (C / V) != 0) FB_FAIL(FB_ERR_UNSUPPORTED, "fb_bn_bwd_reduce2: C=%d (the channel vectors of a pixel must divide 256)", C);
+    const int cvec = C / V, rows = 256 / cvec;
+    const int PB = bn_reduce_pixels(n_pixels, pixels_per_group);
+    const int n_mblocks = fb_bn_bwd_reduce_rows(n_pixels, pixels_per_group);
+    const size_t smem = (size_t)rows * C * 3 * sizeof(float);
+    const int32_t info[FB_PROF_INFO] = {(int32_t)(n_pixels / 128), C, (int32_t)(pixels_per_group / 128), dtype, 1 /* dual */, mask ? 1 : 0, 0, 0, 0, 0, 0};
+    const int prof = fb_prof_begin(FB_PROF_BN_BWD_REDUCE, (hipStream_t)stream, info);
+    const BnReduceB B{(const uint4*)x_b, invstd_b, partial_b, ch_off_b};
+    if (dtype == FB_F32)
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, true>), dim3(n_mblocks), dim3(256), smem, (hipStream_t)stream, (const uint4*)dout, (const uint4*)nullptr,
+                           (const unsigned char*)mask, (const uint4*)x_a, mean_tab, invstd_a, ch_total, ch_off_a, partial_a, (long long)n_pixels, C, (long long)pixels_per_group, n_mblocks, PB, B);
+    else
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_tag, true>), dim3(n_mblocks), dim3(256), smem, (hipStream_t)stream, (const uint4*)dout, (const uint4*)nullptr,
+                           (const unsigned char*)mask, (const uint4*)x_a, mean_tab, invstd_a, ch_total, ch_off_a, partial_a, (long long)n_pixels, C, (long long)pixels_per_group, n_mblocks, PB, B);
+    fb_prof_end(prof, (hipStream_t)stream);
+    FB_CHECK_LAUNCH("fb_bn_bwd_reduce2");
     return FB_OK;
 }
 
@@ -496,18 +552,21 @@ __global__ void bn_bwd_apply_kernel(const uint4* __restrict__ dout, const uint4*
         for (int k = 0; k < V; ++k) {
             const float dy = ((mk >> k) & 1u) ? d[k] : 0.f;
             dyv[k] = dy;
-            o[k] = cf[3 * k] * dy + cf[3 * k + 1] * xv[k] + cf[3 * k + 2];
+            o[k] = fb_bn_dx(cf[3 * k], cf[3 * k + 1], cf[3 * k + 2], dy, xv[k]);
         }
         dx[i] = ET<T>::pack(o);
         if (dy_out) dy_out[i] = ET<T>::pack(dyv);
     }
 }
 
-template <typename T>
+// DUAL: the second BatchNorm of fb_bn_bwd_reduce2 -- dx_b = c_dy' * dy + c_x' * x_b + c_0' from the same (dout, mask) read
+struct BnApplyB { const uint4* x; const float* coef; uint4* dx; };
+template <typename T, bool DUAL = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_span_kernel(const uint4* __restrict__ dout, const uint4* __restrict__ y,
                                                                 const unsigned char* __restrict__ mask, const uint4* __restrict__ x,
                                                                 const float* __restrict__ coef, uint4* __restrict__ dx, uint4* __restrict__ dy_out,
-                                                                long long n_vec, int cvec, long long vec_per_group, int C, int span, float* __restrict__ amax) {
+                                                                long long n_vec, int cvec, long long vec_per_group, int C, int span, float* __restrict__ amax,
+                                                                BnApplyB B) {
     constexpr int V = ET<T>::VEC;
     float am = 0.f;
     const long long g = blockIdx.y, base = g * vec_per_group;
@@ -517,18 +576,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_span_kernel(const uint4* __r
     const int c0 = (int)(threadIdx.x % cvec) * V;
     float cf[3 * V];
     load_coef<3 * V>(coef + (g * C + c0) * 3, cf);
+    float cfB[DUAL ? 3 * V : 1];
+    if constexpr (DUAL) { load_coef<3 * V>(B.coef + (g * C + c0) * 3, cfB); B.x += base; B.dx += base; }
     dout += base; x += base; dx += base;
     if (mask) mask += base;
     if (y) y += base;
     if (dy_out) dy_out += base;
-    auto one = [&](const uint4& dr, const uint4& xr, unsigned mk, long long i) {
+    auto one = [&](const uint4& dr, const uint4& xr, const uint4& xbr, unsigned mk, long long i) {
         float d[V], xv[V], o[V], dyv[V];
         ET<T>::unpack(dr, d); ET<T>::unpack(xr, xv);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             const float dy = ((mk >> k) & 1u) ? d[k] : 0.f;
             dyv[k] = dy;
-            o[k] = cf[3 * k] * dy + cf[3 * k + 1] * xv[k] + cf[3 * k + 2];
+            o[k] = fb_bn_dx(cf[3 * k], cf[3 * k + 1], cf[3 * k + 2], dy, xv[k]);
         }
         if (amax) {
 #pragma unroll
@@ -536,6 +597,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_span_kernel(const uint4* __r
         }
         st_stream(dx + i, ET<T>::pack(o));
         if (dy_out) st_stream(dy_out + i, ET<T>::pack(dyv));
+        if constexpr (DUAL) {
+            float xb[V], ob[V];
+            ET<T>::unpack(xbr, xb);
+#pragma unroll
+            for (int k = 0; k < V; ++k) ob[k] = fb_bn_dx(cfB[3 * k], cfB[3 * k + 1], cfB[3 * k + 2], dyv[k], xb[k]);
+            st_stream(B.dx + i, ET<T>::pack(ob));
+        }
     };
     auto mask_at = [&](long long i) -> unsigned {
         if (mask) return mask[i];
@@ -549,14 +617,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_span_kernel(const uint4* __r
     };
     long long i = lo + threadIdx.x;
     for (; i + (BN_SPAN_U - 1) * 256 < hi; i += BN_SPAN_U * 256) {
-        uint4 dr[BN_SPAN_U], xr[BN_SPAN_U];
+        uint4 dr[BN_SPAN_U], xr[BN_SPAN_U], xbr[BN_SPAN_U];
         unsigned mk[BN_SPAN_U];
 #pragma unroll
-        for (int u = 0; u < BN_SPAN_U; ++u) { dr[u] = ld_stream(dout + i + u * 256); xr[u] = ld_stream(x + i + u * 256); mk[u] = mask_at(i + u * 256); }
+        for (int u = 0; u < BN_SPAN_U; ++u) {
+            dr[u] = ld_stream(dout + i + u * 256); xr[u] = ld_stream(x + i + u * 256); mk[u] = mask_at(i + u * 256);
+            if constexpr (DUAL) xbr[u] = ld_stream(B.x + i + u * 256); else xbr[u] = xr[u];
+        }
 #pragma unroll
-        for (int u = 0; u < BN_SPAN_U; ++u) one(dr[u], xr[u], mk[u], i + u * 256);
+        for (int u = 0; u < BN_SPAN_U; ++u) one(dr[u], xr[u], xbr[u], mk[u], i + u * 256);
     }
-    for (; i < hi; i += 256) one(dout[i], x[i], mask_at(i), i);
+    for (; i < hi; i += 256) { if constexpr (DUAL) one(dout[i], x[i], B.x[i], mask_at(i), i); else one(dout[i], x[i], x[i], mask_at(i), i); }
     if (amax) amax_commit(amax, am);                          // (uniform branch) one value per run; folded per statistics group afterwards
 }
 
@@ -575,10 +646,10 @@ extern "C" int fb_bn_bwd_apply(const void* dout, const void* y, const void* mask
         const dim3 grid((unsigned)((vpg + span - 1) / span), (unsigned)((n_vec + vpg - 1) / vpg));
         if (dtype == FB_F32)
             hipLaunchKernelGGL((bn_bwd_apply_span_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const uint4*)dout, (const uint4*)y,
-                               (const unsigned char*)mask, (const uint4*)x, coef, (uint4*)dx, (uint4*)dy_out, n_vec, cvec, vpg, C, span, amax_out ? amax_ws : nullptr);
+                               (const unsigned char*)mask, (const uint4*)x, coef, (uint4*)dx, (uint4*)dy_out, n_vec, cvec, vpg, C, span, amax_out ? amax_ws : nullptr, BnApplyB{});
         else
             hipLaunchKernelGGL((bn_bwd_apply_span_kernel<bf16_tag>), grid, dim3(256), 0, (hipStream_t)stream, (const uint4*)dout, (const uint4*)y,
-                               (const unsigned char*)mask, (const uint4*)x, coef, (uint4*)dx, (uint4*)dy_out, n_vec, cvec, vpg, C, span, nullptr);
+                               (const unsigned char*)mask, (const uint4*)x, coef, (uint4*)dx, (uint4*)dy_out, n_vec, cvec, vpg, C, span, nullptr, BnApplyB{});
         fb_prof_end(prof, (hipStream_t)stream);
         if (amax_out) hipLaunchKernelGGL(amax_finish_kernel, dim3(grid.y), dim3(256), 0, (hipStream_t)stream, amax_ws, (int)grid.x, amax_out);
         FB_CHECK_LAUNCH("fb_bn_bwd_apply");
@@ -593,5 +664,30 @@ extern "C" int fb_bn_bwd_apply(const void* dout, const void* y, const void* mask
                            (const unsigned char*)mask, (const uint4*)x, coef, (uint4*)dx, (uint4*)dy_out, n_vec, cvec, vpg, C);
     FB_CHECK_LAUNCH("fb_bn_bwd_apply");
     if (amax_out) return fb_absmax((const float*)dx, pixels_per_group * C, (int32_t)n_groups, pixels_per_group * C, 1, amax_out, stream);
+    return FB_OK;
+}
+
+
+/* The apply step of two BatchNorms that share the incoming gradient and its ReLU mask (fb_bn_bwd_reduce2): one read of dout for both dx tensors. */
+extern "C" int fb_bn_bwd_apply2(const void* dout, const void* mask, const void* x_a, const float* coef_a, void* dx_a, const void* x_b, const float* coef_b,
+                                void* dx_b, int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t dtype, void* stream) {
+    if (!dout || !x_a || !coef_a || !dx_a || !x_b || !coef_b || !dx_b) FB_FAIL(FB_ERR_ARG, "fb_bn_bwd_apply2: null pointer");
+    const int V = dtype == FB_F32 ? 4 : 8;
+    if (C % V != 0 || 256 % (C / V) != 0 || pixels_per_group <= 0) FB_FAIL(FB_ERR_UNSUPPORTED, "fb_bn_bwd_apply2: C=%d (the channel vectors of a pixel must divide 256)", C);
+    const int cvec = C / V;
+    const long long n_vec = n_pixels * cvec, vpg = pixels_per_group * cvec;
+    const int32_t info[FB_PROF_INFO] = {(int32_t)(n_pixels / 128), C, (int32_t)(pixels_per_group / 128), dtype, 1 /* dual */, mask ? 1 : 0, 0, 0, 0, 0, 0};
+    const int prof = fb_prof_begin(FB_PROF_BN_BWD_APPLY, (hipStream_t)stream, info);
+    const int span = bn_span(n_vec);
+    const dim3 grid((unsigned)((vpg + span - 1) / span), (unsigned)((n_vec + vpg - 1) / vpg));
+    const BnApplyB B{(const uint4*)x_b, coef_b, (uint4*)dx_b};
+    if (dtype == FB_F32)
+        hipLaunchKernelGGL((bn_bwd_apply_span_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)stream, (const uint4*)dout, (const uint4*)nullptr,
+                           (const unsigned char*)mask, (const uint4*)x_a, coef_a, (uint4*)dx_a, (uint4*)nullptr, n_vec, cvec, vpg, C, span, (float*)nullptr, B);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_span_kernel<bf16_tag, true>), grid, dim3(256), 0, (hipStream_t)stream, (const uint4*)dout, (const uint4*)nullptr,
+                           (const unsigned char*)mask, (const uint4*)x_a, coef_a, (uint4*)dx_a, (uint4*)nullptr, n_vec, cvec, vpg, C, span, (float*)nullptr, B);
+    fb_prof_end(prof, (hipStream_t)stream);
+    FB_CHECK_LAUNCH("fb_bn_bwd_apply2");
     return FB_OK;
 }

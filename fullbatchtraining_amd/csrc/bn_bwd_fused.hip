@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BF_WGCU, BF
             for (int k = 0; k < V; ++k) {
                 const float dy = ((m >> k) & 1u) ? d[k] : 0.f;
                 dyv[k] = dy;
-                o[k] = cf[3 * k] * dy + cf[3 * k + 1] * xv[k] + cf[3 * k + 2];
+                o[k] = fb_bn_dx(cf[3 * k], cf[3 * k + 1], cf[3 * k + 2], dy, xv[k]);
             }
             bf_st(rO, tid * 16, slot(j) * 4096, ET<T>::pack(o));
             if (p.dy_out) bf_st(rY, tid * 16, slot(j) * 4096, ET<T>::pack(dyv));

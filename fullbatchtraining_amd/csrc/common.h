@@ -311,6 +311,11 @@ __device__ __forceinline__ void store_b128_guard(fb_store_u32x4 data) {
 #endif
 }
 
+// dx of a BatchNorm backward, dx = c_dy * dy + c_x * x + c_0 (coefficients from fb_bn_bwd_finalize): ONE spelling with explicit fused multiply-adds,
+// shared by every kernel that evaluates it (fb_bn_bwd_apply / _apply2, the stem weight gradient's loader, fb_bn_bwd_fused) -- left to the
+// compiler's contraction the same source line rounded differently in two instantiations of one template (fp32, last bit)
+__device__ __forceinline__ float fb_bn_dx(float c_dy, float c_x, float c_0, float dy, float x) { return fmaf(c_dy, dy, fmaf(c_x, x, c_0)); }
+
 // Sum over the 16 lanes of a DPP row (lanes 16k..16k+15), result in every lane: four v_add_f32 with row_ror modifiers --
 // no LDS traffic (``__shfl_xor`` lowers to ds_bpermute_b32, which queues behind the fragment reads of the co-resident workgroup).
 __device__ __forceinline__ float row16_sum(float v) {

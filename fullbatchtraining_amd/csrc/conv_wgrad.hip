@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const float dy = ((rm[i] >> q) & 1u) ? d[q] : 0.f;
-                    o[q] = cf[3 * q] * dy + cf[3 * q + 1] * xv[q] + cf[3 * q + 2];
+                    o[q] = fb_bn_dx(cf[3 * q], cf[3 * q + 1], cf[3 * q + 2], dy, xv[q]);
                     if (rm[i] & 0x100u) o[q] = 0.f;
                 }
                 ra[i] = ET<bf16_tag>::pack(o);

@@ -721,6 +721,34 @@ class Engine:
              self.dtc, *((self._amax_slot(dx, px * L.cout), self.amax_ws.data_ptr()) if self.f32_split == "f16x2" else (None, None)))
         return dx, dy
 
+    def _bn_bwd2(self, La, Lb, dout, mask, G, gout, pidx):
+        """BatchNorm backward of TWO layers that take the same incoming gradient through the same ReLU mask (conv2 and the shortcut convolution of a
+        downsampling block): one read of ``dout`` per pass for both (``fb_bn_bwd_reduce2`` / ``fb_bn_bwd_apply2``; bit-identical to two
+        ``_bn_bwd`` calls).  Returns (dx_a, dx_b)."""
+        n = G * self.chunk
+        px, ppg = n * La.hout * La.wout, self.chunk * La.hout * La.wout
+        bits = self.masks[mask.data_ptr()]
+        rows = lib.load().fb_bn_bwd_reduce_rows(px, ppg)
+        half = 2 * rows * La.cout                            # floats of one layer's partial rows
+        pa, pb = self.stat_ws.data_ptr(), self.stat_ws.data_ptr() + 4 * half
+        call("fb_bn_bwd_reduce2", dout.data_ptr(), bits.data_ptr(), La.x.data_ptr(), La.invstd.data_ptr(), La.ch_off, pa, Lb.x.data_ptr(), Lb.invstd.data_ptr(),
+             Lb.ch_off, pb, self.mean_tab[pidx].data_ptr(), self.plan.ch_total, px, La.cout, ppg, self.dtc)
+        for L, part in ((La, pa), (Lb, pb)):
+            call("fb_bn_bwd_finalize", part, rows, G, L.cout, float(self.valid * L.hout * L.wout), L.scale.data_ptr(), self.mean_tab[pidx].data_ptr(),
+                 L.invstd.data_ptr(), self.plan.ch_total, L.ch_off, gout.data_ptr() + 4 * L.g_off, gout.data_ptr() + 4 * L.b_off, self.plan.P, L.coef.data_ptr(), 0)
+        dxa, dxb = self.pool.get((n, La.hout, La.wout, La.cout)), self.pool.get((n, La.hout, La.wout, La.cout))
+        call("fb_bn_bwd_apply2", dout.data_ptr(), bits.data_ptr(), La.x.data_ptr(), La.coef.data_ptr(), dxa.data_ptr(), Lb.x.data_ptr(), Lb.coef.data_ptr(),
+             dxb.data_ptr(), px, La.cout, ppg, self.dtc)
+        return dxa, dxb
+
+    def _bn_bwd2_ok(self, La, Lb, G):
+        if os.environ.get("FB_BN_BWD_DUAL", "1") == "0" or self.f32_split == "f16x2" or La.cout != Lb.cout or (La.hout, La.wout) != (Lb.hout, Lb.wout):
+            return False
+        vec = 16 // torch.empty((), dtype=self.dt).element_size()
+        n = G * self.chunk
+        rows = lib.load().fb_bn_bwd_reduce_rows(n * La.hout * La.wout, self.chunk * La.hout * La.wout)
+        return La.cout % vec == 0 and 256 % (La.cout // vec) == 0 and 4 * rows * La.cout <= self.stat_ws.numel()
+
     def _wgrad_bn_ok(self, L, mask):
         """Can the weight gradient of L apply the BatchNorm backward of its own output itself (``fb_wgrad_args.bn_x``: no dx tensor)?"""
         if os.environ.get("FB_WGRAD_BNF", "1") == "0" or self.dt != torch.bfloat16 or self.masks.get(mask.data_ptr()) is None:
@@ -829,7 +857,12 @@ class Engine:
             # convolution where fb_conv_masked_addend_supported says so.
             out_bits = self.masks.get(b.out.data_ptr())
             lazy = out_bits is not None and (b.shortcut is not None or self._masked_addend_ok(first, G, wsets))
-            dx, dy = self._bn_bwd(last, d, b.out, G, gout, pidx, want_dy=not lazy, reduced=d_reduced)
+            dxs_early = None
+            if lazy and b.shortcut is not None and not d_reduced and self._bn_bwd2_ok(last, b.shortcut, G):
+                dx, dxs_early = self._bn_bwd2(last, b.shortcut, d, b.out, G, gout, pidx)          # conv2's and the shortcut's BatchNorm: one read of d each pass
+                dy = None
+            else:
+                dx, dy = self._bn_bwd(last, d, b.out, G, gout, pidx, want_dy=not lazy, reduced=d_reduced)
             # the BatchNorm that consumes this block's input gradient: the last one of the previous block, or the stem's
             if bi > 0:
                 consumer = (plan.blocks[bi - 1].convs[-1], plan.blocks[bi - 1].out)
@@ -850,7 +883,10 @@ class Engine:
                     pool.put(d_mid)
             if b.shortcut is not None:
                 S = b.shortcut
-                dxs, _ = self._bn_bwd(S, d, b.out, G, gout, pidx, want_dy=False) if lazy else self._bn_bwd(S, dy, None, G, gout, pidx, want_dy=False)
+                if dxs_early is not None:
+                    dxs = dxs_early
+                else:
+                    dxs, _ = self._bn_bwd(S, d, b.out, G, gout, pidx, want_dy=False) if lazy else self._bn_bwd(S, dy, None, G, gout, pidx, want_dy=False)
                 src = b.pooled if b.pooled is not None else a0
                 self._wgrad(S, src, dxs, G, gout)
                 d_p = self._dgrad(S, dxs, G, wsets)

@@ -207,6 +207,15 @@ int fb_bn_bwd_finalize(const float* partial, int32_t n_mblocks, int32_t n_groups
 int fb_bn_bwd_apply(const void* dout, const void* y, const void* mask, const void* x, const float* coef, void* dx, void* dy_out,
                     int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t dtype, float* amax_out, float* amax_ws, void* stream);
 
+/* Two BatchNorms that take the SAME incoming gradient through the SAME ReLU mask (a downsampling block, resnets.py:222-230: out = relu(bn2(conv2) +
+ * bn_s(conv_s)): both BatchNorm backward passes start from the gradient of `out`): one read of dout serves both.  fb_bn_bwd_reduce2 writes each
+ * BatchNorm's partial rows (sum dy is common) exactly as fb_bn_bwd_reduce would -- finalize each with fb_bn_bwd_finalize -- and fb_bn_bwd_apply2
+ * writes both dx tensors.  Bit-identical to the separate calls; the channel vectors of a pixel must divide 256. */
+int fb_bn_bwd_reduce2(const void* dout, const void* mask, const void* x_a, const float* invstd_a, int32_t ch_off_a, float* partial_a,
+                      const void* x_b, const float* invstd_b, int32_t ch_off_b, float* partial_b, const float* mean_tab, int32_t ch_total,
+                      int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t dtype, void* stream);
+int fb_bn_bwd_apply2(const void* dout, const void* mask, const void* x_a, const float* coef_a, void* dx_a, const void* x_b, const float* coef_b,
+                     void* dx_b, int64_t n_pixels, int32_t C, int64_t pixels_per_group, int32_t dtype, void* stream);
 /* The three calls above in ONE pass over (dout, x) (csrc/bn_bwd_fused.hip; autograd's native_batch_norm_backward + threshold_backward behind
  * resnets.py:214-230): a cluster of workgroups that is resident as a whole keeps a statistics group's operands in registers between the
  * reduction and the apply step -- 3 tensor passes instead of 5.  Same arithmetic as reduce / finalize / apply (fp32 sums per thread, partial

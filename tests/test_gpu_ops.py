@@ -1022,3 +1022,53 @@ def test_wgrad_with_the_batchnorm_apply_in_its_loader(cin_pad, hw, imgs, G, spli
     assert not handle.fb_wgrad_bn_fused_supported(lib.C.byref(a))
     with pytest.raises(lib.EngineError, match="bn_x"):
         lib.call("fb_conv2d_wgrad", lib.C.byref(a))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,hw,imgs,G", [(128, 16, 32, 3), (512, 4, 128, 2), (256, 8, 16, 5)])
+def test_bn_bwd_of_two_batchnorms_sharing_the_gradient(dtype, C, hw, imgs, G):
+    """fb_bn_bwd_reduce2 / fb_bn_bwd_apply2: the BatchNorm of conv2 and the one of the shortcut convolution of a downsampling block both start from the
+    gradient of the block output (through its ReLU mask): one read of dout per pass serves both, bit for bit what the separate calls give."""
+    lib = _lib()
+    handle = lib.load()
+    dtc = lib.dtype_code(dtype)
+    n = G * imgs
+    px, ppg = n * hw * hw, imgs * hw * hw
+    torch.manual_seed(C)
+    eb = 4 if dtype == torch.float32 else 2
+    xa, xb, dout = (torch.randn(n, hw, hw, C, device="cuda").to(dtype) for _ in range(3))
+    bits = torch.randint(0, 256, (dout.numel() * eb // 16,), device="cuda", dtype=torch.uint8)
+    mean_tab = torch.randn(G, 2 * C, device="cuda") * 0.1                               # layer a: columns [0, C), layer b: [C, 2C)
+    inv = [torch.rand(G, C, device="cuda") + 0.5 for _ in range(2)]
+    scale = [torch.rand(G, C, device="cuda") + 0.5 for _ in range(2)]
+    rows = handle.fb_bn_bwd_reduce_rows(px, ppg)
+
+    def finalize(part, k, gout, coef):
+        lib.call("fb_bn_bwd_finalize", part.data_ptr(), rows, G, C, float(ppg), scale[k].data_ptr(), mean_tab.data_ptr(), inv[k].data_ptr(), 2 * C, k * C,
+                 gout.data_ptr(), gout.data_ptr() + 4 * C, 2 * C, coef.data_ptr(), 0)
+
+    out = {}
+    for mode in ("separate", "dual"):
+        parts = [torch.zeros(2 * rows * C, device="cuda") for _ in range(2)]
+        gouts = [torch.zeros(G, 2 * C, device="cuda") for _ in range(2)]
+        coefs = [torch.zeros(G, C, 3, device="cuda") for _ in range(2)]
+        dxs = [torch.empty_like(dout) for _ in range(2)]
+        if mode == "separate":
+            for k, x in enumerate((xa, xb)):
+                lib.call("fb_bn_bwd_reduce", dout.data_ptr(), None, bits.data_ptr(), x.data_ptr(), mean_tab.data_ptr(), inv[k].data_ptr(), 2 * C, k * C,
+                         parts[k].data_ptr(), px, C, ppg, dtc)
+                finalize(parts[k], k, gouts[k], coefs[k])
+                lib.call("fb_bn_bwd_apply", dout.data_ptr(), None, bits.data_ptr(), x.data_ptr(), coefs[k].data_ptr(), dxs[k].data_ptr(), None, px, C, ppg, dtc, None, None)
+        else:
+            lib.call("fb_bn_bwd_reduce2", dout.data_ptr(), bits.data_ptr(), xa.data_ptr(), inv[0].data_ptr(), 0, parts[0].data_ptr(), xb.data_ptr(), inv[1].data_ptr(), C,
+                     parts[1].data_ptr(), mean_tab.data_ptr(), 2 * C, px, C, ppg, dtc)
+            for k in range(2):
+                finalize(parts[k], k, gouts[k], coefs[k])
+            lib.call("fb_bn_bwd_apply2", dout.data_ptr(), bits.data_ptr(), xa.data_ptr(), coefs[0].data_ptr(), dxs[0].data_ptr(), xb.data_ptr(), coefs[1].data_ptr(),
+                     dxs[1].data_ptr(), px, C, ppg, dtc)
+        torch.cuda.synchronize()
+        out[mode] = (parts, gouts, coefs, dxs)
+    for group in range(4):
+        for k in range(2):
+            assert torch.equal(out["separate"][group][k], out["dual"][group][k]), (group, k)
+    assert float(out["dual"][3][0].float().abs().max()) > 0 and not torch.equal(out["dual"][3][0], out["dual"][3][1])
