@@ -102,13 +102,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     uint4 ra[LD_A], rb[LD_B];
     uint4 rx[BNF ? LD_A : 1];                               // BNF: the BatchNorm input at the same positions
     unsigned rm[BNF ? LD_A : 1];
-    float cf[BNF ? 24 : 1];                                 // BNF: three coefficients for each of this thread's 8 channels (one 16-byte chunk: tid % CH_A)
+    constexpr int BV = 16 / EB;                             // channels of one 16-byte chunk
+    float cf[BNF ? 3 * BV : 1];                             // BNF: three coefficients for each channel of this thread's chunk (tid % CH_A)
     if constexpr (BNF) {
-        static_assert(EB == 2 && 256 % CH_A == 0, "BNF: bf16, fixed channel chunk per thread");
-        const float* c = p.bn_coef + ((long long)group * p.Cd + tile_m * TM + (tid % CH_A) * 8) * 3;
+        static_assert(256 % CH_A == 0 && !HSPLIT, "BNF: fixed channel chunk per thread; not for the fp16x2 planes (their scale needs the materialised dx)");
+        const float* c = p.bn_coef + ((long long)group * p.Cd + tile_m * TM + (tid % CH_A) * BV) * 3;
 #pragma unroll
-        for (int q = 0; q < 24; ++q) cf[q] = c[q];
+        for (int q = 0; q < 3 * BV; ++q) cf[q] = c[q];
     }
+    // dx = c_dy * dy + c_x * x + c_0 (fb_bn_bwd_apply: same expression, same rounding) of chunk i, in place
+    auto bn_dx_chunk = [&](int i) {
+        if constexpr (BNF) {
+            float d[BV], xv[BV], o[BV];
+            ET<T>::unpack(ra[i], d); ET<T>::unpack(rx[i], xv);
+#pragma unroll
+            for (int q = 0; q < BV; ++q) {
+                const float dy = ((rm[i] >> q) & 1u) ? d[q] : 0.f;
+                o[q] = fb_bn_dx(cf[3 * q], cf[3 * q + 1], cf[3 * q + 2], dy, xv[q]);
+                if (rm[i] & 0x100u) o[q] = 0.f;
+            }
+            ra[i] = ET<T>::pack(o);
+        }
+    };
     auto gload = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < LD_A; ++i) {
@@ -142,6 +157,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
             for (int i = 0; i < LD_A; ++i) {
                 const int id = tid + 256 * i, row = id / CH_A, ch = id % CH_A;
                 uint2 h, m, l;
+                bn_dx_chunk(i);
                 char* d = tileA + row * PROW_A + ch * 8;
                 if constexpr (HSPLIT) { split_h2x4(ra[i], hs_a, h, l); *(uint2*)d = h; *(uint2*)(d + PLANE_A) = l; }
                 else { split_f32x4(ra[i], h, m, l); *(uint2*)d = h; *(uint2*)(d + PLANE_A) = m; *(uint2*)(d + 2 * PLANE_A) = l; }
@@ -158,17 +174,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
         for (int i = 0; i < LD_A; ++i) {
             const int id = tid + 256 * i, row = id / CH_A, ch = id % CH_A;
-            if constexpr (BNF) {                                 // dx = c_dy * dy + c_x * x + c_0 (fb_bn_bwd_apply), bf16
-                float d[8], xv[8], o[8];
-                ET<bf16_tag>::unpack(ra[i], d); ET<bf16_tag>::unpack(rx[i], xv);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const float dy = ((rm[i] >> q) & 1u) ? d[q] : 0.f;
-                    o[q] = fb_bn_dx(cf[3 * q], cf[3 * q + 1], cf[3 * q + 2], dy, xv[q]);
-                    if (rm[i] & 0x100u) o[q] = 0.f;
-                }
-                ra[i] = ET<bf16_tag>::pack(o);
-            }
+            bn_dx_chunk(i);
             *(uint4*)(tileA + row * ROW_A + ch * 16) = ra[i];
         }
 #pragma unroll
@@ -270,13 +276,13 @@ int fb_try_wgrad1x1(const fb_wgrad_args* a, hipStream_t st);      // conv_wgrad1
 // BatchNorm backward apply inside the loader: bf16, 1x1, the 64 x 32-channel tiles of the stem (register-staged operands)
 extern "C" int32_t fb_wgrad_bn_fused_supported(const fb_wgrad_args* a) {
     static const bool disabled = getenv("FB_DISABLE_WGRAD_BNF") != nullptr;
-    return !disabled && a && a->dtype == FB_BF16 && a->R == 1 && a->S == 1 && a->stride == 1 && a->pad == 0 && a->Cs % 32 == 0 && a->Cs % 64 != 0
+    return !disabled && a && !a->amax_x && !a->amax_dy && a->R == 1 && a->S == 1 && a->stride == 1 && a->pad == 0 && a->Cs % 32 == 0 && a->Cs % 64 != 0
            && a->Cd % 64 == 0 && a->Hs == a->Hd && a->Ws == a->Wd;
 }
 
 extern "C" int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream) {
     if (!a || !a->x || !a->dy || !a->dw_partial) FB_FAIL(FB_ERR_ARG, "fb_conv2d_wgrad: null pointer");
-    if (a->bn_x && (!a->bn_coef || !fb_wgrad_bn_fused_supported(a))) FB_FAIL(FB_ERR_UNSUPPORTED, "fb_conv2d_wgrad: bn_x (BatchNorm apply in the loader) is for bf16 1x1 layers with Cs < 64 and needs bn_coef");
+    if (a->bn_x && (!a->bn_coef || !fb_wgrad_bn_fused_supported(a))) FB_FAIL(FB_ERR_UNSUPPORTED, "fb_conv2d_wgrad: bn_x (BatchNorm apply in the loader) is for 1x1 layers with Cs < 64 (no fp16x2 planes) and needs bn_coef");
     if (a->Cs % 32 != 0 || a->Cd % 64 != 0) FB_FAIL(FB_ERR_SHAPE, "fb_conv2d_wgrad: Cs=%d must be a multiple of 32, Cd=%d of 64", a->Cs, a->Cd);
     if (a->n_img % a->imgs_per_group != 0) FB_FAIL(FB_ERR_SHAPE, "fb_conv2d_wgrad: n_img %% imgs_per_group != 0");
     if (a->split_k < 1) FB_FAIL(FB_ERR_ARG, "fb_conv2d_wgrad: split_k < 1");
@@ -302,7 +308,9 @@ extern "C" int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream) {
     const int prof = fb_prof_begin(FB_PROF_WGRAD, st, info);
     if (a->bn_x) {
         dim3 grid((a->Cd / 64) * (a->Cs / 32), taps, n_groups * a->split_k);
-        hipLaunchKernelGGL((conv_wgrad_kernel<bf16_tag, 1, 1, 4, 1, 2, true>), grid, dim3(256), 0, st, p);
+        if (a->dtype == FB_F32 && split) hipLaunchKernelGGL((conv_wgrad_kernel<f32s_tag, 1, 1, 4, 1, 2, true>), grid, dim3(256), 0, st, p);
+        else if (a->dtype == FB_F32) hipLaunchKernelGGL((conv_wgrad_kernel<float, 1, 1, 4, 1, 2, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_tag, 1, 1, 4, 1, 2, true>), grid, dim3(256), 0, st, p);
     } else if (fb_try_wgrad3x3_v2(a, st)) { fb_prof_kernel(prof, FB_K_WGRAD3X3_V2);
     } else if (fb_try_wgrad3x3(a, st)) { fb_prof_kernel(prof, FB_K_WGRAD3X3_V1);
     } else if (fb_try_wgrad1x1(a, st)) { fb_prof_kernel(prof, FB_K_WGRAD1X1);

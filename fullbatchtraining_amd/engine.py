@@ -751,8 +751,8 @@ class Engine:
 
     def _wgrad_bn_ok(self, L, mask):
         """Can the weight gradient of L apply the BatchNorm backward of its own output itself (``fb_wgrad_args.bn_x``: no dx tensor)?"""
-        if os.environ.get("FB_WGRAD_BNF", "1") == "0" or self.dt != torch.bfloat16 or self.masks.get(mask.data_ptr()) is None:
-            return False
+        if os.environ.get("FB_WGRAD_BNF", "1") == "0" or self.f32_split == "f16x2" or self.masks.get(mask.data_ptr()) is None:
+            return False                             # (fp16x2 planes: the scale of dx needs the materialised tensor)
         a = lib.WgradArgs(None, None, None, self.chunk, L.hin, L.win, L.cin_pad, L.hout, L.wout, L.cout, L.R, L.S, L.stride, L.pad, self.chunk, 1, self.dtc, 0)
         return bool(lib.load().fb_wgrad_bn_fused_supported(lib.C.byref(a)))
 

@@ -127,9 +127,9 @@ typedef struct {
     int64_t group_stride;
     const float* amax_x; const float* amax_dy;   /* optional (FB_F32): largest magnitudes of x and dy PER GROUP of imgs_per_group images
                                                   * (fb_absmax, per_set): fp16x2 split as in fb_conv_args */
-    /* optional (FB_BF16, 1x1, Cs < 64: the stem on its patches; fb_wgrad_bn_fused_supported): the BatchNorm backward apply step INSIDE the
+    /* optional (1x1, Cs < 64: the stem on its patches; bf16 and fp32 without amax_*; fb_wgrad_bn_fused_supported): the BatchNorm backward apply step INSIDE the
      * operand loader -- `dy` then holds the gradient w.r.t. the BatchNorm + ReLU OUTPUT, and the kernel multiplies by
-     *   dy'[p][c] = coef[g][c][0] * (dy[p][c] masked by bn_mask) + coef[g][c][1] * bn_x[p][c] + coef[g][c][2]      (rounded to bf16)
+     *   dy'[p][c] = coef[g][c][0] * (dy[p][c] masked by bn_mask) + coef[g][c][1] * bn_x[p][c] + coef[g][c][2]      (rounded to the storage type)
      * i.e. exactly what fb_bn_bwd_apply would have written to dx with the coefficients of fb_bn_bwd_finalize: a layer whose input gradient
      * nobody needs (the stem) saves writing dx and reading it back.  bn_mask: ReLU bitmask (1 byte per 16-byte vector) or NULL. */
     const void* bn_x; const void* bn_mask; const float* bn_coef;

@@ -984,21 +984,22 @@ def test_bn_bwd_fused_equals_the_two_pass_form(dtype, C, hw, imgs, G):
     assert rel(a[0], want) < (1e-4 if dtype == torch.float32 else 8e-3), rel(a[0], want)
 
 
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("cin_pad,hw,imgs,G,split", [(32, 32, 16, 3, 4), (160, 16, 8, 2, 2), (32, 8, 128, 2, 1)])
-def test_wgrad_with_the_batchnorm_apply_in_its_loader(cin_pad, hw, imgs, G, split):
+def test_wgrad_with_the_batchnorm_apply_in_its_loader(dt, cin_pad, hw, imgs, G, split):
     """fb_wgrad_args.bn_x: the stem's weight gradient computes dx = c_dy * (dout masked) + c_x * x + c_0 (fb_bn_bwd_apply) in its operand loader
     instead of reading a materialised dx: the same slabs as fb_bn_bwd_apply -> fb_conv2d_wgrad, bit for bit (same fp32 expression, same bf16
-    rounding), with and without a ReLU bitmask."""
+    rounding; fp32 storage: the bf16x6 split of the computed values), with and without a ReLU bitmask."""
     lib = _lib()
     handle = lib.load()
-    dt, dtc, C = torch.bfloat16, lib.dtype_code(torch.bfloat16), 64
+    dtc, C = lib.dtype_code(dt), 64
     n = G * imgs
     px, ppg = n * hw * hw, imgs * hw * hw
     torch.manual_seed(cin_pad + hw)
     patches = torch.randn(n, hw, hw, cin_pad, device="cuda").to(dt)
     x = torch.randn(n, hw, hw, C, device="cuda").to(dt)
     dout = torch.randn(n, hw, hw, C, device="cuda").to(dt)
-    bits = torch.randint(0, 256, (x.numel() // 8,), device="cuda", dtype=torch.uint8)
+    bits = torch.randint(0, 256, (x.numel() * x.element_size() // 16,), device="cuda", dtype=torch.uint8)
     coef = torch.randn(G, C, 3, device="cuda")
     for mask in (bits, None):
         dx = torch.empty_like(x)
