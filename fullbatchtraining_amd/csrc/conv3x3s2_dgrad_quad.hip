@@ -8,7 +8,8 @@
 // lives in set-up, first-load latency and epilogue (128->64 at 32x32: 344 TF/s, 256->128 at 16x16: 540 TF/s).
 // Here a workgroup owns 128 quads x 64 output channels x all four classes (512 output pixels):
 //   * per 32-channel half-slice of dY (64-byte rows) the (rows+1) x (W+1) halo of the quads (<= 200 rows, 12.5 KiB) and the 64 x 64-byte
-//     weight rows of ALL nine taps (36 KiB) are staged by LDS-DMA, double buffered: one barrier per 72 MFMAs per wave
+//     weight rows of ALL nine taps (36 KiB) are staged by LDS-DMA into ONE 49 KiB stage; two workgroups share a CU, so one's staging
+//     wait and epilogue run under the other's 72 MFMAs per wave and half-slice (template STAGES = 2: the double-buffered one-workgroup form)
 //   * a wave owns 32 quads: 4 classes x 2 quad fragments x 4 channel fragments = 128 accumulator registers; a tap contributes to
 //     exactly one class, so it costs 4 weight-fragment + 2 pixel-fragment reads for 8 MFMAs; every fragment address is a lane register
 //     + an immediate (64-byte rows: a wave's 16-row fragment read is one contiguous KiB, no swizzle needed)
@@ -55,13 +56,13 @@ template <int WQ> struct S2DGeo {                                  // WQ = width
 };
 }  // namespace
 
-template <int WQ>
-__global__ __launch_bounds__(256) void conv3x3s2_dgrad_quad_kernel(const S2DParams p) {
+template <int WQ, int STAGES>
+__global__ __launch_bounds__(256, STAGES == 1 ? 2 : 1) void conv3x3s2_dgrad_quad_kernel(const S2DParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using G = S2DGeo<WQ>;
     constexpr int PITCH = G::PITCH, NGRP = G::NGRP;
     constexpr int HALO_BYTES = NGRP * 1024, WT_BYTES = 9 * 4096, STAGE_BYTES = HALO_BYTES + WT_BYTES;
-    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) char lds[STAGES * STAGE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -127,12 +128,21 @@ __global__ __launch_bounds__(256) void conv3x3s2_dgrad_quad_kernel(const S2DPara
 #pragma unroll
             for (int jq = 0; jq < 2; ++jq) acc[i][c][jq] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    issue(0, 0);
-    s2d_wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
+    if constexpr (STAGES == 2) {
+        issue(0, 0);
+        s2d_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+    }
     for (int cc = 0; cc < n_cc; ++cc) {
-        const int cur = cc & 1;
-        if (cc + 1 < n_cc) issue(cur ^ 1, cc + 1);
+        const int cur = STAGES == 2 ? (cc & 1) : 0;
+        if constexpr (STAGES == 2) {
+            if (cc + 1 < n_cc) issue(cur ^ 1, cc + 1);
+        } else {
+            // one stage (49 KiB): two workgroups share a CU and cover each other's staging and epilogue
+            issue(0, cc);
+            s2d_wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+        }
         const unsigned so = cur * STAGE_BYTES;
         const unsigned w0 = wa + so, p0 = pa[0] + so, p1 = pa[1] + so;
         // one wave per SIMD (98 KiB of LDS per workgroup): the six fragment reads of tap T+1 are issued before the MFMAs of tap T
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(256) void conv3x3s2_dgrad_quad_kernel(const S2DPara
 #pragma unroll
                 for (int jq = 0; jq < 2; ++jq) acc[i][CLS][jq] = mma_chunk<bf16_tag>(wf[T & 1][i], pf[T & 1][jq], acc[i][CLS][jq]);
         });
-        s2d_wait_vmcnt<0>();
+        if constexpr (STAGES == 2) s2d_wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
     }
 
@@ -215,11 +225,7 @@ int fb_try_conv3x3s2_dgrad_quad(const fb_conv_args* a, hipStream_t st) {
     if (a->mode != 1 || a->R != 3 || a->S != 3 || a->stride != 2 || a->pad != 1 || a->dtype != FB_BF16) return 0;
     if (a->Hs != a->Ws || a->Hd != 2 * a->Hs || a->Wd != 2 * a->Ws) return 0;
     const int WQ = a->Ws;
-    // measured against the implicit GEMM at the benchmark's group size (12 544 images): dY 16x16 (128->64 ch) 1378 -> 959 us,
-    // 8x8 (256->128) 877 -> 744 us, 4x4 (512->256) 617 -> 666 us: the 4x4 case (16 half-slices per tile, 8 images per tile) stays with
-    // the implicit GEMM unless FB_S2_QUAD_ALL is set (the kernel is tested for all three)
-    static const bool all = getenv("FB_S2_QUAD_ALL") != nullptr;
-    if (WQ != 16 && WQ != 8 && !(WQ == 4 && all)) return 0;
+    if (WQ != 16 && WQ != 8 && WQ != 4) return 0;
     if (a->Cs % 32 != 0 || a->Cd % 64 != 0) return 0;
     if (a->wset_stride != 0 && a->imgs_per_wset > 0 && a->imgs_per_wset < a->n_img) return 0;          // one shared weight set
     if (a->addend_mask) return 0;
@@ -232,8 +238,20 @@ int fb_try_conv3x3s2_dgrad_quad(const fb_conv_args* a, hipStream_t st) {
     const int n_pt = WQ == 16 ? a->n_img * 2 : (a->n_img + imgs_per_tile - 1) / imgs_per_tile;
     p.n_tiles = n_pt * p.n_ct;
     dim3 grid(p.n_tiles);
-    if (WQ == 16) hipLaunchKernelGGL((conv3x3s2_dgrad_quad_kernel<16>), grid, dim3(256), 0, st, p);
-    else if (WQ == 8) hipLaunchKernelGGL((conv3x3s2_dgrad_quad_kernel<8>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv3x3s2_dgrad_quad_kernel<4>), grid, dim3(256), 0, st, p);
+    // One 49 KiB stage and TWO workgroups per CU (round 4) against two stages and one workgroup (round 3), 12 544 images, us, without / with
+    // a full-resolution addend: dY 16x16 (128->64 ch) 1010 / 1707 -> 793 / 1227, 8x8 (256->128) 776 / 1117 -> 589 / 790, 4x4 (512->256)
+    // 678 / 839 -> 506 / 612 (implicit GEMM: 649 / 778).  The tile's life is staging latency + a 128 KiB epilogue around 4-9 us of MFMA work:
+    // a second resident workgroup covers both, a second stage covers neither.  FB_S2Q_STAGES=2 selects the round-3 form.
+    const char* st_env = getenv("FB_S2Q_STAGES");              // read per call: the tests compare the two forms in one process
+    const int stages = st_env ? atoi(st_env) : 1;
+    if (stages == 1) {
+        if (WQ == 16) hipLaunchKernelGGL((conv3x3s2_dgrad_quad_kernel<16, 1>), grid, dim3(256), 0, st, p);
+        else if (WQ == 8) hipLaunchKernelGGL((conv3x3s2_dgrad_quad_kernel<8, 1>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv3x3s2_dgrad_quad_kernel<4, 1>), grid, dim3(256), 0, st, p);
+    } else {
+        if (WQ == 16) hipLaunchKernelGGL((conv3x3s2_dgrad_quad_kernel<16, 2>), grid, dim3(256), 0, st, p);
+        else if (WQ == 8) hipLaunchKernelGGL((conv3x3s2_dgrad_quad_kernel<8, 2>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv3x3s2_dgrad_quad_kernel<4, 2>), grid, dim3(256), 0, st, p);
+    }
     return 1;
 }

@@ -53,6 +53,10 @@ def main():
         print(f"{name:5s} fwd   {t:8.1f} us  {flops / t / 1e6:7.1f} TF/s  {byts / t / 1e3:7.1f} GB/s", flush=True)
         t = bench(lambda: lib.conv2d(dy, wt, dx, k, k, stride, pad, 1))
         print(f"{name:5s} dgrad {t:8.1f} us  {flops / t / 1e6:7.1f} TF/s  {byts / t / 1e3:7.1f} GB/s", flush=True)
+        if os.environ.get("ADD"):                                  # the residual form: dst = dgrad + addend (same shape)
+            add = torch.randn(n, hw, hw, cin, device="cuda").to(dtype)
+            t = bench(lambda: lib.conv2d(dy, wt, dx, k, k, stride, pad, 1, addend=add, addend_mode=1))
+            print(f"{name:5s} dgrad+add {t:8.1f} us  {flops / t / 1e6:7.1f} TF/s  {(byts + add.numel() * eb) / t / 1e3:7.1f} GB/s", flush=True)
         ipg = 128
         if os.environ.get("NO_WGRAD"):
             continue
