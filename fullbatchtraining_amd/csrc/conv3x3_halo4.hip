@@ -68,15 +68,19 @@ template <int W> constexpr int h4_frag_rows(int j) { return W == 32 ? (j >> 1) *
 __device__ __forceinline__ int h4_div(int n, unsigned magic) { return magic ? (int)__umulhi((unsigned)n, magic) : n; }
 constexpr unsigned H4_OOB = 0x80000000u;
 
-template <int W> struct H4Geo {
+// CP (4x4 maps only): the COMPACT layout -- no halo cells.  A padded 4x4 image is 36 cells for 16 pixels (72 KiB per 128-byte slice of a
+// 16-image tile: one workgroup per CU, 2.25 x the bytes through the LDS-DMA path); compact, an image is its 16 pixels + ONE zero row
+// (17 rows, 34 KiB per slice: two workgroups per CU with 64-channel tiles).  The price is nine per-lane fragment addresses instead of
+// three (a lane whose tap falls outside the image points at the zero row), i.e. 12 more registers.
+template <int W, bool CP = false> struct H4Geo {
     static constexpr int TH = W >= 16 ? 256 / W : W;              // image rows per image part of the tile
     static constexpr int IMGS = W >= 16 ? 1 : 256 / (W * W);      // whole images per tile (W = 8: 4, W = 4: 16)
     static constexpr int TILES_PER_IMG = W == 32 ? 4 : 1;
     // 32x32: pitch 40 = five 1 KiB load groups per halo row, so the top/bottom halo rows are whole groups (their validity
     // depends on the tile's position in the image and is decided per load on the scalar unit)
     static constexpr int PITCH = W == 32 ? 40 : W + 2;
-    static constexpr int IMG_ROWS = (TH + 2) * PITCH;             // halo rows per image part
-    static constexpr int ROWS = IMGS * IMG_ROWS;                  // 400, 324, 400, 576
+    static constexpr int IMG_ROWS = CP ? W * W + 1 : (TH + 2) * PITCH;   // halo rows per image part
+    static constexpr int ROWS = IMGS * IMG_ROWS;                  // 400, 324, 400, 576 (compact 4x4: 272)
     static constexpr int NGRP = (ROWS + 7) / 8;                   // 1 KiB groups of 8 rows
 };
 
@@ -88,10 +92,11 @@ struct H4Tile { int pt, ct, n0, y0; };                             // wave-unifo
 // the 512-channel 4x4 layers are limited by exactly that stream in the implicit GEMM)
 // BST (bf16 input gradient): the reduction pass of the BatchNorm backward that consumes dst, fused into the epilogue -- g = the bf16 output
 // where the bit of bst_mask is set, x = bst_x at the same position; `stat` receives the 128-pixel-block sums of g and of g*x.
-template <typename T, int W, int FI = 4, bool BST = false>
+template <typename T, int W, int FI = 4, bool BST = false, bool CP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1 : 2, FI == 8 ? 1 : 2))) void conv3x3s1_halo4_kernel(const Halo4Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    using G = H4Geo<W>;
+    static_assert(!CP || (W == 4 && std::is_same<T, bf16_tag>::value), "compact layout: bf16 4x4 maps");
+    using G = H4Geo<W, CP>;
     constexpr int EB = ET<T>::EB;
     constexpr int PITCH = G::PITCH, NGRP = G::NGRP;
     constexpr int CO_T = 16 * FI, NWL = FI / 2;                   // output channels per tile; weight LDS-DMA instructions per wave and tap
@@ -122,21 +127,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
         bool ok = row < G::ROWS && hx >= 1 && hx <= W;
         if constexpr (W != 32) ok = ok && hy >= 1 && hy <= G::TH;
         voffH[k] = ok ? (unsigned)(((img_l * p.H + hy) * W + hx) * row_b + (((lane & 7) ^ (hx & 7)) * 16)) : H4_OOB;
+        if constexpr (CP)                                      // row rr < 16 of an image part = its pixel rr (swizzle keyed on the pixel), row 16 = zeros
+            voffH[k] = row < G::ROWS && rr < W * W ? (unsigned)((img_l * W * W + rr) * row_b + (((lane & 7) ^ (rr & 7)) * 16)) : H4_OOB;
     }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
     // fragment j of a wave = pixels 16j..16j+15 of its 64: the same columns (W = 32: +16, same residue mod 8) a fixed number of
     // halo rows further down, so only fragment 0 needs registers -- [horizontal variant dx+1][K half]; j and the vertical tap
     // are instruction immediates
-    unsigned pa[3][2];
+    // (compact 4x4: [tap][K half] -- a fragment is one image, the tap's neighbour pixel or the image's zero row; fragment j = + j * 17 rows)
+    unsigned pa[CP ? 9 : 3][2];
     {
         const int q = wave * 64 + (lane & 15);
         const int img_l = q / (G::TH * W), qi = q - img_l * (G::TH * W);
         const int ty = qi / W, tx = qi % W;
+        if constexpr (CP) {
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            const int hrow = img_l * G::IMG_ROWS + ty * PITCH + tx + b;
+            for (int u = 0; u < 9; ++u) {
+                const int ny = ty + u / 3 - 1, nx = tx + u % 3 - 1;
+                const bool in = ny >= 0 && ny < W && nx >= 0 && nx < W;
+                const int pr = in ? ny * W + nx : W * W;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) pa[b][h] = lds0 + hrow * 128 + ((((lane >> 4) + 4 * h) ^ ((tx + b) & 7)) * 16);
+                for (int h = 0; h < 2; ++h) pa[u][h] = lds0 + (img_l * G::IMG_ROWS + pr) * 128 + ((((lane >> 4) + 4 * h) ^ (pr & 7)) * 16);
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int hrow = img_l * G::IMG_ROWS + ty * PITCH + tx + b;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) pa[b][h] = lds0 + hrow * 128 + ((((lane >> 4) + 4 * h) ^ ((tx + b) & 7)) * 16);
+            }
         }
     }
     // output offset of this lane inside a tile: pixel 64*wave + (lane & 15), channels 4*(lane >> 4) .. +3 of a 16-channel fragment
@@ -248,6 +267,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
     };
     auto rsrcA_of = [&](const H4Tile& t) {
         // origin pixel (y0-1, -1): may lie before the tensor for the first tile -- only in-image offsets are ever dereferenced
+        if constexpr (CP) return __builtin_amdgcn_make_buffer_rsrc((void*)(p.src + (long long)t.n0 * W * W * row_b), 0, G::IMGS * W * W * row_b, 0x00020000);
         const long long origin = ((long long)(t.n0 * p.H + t.y0 - 1) * W - 1) * row_b;
         return __builtin_amdgcn_make_buffer_rsrc((void*)(p.src + origin), 0, (G::IMGS * p.H * W + 2 * W + 2) * row_b, 0x00020000);
     };
@@ -347,9 +367,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
                 else issued = false;
                 uint4 wf0[FI], pf0[4], wf1[FI], pf1[4];
                 h4_static_for<0, FI>([&](auto i) { wf0[decltype(i)::value] = h4_read16<decltype(i)::value * 2048 + BUF * WT_BYTES>(wa[0]); });
-                h4_static_for<0, 4>([&](auto j) { pf0[decltype(j)::value] = h4_read16<(A * PITCH + h4_frag_rows<W>(decltype(j)::value)) * 128>(pa[B][0]); });
+                constexpr int PA = CP ? U : B;                 // which fragment address; the fragment / vertical-tap offset is an immediate
+                h4_static_for<0, 4>([&](auto j) { pf0[decltype(j)::value] = h4_read16<(CP ? decltype(j)::value * G::IMG_ROWS : A * PITCH + h4_frag_rows<W>(decltype(j)::value)) * 128>(pa[PA][0]); });
                 h4_static_for<0, FI>([&](auto i) { wf1[decltype(i)::value] = h4_read16<decltype(i)::value * 2048 + BUF * WT_BYTES>(wa[1]); });
-                h4_static_for<0, 4>([&](auto j) { pf1[decltype(j)::value] = h4_read16<(A * PITCH + h4_frag_rows<W>(decltype(j)::value)) * 128>(pa[B][1]); });
+                h4_static_for<0, 4>([&](auto j) { pf1[decltype(j)::value] = h4_read16<(CP ? decltype(j)::value * G::IMG_ROWS : A * PITCH + h4_frag_rows<W>(decltype(j)::value)) * 128>(pa[PA][1]); });
                 if constexpr (is_hsplit<T>::value) {     // fp32 operands as two scaled fp16 pieces each, three MFMAs per fragment pair (common.h)
                     h4_wait_lgkmcnt<0>();
                     split2h_t sp[4];                       // both reads of a fragment are operands already: the halo was converted in place
@@ -580,7 +601,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
 
 static unsigned h4_magic(int d) { return d <= 1 ? 0u : (unsigned)(((1ULL << 32) + (unsigned)d - 1) / (unsigned)d); }
 
-// 0: not for this kernel; 1: 64-channel tiles; 2: 128-channel tiles
+// 0: not for this kernel; 1: 64-channel tiles; 2: 128-channel tiles; 3: 64-channel tiles, compact 4x4 layout
 static int h4_variant(const fb_conv_args* a) {
     static const bool disabled = getenv("FB_DISABLE_HALO4") != nullptr;
     if (disabled) return 0;
@@ -598,14 +619,19 @@ static int h4_variant(const fb_conv_args* a) {
     static const char* wide_env = getenv("FB_H4_WIDE");
     char wtag[8];
     snprintf(wtag, sizeof(wtag), "%d", W);
-    const bool wide = a->dtype == FB_BF16 && a->Cd % 128 == 0 && (W == 4 || (wide_env && W != 32 && strstr(wide_env, wtag)));
-    if (W == 4 && !wide) return 0;
+    // 4x4 maps (bf16): the compact layout with 64-channel tiles, two workgroups per CU (FB_H4_COMPACT=0: the padded layout, which only fits
+    // 128-channel tiles with one workgroup per CU)
+    const char* cp_env = getenv("FB_H4_COMPACT");                  // read per call: the tests compare the two layouts in one process
+    const bool compact_off = cp_env != nullptr && atoi(cp_env) == 0;
+    const bool compact = W == 4 && a->dtype == FB_BF16 && !compact_off;
+    const bool wide = !compact && a->dtype == FB_BF16 && a->Cd % 128 == 0 && (W == 4 || (wide_env && W != 32 && strstr(wide_env, wtag)));
+    if (W == 4 && !wide && !compact) return 0;
     if ((long long)(imgs_per_tile * a->Hs * W + 2 * W + 2) * a->Cs * EB >= (1LL << 31)) return 0;
     const int n_pt = a->n_img * a->Hs * W / 256, n_ct = a->Cd / (wide ? 128 : 64);
     if ((long long)n_pt * n_ct * n_ct >= (1LL << 32) || (long long)a->n_img * imgs_per_wset >= (1LL << 32)) return 0;
     // fused BatchNorm-backward reduction: bf16 input gradients on 16x16 / 8x8 / 4x4 maps
     if (a->bst_x && (a->mode != 1 || !a->bst_mask || !a->stat_partial || a->dtype != FB_BF16 || W == 32)) return 0;
-    return wide ? 2 : 1;
+    return compact ? 3 : (wide ? 2 : 1);
 }
 
 int fb_conv3x3_halo4_takes(const fb_conv_args* a) { return h4_variant(a) != 0; }
@@ -642,6 +668,11 @@ int fb_try_conv3x3_halo4(const fb_conv_args* a, hipStream_t st) {
     static const int wg_per_cu = getenv("FB_H4_WG_PER_CU") ? atoi(getenv("FB_H4_WG_PER_CU")) : 2;
     const int slots = (wg_per_cu == 1 ? 1 : 2) * n_cu;
     dim3 grid(p.n_tiles < slots ? p.n_tiles : slots);
+    if (variant == 3) {
+        if (a->bst_x) hipLaunchKernelGGL((conv3x3s1_halo4_kernel<bf16_tag, 4, 4, true, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv3x3s1_halo4_kernel<bf16_tag, 4, 4, false, true>), grid, dim3(256), 0, st, p);
+        return 1;
+    }
     if (a->bst_x) {
         dim3 grid1(p.n_tiles < n_cu ? p.n_tiles : n_cu);
         if (wide && W == 16) hipLaunchKernelGGL((conv3x3s1_halo4_kernel<bf16_tag, 16, 8, true>), grid1, dim3(256), 0, st, p);

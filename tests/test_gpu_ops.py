@@ -51,12 +51,12 @@ def krsc(w):  # [co, ci, kh, kw] -> [co, kh*kw, ci]
                                                    (64, 64, 3, 1, 8, 2400), (64, 128, 3, 1, 16, 300), (64, 64, 3, 1, 32, 160),   # > 2 tiles per persistent workgroup
                                                    (32, 64, 1, 1, 32, 40), (32, 64, 1, 1, 32, 300),   # stem on patches: streaming K = 32 kernel (bf16), grid-stride
                                                    (64, 128, 3, 2, 32, 3), (128, 256, 3, 2, 16, 6), (96, 64, 3, 2, 16, 4),   # more stride-2 shapes
-                                                   (128, 128, 3, 1, 4, 48), (512, 512, 3, 1, 4, 272), (64, 256, 3, 1, 4, 16),   # 4x4 maps: 128-channel halo tiles (bf16)
+                                                   (128, 128, 3, 1, 4, 48), (512, 512, 3, 1, 4, 272), (64, 256, 3, 1, 4, 16), (64, 64, 3, 1, 4, 32),   # 4x4 maps: compact halo layout (bf16)
                                                    # short-K 1x1 convolutions: streaming kernel (bf16), every (K, channels-per-wave) variant, ragged pixel counts,
                                                    # several units per persistent workgroup
                                                    (64, 128, 1, 1, 16, 3), (128, 256, 1, 1, 8, 5), (256, 512, 1, 1, 4, 16), (256, 1024, 1, 1, 14, 2), (64, 256, 1, 1, 8, 3),
                                                    (128, 128, 1, 1, 8, 40), (256, 128, 1, 1, 6, 3), (64, 128, 1, 1, 6, 3), (64, 128, 1, 1, 16, 700), (256, 256, 1, 1, 14, 300)])
-def test_conv_fwd_and_stats(dtype, cin, cout, k, stride, hw, n):
+def test_conv_fwd_and_stats(dtype, cin, cout, k, stride, hw, n, monkeypatch):
     lib = _lib()
     torch.manual_seed(0)
     pad = k // 2
@@ -75,6 +75,12 @@ def test_conv_fwd_and_stats(dtype, cin, cout, k, stride, hw, n):
     refn = nhwc(ref).reshape(-1, cout)
     assert rel(stat[0].sum(0).cpu(), refn.sum(0)) < 1e-4
     assert rel(stat[1].sum(0).cpu(), (refn * refn).sum(0)) < 1e-4
+    if hw == 4 and k == 3 and dtype == torch.bfloat16 and cout % 128 == 0:
+        # the padded 4x4 layout with 128-channel tiles (FB_H4_COMPACT=0) adds the same products in the same order plus zeros: same bits
+        monkeypatch.setenv("FB_H4_COMPACT", "0")
+        out2, stat2 = torch.empty_like(out), torch.zeros_like(stat)
+        lib.conv2d(xd, wd, out2, k, k, stride, pad, 0, stat_partial=stat2)
+        assert torch.equal(out, out2) and torch.equal(stat, stat2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -86,7 +92,7 @@ def test_conv_fwd_and_stats(dtype, cin, cout, k, stride, hw, n):
                                                           # stride-2 quad kernel (bf16): dY 16x16 / 8x8 / 4x4, ragged image counts, all addend modes
                                                           (64, 128, 3, 2, 32, 3, 2), (128, 256, 3, 2, 16, 5, 1), (64, 64, 3, 2, 8, 11, 2),
                                                           (128, 96, 3, 2, 16, 2, 0), (64, 128, 3, 2, 32, 70, 0),
-                                                          (256, 128, 3, 1, 4, 32, 1), (128, 256, 3, 1, 4, 16, 0), (512, 512, 3, 1, 4, 272, 1),   # 4x4 maps, 128-channel halo tiles
+                                                          (256, 128, 3, 1, 4, 32, 1), (128, 256, 3, 1, 4, 16, 0), (512, 512, 3, 1, 4, 272, 1), (64, 64, 3, 1, 4, 16, 2),   # 4x4 maps: compact halo layout
                                                           # 1x1 input gradients: streaming kernel (K = the forward layer's output channels <= 256), with / without the
                                                           # same-shape addend; pooled addend and K = 512 stay on the implicit GEMM
                                                           (256, 128, 1, 1, 8, 5, 0), (1024, 256, 1, 1, 7, 4, 1), (512, 128, 1, 1, 8, 3, 1), (128, 64, 1, 1, 16, 300, 1),
@@ -116,6 +122,11 @@ def test_conv_dgrad(dtype, cin, cout, k, stride, hw, n, amode, monkeypatch):
     out = torch.empty(n, hw, hw, cin, dtype=dtype, device="cuda")
     lib.conv2d(dyd, wt, out, k, k, stride, pad, 1, addend=add_d, addend_mode=amode)
     assert rel(nchw(out.float().cpu()), ref) < tol(dtype)
+    if hw == 4 and k == 3 and stride == 1 and dtype == torch.bfloat16 and cin % 128 == 0:
+        monkeypatch.setenv("FB_H4_COMPACT", "0")       # padded 4x4 layout, 128-channel tiles: same bits
+        out2 = torch.empty_like(out)
+        lib.conv2d(dyd, wt, out2, k, k, stride, pad, 1, addend=add_d, addend_mode=amode)
+        assert torch.equal(out, out2)
     if stride == 2 and dtype == torch.bfloat16:
         # the quad kernel's double-buffered one-workgroup form (FB_S2Q_STAGES=2) accumulates in the same order: same bits
         monkeypatch.setenv("FB_S2Q_STAGES", "2")
