@@ -112,12 +112,33 @@ template <int W> struct W3Geo<W, 2> {
     static constexpr int blk_rows(int, int R) { return R * PITCH; }
     __device__ static __forceinline__ int fB(int row) { return (row >> 1) & 3; }
 };
+// 4x4 maps, stride 1, COMPACT: an image is its 16 pixels + ONE zero row (17 halo rows instead of 6 x 16), a K-step is four whole images
+// (64 pixels, 11 KiB of halo + 8 KiB of dY instead of 24 + 4 KiB for 32 pixels): a third of the LDS-DMA bytes and half the barriers per
+// MFMA.  A lane's tap neighbour (or the image's zero row) is one of nine address registers per 4-pixel half instead of three.
+struct W3GeoCP4 {
+    static constexpr bool PER_BLOCK = false;
+    static constexpr int VALID = 64, KPX = 64, PITCH = 4, RS = 4, IMGS = 4;
+    static constexpr int IMG_ROWS = 17;                                        // two images per 32-pixel block: rows 0..33 of the block
+    static constexpr int BLK_ROWS = 48;                                        // block pitch: a multiple of 16 rows (the swizzle bits of a row must not depend on the block)
+    static constexpr int HROWS = 88;                                           // 48 + 34 rows, padded to whole 1 KiB groups
+    static constexpr int HI_DELTA = 4;
+    static constexpr bool WHOLE = true;
+    // halo row of pixel pl in [0,32) (block 0) for tap u: the neighbour pixel, or the zero row of the image
+    __device__ static __forceinline__ int tap_row(int pl, int u) {
+        const int img = pl / 16, y = (pl % 16) / 4 + u / 3 - 1, x = pl % 4 + u % 3 - 1;
+        return img * IMG_ROWS + ((y >= 0 && y < 4 && x >= 0 && x < 4) ? y * 4 + x : 16);
+    }
+    __device__ static __forceinline__ int lane_row(int, int) { return 0; }
+    static constexpr int blk_rows(int BLK, int) { return BLK * BLK_ROWS; }
+    __device__ static __forceinline__ int fB(int row) { return w3_f(row); }
+};
 }  // namespace
 
-template <int W, int SD>
+template <int W, int SD, bool CP = false>
 __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    using G = W3Geo<W, SD>;
+    static_assert(!CP || (W == 4 && SD == 1), "compact layout: 4x4 maps, stride 1");
+    using G = typename std::conditional<CP, W3GeoCP4, W3Geo<W, SD>>::type;
     constexpr int WI = SD * W;                          // input width; p.H is the OUTPUT height
     const int Hi = SD * p.H;
     constexpr int KPX = G::KPX, PITCH = G::PITCH, HROWS = G::HROWS;
@@ -172,7 +193,11 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Par
         const int lslot = ((lane & 7) >> 1) ^ G::fB(row);
         const bool xok = hx >= 1 && hx <= WI && (wave + 4 * k) < NGB;
         const unsigned base = (unsigned)((img_l * Hi * WI + (hx - 1)) * rowB_b + tile_n * 128 + lslot * 32 + (lane & 1) * 16);
-        if constexpr (G::WHOLE) {
+        if constexpr (CP) {                                                    // block b = rows 48 b ..: image i at + 17 i, its pixel q at + q, row 16 = zeros
+            const int blk = row / W3GeoCP4::BLK_ROWS, rb = row % W3GeoCP4::BLK_ROWS, im = rb / 17, q = rb % 17;
+            hyB[k] = 0;
+            voffB[k] = (blk < 2 && rb < 34 && q < 16) ? (unsigned)(((blk * 2 + im) * 16 + q) * rowB_b + tile_n * 128 + lslot * 32 + (lane & 1) * 16) : W3_OOB;
+        } else if constexpr (G::WHOLE) {
             const int sy = hy - 1;
             hyB[k] = 0;
             voffB[k] = (xok && sy >= 0 && sy < WI) ? base + (unsigned)(sy * WI * rowB_b) : W3_OOB;
@@ -216,14 +241,16 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Par
 #pragma unroll
     for (int i = 0; i < 4; ++i) la[i] = lds0 + pl * 128 + ((i ^ w3_f(pl)) * 32) + (t & 3) * 8;
     // B: halo row = lane_row(pl, s) + immediate; slot = wave ^ f(row); the read of pixels +4 has its own registers
-    constexpr int NBLK = G::PER_BLOCK ? KPX / 32 : 1;
-    unsigned lb[NBLK][3], lbh[NBLK][3];
+    // (compact 4x4: one register per TAP -- index s runs over the nine taps)
+    constexpr int NBLK = G::PER_BLOCK ? KPX / 32 : 1, NS = CP ? 9 : 3;
+    unsigned lb[NBLK][NS], lbh[NBLK][NS];
 #pragma unroll
     for (int blk = 0; blk < NBLK; ++blk)
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
+        for (int s = 0; s < NS; ++s) {
             int row, rowh;
-            if constexpr (G::PER_BLOCK) { row = G::pix_row(blk * 32 + pl, s); rowh = G::pix_row(blk * 32 + pl + 4, s); }
+            if constexpr (CP) { row = W3GeoCP4::tap_row(pl, s); rowh = W3GeoCP4::tap_row(pl + 4, s); }
+            else if constexpr (G::PER_BLOCK) { row = G::pix_row(blk * 32 + pl, s); rowh = G::pix_row(blk * 32 + pl + 4, s); }
             else { row = G::lane_row(pl, s); rowh = row + G::HI_DELTA; }
             lb[blk][s] = lds0 + A_BYTES + row * 128 + ((wave ^ G::fB(row)) * 32) + (t & 3) * 8;
             lbh[blk][s] = lds0 + A_BYTES + rowh * 128 + ((wave ^ G::fB(rowh)) * 32) + (t & 3) * 8;
@@ -251,9 +278,9 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Par
             constexpr int BLK = decltype(blkc)::value;
             constexpr int PB = BLK * 32;                                  // first pixel of the 32-pixel block
             constexpr int BI = G::PER_BLOCK ? BLK : 0;
-            unsigned b0[3], b1[3];
+            unsigned b0[NS], b1[NS];
 #pragma unroll
-            for (int s = 0; s < 3; ++s) { b0[s] = lb[BI][s] + so; b1[s] = lbh[BI][s] + so; }
+            for (int s = 0; s < NS; ++s) { b0[s] = lb[BI][s] + so; b1[s] = lbh[BI][s] + so; }
             uint4 af[4];
             w3_static_for<0, 4>([&](auto ic) {
                 constexpr int I = decltype(ic)::value;
@@ -265,8 +292,8 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Par
                 constexpr int B0 = decltype(bc)::value * 3;
                 w3_static_for<B0, B0 + 3>([&](auto uc) {
                     constexpr int U = decltype(uc)::value, R = U / 3, S = U % 3;
-                    constexpr int OFF = G::blk_rows(BLK, R) * 128;
-                    bf[U] = w3_join(w3_read_tr<OFF>(b0[S]), w3_read_tr<OFF>(b1[S]));
+                    constexpr int OFF = G::blk_rows(BLK, R) * 128, BS = CP ? U : S;
+                    bf[U] = w3_join(w3_read_tr<OFF>(b0[BS]), w3_read_tr<OFF>(b1[BS]));
                 });
                 w3_wait_lgkmcnt<0>();
 #pragma unroll
@@ -309,7 +336,12 @@ int fb_try_wgrad3x3_v2(const fb_wgrad_args* a, hipStream_t st) {
     if (a->Cs % 64 != 0 || a->Cd % 64 != 0) return 0;
     // K slices are whole images; the last slice of a chunk may be shorter (or empty: it then contributes zeros)
     int imgs_per_block = (a->imgs_per_group + a->split_k - 1) / a->split_k;
-    if (W == 4) { if (a->imgs_per_group & 1) return 0; imgs_per_block += imgs_per_block & 1; }   // 4x4 maps: image pairs per K-step
+    // 4x4 maps: image pairs per K-step; stride 1 with chunks of a multiple of four images: the compact layout, four images per K-step
+    // (FB_WGRAD3_COMPACT=0: the padded layout)
+    const char* cp_env = getenv("FB_WGRAD3_COMPACT");
+    const bool compact = W == 4 && SD == 1 && a->imgs_per_group % 4 == 0 && !(cp_env && atoi(cp_env) == 0);
+    if (compact) imgs_per_block = (imgs_per_block + 3) / 4 * 4;
+    else if (W == 4) { if (a->imgs_per_group & 1) return 0; imgs_per_block += imgs_per_block & 1; }
     // (a workgroup addresses its own K slice only: at most a chunk)
     const long long bytes_x = (long long)(imgs_per_block + 2) * a->Hs * a->Ws * a->Cs * 2, bytes_dy = (long long)(imgs_per_block + 2) * a->Hd * a->Wd * a->Cd * 2;
     if (bytes_x >= (1LL << 31) || bytes_dy >= (1LL << 31)) return 0;
@@ -327,6 +359,7 @@ int fb_try_wgrad3x3_v2(const fb_wgrad_args* a, hipStream_t st) {
         else if (W == 32) hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<32, 1>), grid, dim3(256), 0, st, p);
         else if (W == 16) hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<16, 1>), grid, dim3(256), 0, st, p);
         else if (W == 8) hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<8, 1>), grid, dim3(256), 0, st, p);
+        else if (compact) hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<4, 1, true>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<4, 1>), grid, dim3(256), 0, st, p);
     } else {
         if (W == 16) hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<16, 2>), grid, dim3(256), 0, st, p);

@@ -194,6 +194,7 @@ def test_conv_f32_fp16x2_split(cin, cout, k, stride, hw, n, magnitude):
                                                                   (64, 128, 3, 1, 16, 6, 1, 3),
                                                                   (128, 64, 3, 1, 8, 6, 2, 2), (64, 128, 3, 1, 4, 8, 2, 2),    # 8x8 / 4x4 maps
                                                                   (64, 64, 3, 1, 4, 6, 1, 3), (64, 64, 3, 1, 4, 6, 1, 2),
+                                                                  (128, 64, 3, 1, 4, 12, 2, 2), (64, 64, 3, 1, 4, 20, 1, 3), (512, 512, 3, 1, 4, 128, 2, 1),   # 4x4, compact halo (chunks of 4k images)
                                                                   (64, 128, 3, 2, 32, 4, 2, 2), (128, 64, 3, 2, 16, 6, 1, 3), (64, 64, 3, 2, 8, 8, 2, 2),   # stride 2, all taps
                                                                   (128, 128, 3, 2, 16, 5, 1, 1),
                                                                   (64, 64, 3, 1, 16, 10, 2, 3), (64, 64, 3, 1, 32, 7, 1, 4), (64, 64, 3, 1, 4, 10, 2, 3), (64, 128, 3, 2, 16, 7, 2, 5),   # ragged K slices
@@ -204,7 +205,7 @@ def test_conv_f32_fp16x2_split(cin, cout, k, stride, hw, n, magnitude):
                                                                   (256, 1024, 1, 1, 7, 4, 2, 3), (1024, 256, 1, 1, 7, 4, 1, 2), (64, 256, 1, 1, 8, 3, 2, 2), (256, 64, 1, 1, 8, 3, 1, 1),
                                                                   (128, 128, 1, 1, 8, 5, 2, 3), (64, 128, 1, 1, 8, 4, 1, 2), (128, 64, 1, 1, 6, 3, 2, 2), (512, 128, 1, 1, 14, 2, 2, 5),
                                                                   (256, 512, 1, 1, 4, 4, 1, 8)])
-def test_conv_wgrad(dtype, cin, cout, k, stride, hw, ipg, groups, split):
+def test_conv_wgrad(dtype, cin, cout, k, stride, hw, ipg, groups, split, monkeypatch):
     lib = _lib()
     torch.manual_seed(2)
     pad = k // 2
@@ -222,6 +223,14 @@ def test_conv_wgrad(dtype, cin, cout, k, stride, hw, ipg, groups, split):
         ref = torch.nn.grad.conv2d_weight(x[sl], (cout, cin, k, k), dy[sl], stride, pad)
         got = out[g, : cout * k * k * cin].view(cout, k, k, cin).permute(0, 3, 1, 2).cpu()
         assert rel(got, ref) < (1e-5 if dtype == torch.float32 else 1e-5), (g, rel(got, ref))
+    if hw == 4 and k == 3 and stride == 1 and ipg % 4 == 0 and dtype == torch.bfloat16:
+        # the padded 4x4 layout (image pairs per K-step) adds the same products in the same order plus zeros: same bits
+        monkeypatch.setenv("FB_WGRAD3_COMPACT", "0")
+        slab2 = torch.full_like(slab, float("nan"))
+        lib.conv2d_wgrad(xd, dyd, slab2, k, k, stride, pad, ipg, split)
+        monkeypatch.delenv("FB_WGRAD3_COMPACT")
+        if ((ipg + split - 1) // split) % 4 == 0:          # same K slices in both layouts
+            assert torch.equal(slab, slab2)
     if split == 1:      # group_stride: per-chunk gradients written straight into arena rows, no reduce pass
         arena = torch.full((groups, cout * k * k * cin + 40), float("nan"), device="cuda")
         lib.conv2d_wgrad(xd, dyd, arena[:, 8:], k, k, stride, pad, ipg, 1, group_stride=arena.shape[1])
