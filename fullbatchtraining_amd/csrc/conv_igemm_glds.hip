@@ -38,7 +38,9 @@ __device__ __forceinline__ int xcd_remap1d(int b, int n) {
 }
 #define FB_OOB 0x80000000u
 
-template <typename T, int BN_CO>
+// STAGES 2: the loads of K-step t+1 are in flight while step t is multiplied (64 KiB: two workgroups per CU); STAGES 1: one 32 KiB (24 KiB)
+// stage -- the waves wait for their own loads, and three resident workgroups per CU cover each other's waits, prologues and epilogues
+template <typename T, int BN_CO, int STAGES = 2>
 __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(const ConvParams p, const int mblocks, const int n_co) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource builtins do not exist there)
     constexpr int EB = ET<T>::EB;
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(const ConvParams p, 
     constexpr int WROWS = BN_CO / 32;
     constexpr int FI = BN_CO / 32, FJ = 4;
     constexpr int TILE_BYTES = (128 + BN_CO) * 128;
-    __shared__ __attribute__((aligned(16))) char lds[2 * TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) char lds[STAGES * TILE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -163,12 +165,20 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(const ConvParams p, 
     const unsigned pb = lds0 + (wave_px * 64 + (lane & 15)) * 128;
 
     if (n_iter > 0) {
-        advance(); issue(0);
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
+        if constexpr (STAGES == 2) {
+            advance(); issue(0);
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+        }
         for (int it = 0; it < n_iter; ++it) {
-            const int cur = it & 1;
-            if (it + 1 < n_iter) { advance(); issue(cur ^ 1); }
+            const int cur = STAGES == 2 ? (it & 1) : 0;
+            if constexpr (STAGES == 2) {
+                if (it + 1 < n_iter) { advance(); issue(cur ^ 1); }
+            } else {
+                advance(); issue(0);
+                wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+            }
             const unsigned so = cur * TILE_BYTES;
             const unsigned w0 = wb + pc0 + so, w1 = wb + pc1 + so, p0 = pb + pc0 + so, p1 = pb + pc1 + so;
             uint4 wf0[FI], pf0[FJ], wf1[FI], pf1[FJ];
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(const ConvParams p, 
 #pragma unroll
                 for (int j = 0; j < FJ; ++j) acc[i][j] = mma_chunk<T>(wf1[i], pf1[j], acc[i][j]);
             }
-            wait_vmcnt<0>();
+            if constexpr (STAGES == 2) wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
         }
     }
@@ -294,6 +304,21 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(const ConvParams p, 
 
 template <typename T> static void launch(const ConvParams& p, int classes, hipStream_t st) {
     const int mblocks = (p.M + 127) / 128;
+    if constexpr (std::is_same<T, bf16_tag>::value) {
+        // bf16: one stage, three workgroups per CU (12 544 images, stride-2 forward 64->128 / 128->256 / 256->512: 936 / 587 / 493 us against
+        // 1001 / 669 / 561 with two stages and two workgroups); FB_IGEMM_STAGES=2 selects the double-buffered form (read per call: tests compare)
+        const char* e = getenv("FB_IGEMM_STAGES");
+        if (!(e && atoi(e) == 2)) {
+            if (p.Cd % 128 == 0 && (long long)mblocks * (p.Cd / 128) * classes >= 512) {
+                const int n_co = p.Cd / 128;
+                hipLaunchKernelGGL((conv_igemm_v3_kernel<T, 128, 1>), dim3(mblocks * n_co * classes), dim3(256), 0, st, p, mblocks, n_co);
+            } else {
+                const int n_co = p.Cd / 64;
+                hipLaunchKernelGGL((conv_igemm_v3_kernel<T, 64, 1>), dim3(mblocks * n_co * classes), dim3(256), 0, st, p, mblocks, n_co);
+            }
+            return;
+        }
+    }
     if (p.Cd % 128 == 0 && (long long)mblocks * (p.Cd / 128) * classes >= 512) {
         const int n_co = p.Cd / 128;
         hipLaunchKernelGGL((conv_igemm_v3_kernel<T, 128>), dim3(mblocks * n_co * classes), dim3(256), 0, st, p, mblocks, n_co);

@@ -75,6 +75,12 @@ def test_conv_fwd_and_stats(dtype, cin, cout, k, stride, hw, n, monkeypatch):
     refn = nhwc(ref).reshape(-1, cout)
     assert rel(stat[0].sum(0).cpu(), refn.sum(0)) < 1e-4
     assert rel(stat[1].sum(0).cpu(), (refn * refn).sum(0)) < 1e-4
+    if stride == 2 and dtype == torch.bfloat16:
+        # implicit GEMM: the double-buffered two-workgroup form (FB_IGEMM_STAGES=2) multiplies the same K-steps in the same order
+        monkeypatch.setenv("FB_IGEMM_STAGES", "2")
+        out2, stat2 = torch.empty_like(out), torch.zeros_like(stat)
+        lib.conv2d(xd, wd, out2, k, k, stride, pad, 0, stat_partial=stat2)
+        assert torch.equal(out, out2) and torch.equal(stat, stat2)
     if hw == 4 and k == 3 and dtype == torch.bfloat16 and cout % 128 == 0:
         # the padded 4x4 layout with 128-channel tiles (FB_H4_COMPACT=0) adds the same products in the same order plus zeros: same bits
         monkeypatch.setenv("FB_H4_COMPACT", "0")
