@@ -24,9 +24,9 @@ def main():
     img = 98 * 128
     conv = {"conv3x3s1_c64_halo5": 2 * 1024 * 64 * 9 * 64, "conv3x3s1_halo4_kernel<bf16_tag, 16,": 2 * 256 * 128 * 9 * 128,
             "conv3x3s1_halo4_kernel<bf16_tag, 8,": 2 * 64 * 256 * 9 * 256, "conv3x3s1_halo4_kernel<bf16_tag, 4,": 2 * 16 * 512 * 9 * 512,
-            "conv_wgrad3x3_v2_kernel<32, 1>": 2 * 1024 * 64 * 9 * 64,
-            "conv_wgrad3x3_v2_kernel<16, 1>": 2 * 256 * 128 * 9 * 128, "conv_wgrad3x3_v2_kernel<8, 1>": 2 * 64 * 256 * 9 * 256,
-            "conv_wgrad3x3_v2_kernel<4, 1>": 2 * 16 * 512 * 9 * 512}
+            "conv_wgrad3x3_v2_kernel<32, 1,": 2 * 1024 * 64 * 9 * 64,
+            "conv_wgrad3x3_v2_kernel<16, 1,": 2 * 256 * 128 * 9 * 128, "conv_wgrad3x3_v2_kernel<8, 1,": 2 * 64 * 256 * 9 * 256,
+            "conv_wgrad3x3_v2_kernel<4, 1,": 2 * 16 * 512 * 9 * 512}
     print("| kernel | launches / step | us / launch | ms / step | HBM MB / launch | TB/s | of 6.3 | TFLOP/s | of 2500 | nearer wall |")
     print("|---|---|---|---|---|---|---|---|---|---|")
     rows = []
