@@ -308,17 +308,19 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Par
 
     // fp32 slab [co][tap][ci].  (Staging the tiles through LDS for 16-byte, 256-byte-contiguous stores was measured: no gain --
     // the epilogue costs what writing the per-chunk fp32 gradients to HBM costs, e.g. 283 MB per launch for a 512x512 layer.)
+    // One buffer descriptor per slab, one per-lane offset, the (tap, fragment, row) part as a SCALAR offset: a store costs one s_mul instead of the
+    // seven vector instructions (two 64-bit multiply-adds among them) of the pointer form (~1000 VALU instructions per workgroup before)
     float* out = p.out + group * p.group_stride + ((long long)split * p.Cd) * 9 * p.Cs;
+    const __amdgpu_buffer_rsrc_t rsrcO = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, p.Cd * 9 * p.Cs * 4, 0x00020000);
+    const int voffO = (((tile_m * 64 + (lane >> 4) * 4) * 9) * p.Cs + tile_n * 64 + wave * 16 + (lane & 15)) * 4;
+    const int row4 = p.Cs * 4;
 #pragma unroll
     for (int u = 0; u < 9; ++u)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int co = tile_m * 64 + i * 16 + (lane >> 4) * 4 + q;
-                const int ci = tile_n * 64 + wave * 16 + (lane & 15);
-                out[((long long)co * 9 + u) * p.Cs + ci] = acc[u][i][q];
-            }
+            for (int q = 0; q < 4; ++q)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[u][i][q]), rsrcO, voffO, ((i * 16 + q) * 9 + u) * row4, 0);
 #endif
 }
 
