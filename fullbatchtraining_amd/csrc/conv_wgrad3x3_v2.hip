@@ -26,6 +26,7 @@ struct Wgrad3V2Params {
     int n_img, H, Cs, Cd;
     int imgs_per_group, imgs_per_block, split_k;
     long long group_stride;
+    int n_chains; float* sq_part;                            // CHAIN: see conv_wgrad3x3_v2_kernel
 };
 
 namespace {
@@ -134,21 +135,31 @@ struct W3GeoCP4 {
 };
 }  // namespace
 
-template <int W, int SD, bool CP = false>
-__global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Params p) {
+// CHAIN (compact 4x4 only): the SUM of the chunk gradients instead of one gradient per chunk.  The reference's statistics need every chunk's
+// gradient norm, so the per-chunk form writes 147 KiB of fp32 per workgroup and chunk (7 of the 11 M parameters of ResNet-18 sit in the three
+// 512 -> 512 layers: 2.8 GB per chunk group written here and read again by fb_mt_accumulate).  Here workgroup (tile, s) of n_chains walks chunks
+// s, s + n_chains, ... : per chunk it accumulates the chunk's tile, adds its sum of squares to sq_part[chunk][tile][wave], folds it into a second
+// register set and starts over; at the end it writes ONE tile, slab s of n_chains (fb_wgrad_reduce adds the slabs in fixed order).  Two
+// accumulator sets do not fit next to 64 output channels per wave: EIGHT waves, a wave owns 16 ci x 9 taps x 32 co (72 + 72 registers).
+template <int W, int SD, bool CP = false, bool CHAIN = false>
+__global__ __launch_bounds__(CHAIN ? 512 : 256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(!CP || (W == 4 && SD == 1), "compact layout: 4x4 maps, stride 1");
+    static_assert(!CHAIN || CP, "chunk chains: compact 4x4 layout");
+    constexpr int NWV = CHAIN ? 8 : 4, FIW = CHAIN ? 2 : 4;     // waves per workgroup; 16-channel dY fragments per wave
     using G = typename std::conditional<CP, W3GeoCP4, W3Geo<W, SD>>::type;
     constexpr int WI = SD * W;                          // input width; p.H is the OUTPUT height
     const int Hi = SD * p.H;
     constexpr int KPX = G::KPX, PITCH = G::PITCH, HROWS = G::HROWS;
     constexpr int A_BYTES = KPX * 128, B_BYTES = HROWS * 128, STAGE = A_BYTES + B_BYTES;
     constexpr int NGA = KPX / 8, NGB = HROWS / 8;      // 1 KiB row groups of the dY tile / of the halo
-    constexpr int KA = (NGA + 3) / 4, KB = (NGB + 3) / 4;
+    constexpr int KA = (NGA + NWV - 1) / NWV, KB = (NGB + NWV - 1) / NWV;
+    // (CHAIN: three stages with counted waits were measured -- 897 us against 807 us with two at 512->512, 98 chunks, 8 chains)
     __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cib = CHAIN ? (wave & 3) : wave, coh = CHAIN ? (wave >> 2) : 0;      // the wave's 16-channel block of X; (CHAIN) its 32-channel half of dY
     // 1-D grid, XCD-aware order: workgroups are dealt to the 8 XCDs round-robin, so the remap makes consecutive work items
     // live on ONE XCD -- the (Cd/64)*(Cs/64) tiles of a (chunk, K slice) read the same dY rows and X halos and now share them
     // in that XCD's L2 (PMC: every launch fetched ~1.3 GB before, dY and X once per tile row / column)
@@ -161,11 +172,15 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Par
     }
     const int tile = item % tiles, gs = item / tiles;
     const int tile_m = __builtin_amdgcn_readfirstlane(tile / tiles_n), tile_n = __builtin_amdgcn_readfirstlane(tile % tiles_n);
-    const int group = __builtin_amdgcn_readfirstlane(gs / p.split_k), split = __builtin_amdgcn_readfirstlane(gs % p.split_k);
-    const int img0 = group * p.imgs_per_group + split * p.imgs_per_block;
-    const int img_end = min(img0 + p.imgs_per_block, (group + 1) * p.imgs_per_group);
+    const int group = __builtin_amdgcn_readfirstlane(CHAIN ? gs : gs / p.split_k), split = __builtin_amdgcn_readfirstlane(CHAIN ? 0 : gs % p.split_k);
+    // CHAIN: `group` is the chain index s; the descriptors cover the whole tensors and a step addresses its images from there
+    const int n_chunks = p.n_img / p.imgs_per_group;
+    const int my_chunks = CHAIN ? (n_chunks - group + p.n_chains - 1) / p.n_chains : 0;
+    const int spc = p.imgs_per_group / G::IMGS;             // (CHAIN) K-steps per chunk
+    const int img0 = CHAIN ? 0 : group * p.imgs_per_group + split * p.imgs_per_block;
+    const int img_end = CHAIN ? p.n_img : min(img0 + p.imgs_per_block, (group + 1) * p.imgs_per_group);
     const int steps_per_img = G::WHOLE ? 1 : p.H / G::RS;
-    const int n_steps = G::WHOLE ? (img_end - img0) / G::IMGS : (img_end - img0) * steps_per_img;
+    const int n_steps = CHAIN ? my_chunks * spc : (G::WHOLE ? (img_end - img0) / G::IMGS : (img_end - img0) * steps_per_img);
     const int rowA_b = p.Cd * 2, rowB_b = p.Cs * 2;    // bytes per pixel of dY / X
     const int lrow8 = lane >> 3;
 
@@ -180,18 +195,18 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Par
     unsigned voffA[KA];
 #pragma unroll
     for (int k = 0; k < KA; ++k) {
-        const int row = (wave + 4 * k) * 8 + lrow8;                          // pixel of the step
+        const int row = (wave + NWV * k) * 8 + lrow8;                        // pixel of the step
         const int lslot = ((lane & 7) >> 1) ^ w3_f(row);
         voffA[k] = row < G::VALID ? (unsigned)(row * rowA_b + tile_m * 128 + lslot * 32 + (lane & 1) * 16) : W3_OOB;
     }
     int hyB[KB]; unsigned voffB[KB];
 #pragma unroll
     for (int k = 0; k < KB; ++k) {
-        const int row = (wave + 4 * k) * 8 + lrow8;                          // halo row index
+        const int row = (wave + NWV * k) * 8 + lrow8;                        // halo row index
         const int img_l = row / G::IMG_ROWS, rr = row - img_l * G::IMG_ROWS;
         const int hy = rr / PITCH, hx = rr - hy * PITCH;
         const int lslot = ((lane & 7) >> 1) ^ G::fB(row);
-        const bool xok = hx >= 1 && hx <= WI && (wave + 4 * k) < NGB;
+        const bool xok = hx >= 1 && hx <= WI && (wave + NWV * k) < NGB;
         const unsigned base = (unsigned)((img_l * Hi * WI + (hx - 1)) * rowB_b + tile_n * 128 + lslot * 32 + (lane & 1) * 16);
         if constexpr (CP) {                                                    // block b = rows 48 b ..: image i at + 17 i, its pixel q at + q, row 16 = zeros
             const int blk = row / W3GeoCP4::BLK_ROWS, rb = row % W3GeoCP4::BLK_ROWS, im = rb / 17, q = rb % 17;
@@ -209,24 +224,25 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Par
     auto issue = [&](int stage, int step) {
         char* base = lds + stage * STAGE;
         int img, y0;
-        if constexpr (G::WHOLE) { img = step * G::IMGS; y0 = 0; }                        // (image index relative to img0)
+        if constexpr (CHAIN) { img = (group + (step / spc) * p.n_chains) * p.imgs_per_group + (step % spc) * G::IMGS; y0 = 0; }
+        else if constexpr (G::WHOLE) { img = step * G::IMGS; y0 = 0; }                   // (image index relative to img0)
         else { img = step / steps_per_img; y0 = (step % steps_per_img) * G::RS; }
         const int soffA = (img * p.H + y0) * W * rowA_b;
 #pragma unroll
         for (int k = 0; k < KA; ++k)
-            if (wave + 4 * k < NGA)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)(base + (wave + 4 * k) * 1024), 16,
+            if (wave + NWV * k < NGA)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)(base + (wave + NWV * k) * 1024), 16,
                                                          voffA[k], soffA, 0, 0);
         const int soffB = img * Hi * WI * rowB_b;
 #pragma unroll
         for (int k = 0; k < KB; ++k) {
-            if (wave + 4 * k < NGB) {
+            if (wave + NWV * k < NGB) {
                 unsigned v = voffB[k];
                 if constexpr (!G::WHOLE) {
                     const int sy = SD * y0 + hyB[k];
                     v = (unsigned)sy < (unsigned)Hi ? voffB[k] + (unsigned)(sy * WI * rowB_b) : W3_OOB;
                 }
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (__attribute__((address_space(3))) void*)(base + A_BYTES + (wave + 4 * k) * 1024),
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (__attribute__((address_space(3))) void*)(base + A_BYTES + (wave + NWV * k) * 1024),
                                                          16, v, soffB, 0, 0);
             }
         }
@@ -237,9 +253,9 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Par
     const int t = lane & 15, g = lane >> 4;
     const int pl = g * 8 + (t >> 2);                     // pixel within the 32-pixel block (low half of the 8-pixel run)
     // A: row = pb + pl (+4); slot = i ^ f(row)   (f is independent of pb (multiple of 32) and of the +4: pl & 4 == 0)
-    unsigned la[4];
+    unsigned la[FIW];                                    // (CHAIN: fragments 2 coh, 2 coh + 1 of the tile's four)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) la[i] = lds0 + pl * 128 + ((i ^ w3_f(pl)) * 32) + (t & 3) * 8;
+    for (int i = 0; i < FIW; ++i) la[i] = lds0 + pl * 128 + (((i + coh * FIW) ^ w3_f(pl)) * 32) + (t & 3) * 8;
     // B: halo row = lane_row(pl, s) + immediate; slot = wave ^ f(row); the read of pixels +4 has its own registers
     // (compact 4x4: one register per TAP -- index s runs over the nine taps)
     constexpr int NBLK = G::PER_BLOCK ? KPX / 32 : 1, NS = CP ? 9 : 3;
@@ -252,15 +268,18 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Par
             if constexpr (CP) { row = W3GeoCP4::tap_row(pl, s); rowh = W3GeoCP4::tap_row(pl + 4, s); }
             else if constexpr (G::PER_BLOCK) { row = G::pix_row(blk * 32 + pl, s); rowh = G::pix_row(blk * 32 + pl + 4, s); }
             else { row = G::lane_row(pl, s); rowh = row + G::HI_DELTA; }
-            lb[blk][s] = lds0 + A_BYTES + row * 128 + ((wave ^ G::fB(row)) * 32) + (t & 3) * 8;
-            lbh[blk][s] = lds0 + A_BYTES + rowh * 128 + ((wave ^ G::fB(rowh)) * 32) + (t & 3) * 8;
+            lb[blk][s] = lds0 + A_BYTES + row * 128 + ((cib ^ G::fB(row)) * 32) + (t & 3) * 8;
+            lbh[blk][s] = lds0 + A_BYTES + rowh * 128 + ((cib ^ G::fB(rowh)) * 32) + (t & 3) * 8;
         }
 
-    f32x4_t acc[9][4];
+    f32x4_t acc[9][FIW], tot[CHAIN ? 9 : 1][CHAIN ? FIW : 1];
 #pragma unroll
     for (int u = 0; u < 9; ++u)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[u][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < FIW; ++i) {
+            acc[u][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            if constexpr (CHAIN) tot[u][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
 
     if (n_steps > 0) {
         issue(0, 0);
@@ -271,9 +290,9 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Par
         const int cur = step & 1;
         if (step + 1 < n_steps) issue(cur ^ 1, step + 1);
         const unsigned so = cur * STAGE;
-        unsigned a0[4];
+        unsigned a0[FIW];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a0[i] = la[i] + so;
+        for (int i = 0; i < FIW; ++i) a0[i] = la[i] + so;
         w3_static_for<0, KPX / 32>([&](auto blkc) {
             constexpr int BLK = decltype(blkc)::value;
             constexpr int PB = BLK * 32;                                  // first pixel of the 32-pixel block
@@ -281,8 +300,8 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Par
             unsigned b0[NS], b1[NS];
 #pragma unroll
             for (int s = 0; s < NS; ++s) { b0[s] = lb[BI][s] + so; b1[s] = lbh[BI][s] + so; }
-            uint4 af[4];
-            w3_static_for<0, 4>([&](auto ic) {
+            uint4 af[FIW];
+            w3_static_for<0, FIW>([&](auto ic) {
                 constexpr int I = decltype(ic)::value;
                 af[I] = w3_join(w3_read_tr<PB * 128>(a0[I]), w3_read_tr<PB * 128 + 512>(a0[I]));
             });
@@ -299,9 +318,27 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Par
 #pragma unroll
                 for (int u = B0; u < B0 + 3; ++u)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[u][i] = mma_chunk<bf16_tag>(af[i], bf[u], acc[u][i]);
+                    for (int i = 0; i < FIW; ++i) acc[u][i] = mma_chunk<bf16_tag>(af[i], bf[u], acc[u][i]);
             });
         });
+        if constexpr (CHAIN) {
+            if (step % spc == spc - 1) {                 // the chunk's tile is complete: its sum of squares, fold it into the total, start over
+                float sq = 0.f;
+#pragma unroll
+                for (int u = 0; u < 9; ++u)
+#pragma unroll
+                    for (int i = 0; i < FIW; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            sq = fmaf(acc[u][i][q], acc[u][i][q], sq);
+                            tot[u][i][q] += acc[u][i][q];
+                            acc[u][i][q] = 0.f;
+                        }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+                if (lane == 0) p.sq_part[((long long)(group + (step / spc) * p.n_chains) * tiles + tile) * 8 + wave] = sq;
+            }
+        }
         w3_wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
     }
@@ -310,17 +347,17 @@ __global__ __launch_bounds__(256) void conv_wgrad3x3_v2_kernel(const Wgrad3V2Par
     // the epilogue costs what writing the per-chunk fp32 gradients to HBM costs, e.g. 283 MB per launch for a 512x512 layer.)
     // One buffer descriptor per slab, one per-lane offset, the (tap, fragment, row) part as a SCALAR offset: a store costs one s_mul instead of the
     // seven vector instructions (two 64-bit multiply-adds among them) of the pointer form (~1000 VALU instructions per workgroup before)
-    float* out = p.out + group * p.group_stride + ((long long)split * p.Cd) * 9 * p.Cs;
+    float* out = CHAIN ? p.out + ((long long)group * p.Cd) * 9 * p.Cs : p.out + group * p.group_stride + ((long long)split * p.Cd) * 9 * p.Cs;
     const __amdgpu_buffer_rsrc_t rsrcO = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, p.Cd * 9 * p.Cs * 4, 0x00020000);
-    const int voffO = (((tile_m * 64 + (lane >> 4) * 4) * 9) * p.Cs + tile_n * 64 + wave * 16 + (lane & 15)) * 4;
+    const int voffO = (((tile_m * 64 + coh * 32 + (lane >> 4) * 4) * 9) * p.Cs + tile_n * 64 + cib * 16 + (lane & 15)) * 4;
     const int row4 = p.Cs * 4;
 #pragma unroll
     for (int u = 0; u < 9; ++u)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < FIW; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[u][i][q]), rsrcO, voffO, ((i * 16 + q) * 9 + u) * row4, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(CHAIN ? tot[u][i][q] : acc[u][i][q]), rsrcO, voffO, ((i * 16 + q) * 9 + u) * row4, 0);
 #endif
 }
 
@@ -352,6 +389,7 @@ int fb_try_wgrad3x3_v2(const fb_wgrad_args* a, hipStream_t st) {
     p.n_img = a->n_img; p.H = a->Hd; p.Cs = a->Cs; p.Cd = a->Cd;
     p.imgs_per_group = a->imgs_per_group; p.split_k = a->split_k; p.imgs_per_block = imgs_per_block;
     p.group_stride = a->group_stride ? a->group_stride : (long long)a->split_k * a->Cd * 9 * a->Cs;
+    p.n_chains = 0; p.sq_part = nullptr;
     const int n_groups = a->n_img / a->imgs_per_group;
     dim3 grid((a->Cd / 64) * (a->Cs / 64) * n_groups * a->split_k);
     if (SD == 1) {
@@ -369,4 +407,35 @@ int fb_try_wgrad3x3_v2(const fb_wgrad_args* a, hipStream_t st) {
         else hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<4, 2>), grid, dim3(256), 0, st, p);
     }
     return 1;
+}
+
+// ---- chunk-chained form (bf16, 3x3 / stride 1 / pad 1 on 4x4 maps): the SUM over the chunks + every chunk's sum of squares ----------------------
+static bool w3_chain_ok(const fb_wgrad_args* a) {
+    static const bool disabled = getenv("FB_DISABLE_WGRAD3_CHAIN") != nullptr;
+    if (disabled || !a || a->dtype != FB_BF16) return false;
+    if (a->R != 3 || a->S != 3 || a->pad != 1 || a->stride != 1) return false;
+    if (a->Hd != 4 || a->Wd != 4 || a->Hs != 4 || a->Ws != 4) return false;
+    if (a->Cs % 64 != 0 || a->Cd % 64 != 0 || a->imgs_per_group < 4 || a->imgs_per_group % 4 != 0 || a->n_img % a->imgs_per_group != 0) return false;
+    if (a->bn_x || a->amax_x || a->amax_dy) return false;
+    // a workgroup addresses the whole tensors from one descriptor
+    if ((long long)a->n_img * 16 * a->Cs * 2 >= (1LL << 31) || (long long)a->n_img * 16 * a->Cd * 2 >= (1LL << 31)) return false;
+    return true;
+}
+
+extern "C" int32_t fb_wgrad_chain_supported(const fb_wgrad_args* a) { return w3_chain_ok(a) ? 1 : 0; }
+
+extern "C" int fb_conv2d_wgrad_chain(const fb_wgrad_args* a, int32_t n_chains, float* slabs, float* sq_part, void* stream) {
+    if (!a || !a->x || !a->dy || !slabs || !sq_part) FB_FAIL(FB_ERR_ARG, "fb_conv2d_wgrad_chain: null pointer");
+    if (!w3_chain_ok(a)) FB_FAIL(FB_ERR_UNSUPPORTED, "fb_conv2d_wgrad_chain: bf16 3x3 / stride 1 / pad 1 weight gradients on 4x4 maps, channels in multiples of 64, chunks of 4k images");
+    const int n_chunks = a->n_img / a->imgs_per_group;
+    if (n_chains < 1 || n_chains > n_chunks) FB_FAIL(FB_ERR_ARG, "fb_conv2d_wgrad_chain: n_chains=%d for %d chunks", n_chains, n_chunks);
+    Wgrad3V2Params p;
+    p.x = (const char*)a->x; p.dy = (const char*)a->dy; p.out = slabs;
+    p.n_img = a->n_img; p.H = a->Hd; p.Cs = a->Cs; p.Cd = a->Cd;
+    p.imgs_per_group = a->imgs_per_group; p.split_k = 1; p.imgs_per_block = a->imgs_per_group;
+    p.group_stride = 0; p.n_chains = n_chains; p.sq_part = sq_part;
+    dim3 grid((a->Cd / 64) * (a->Cs / 64) * n_chains);
+    hipLaunchKernelGGL((conv_wgrad3x3_v2_kernel<4, 1, true, true>), grid, dim3(512), 0, (hipStream_t)stream, p);
+    FB_CHECK_LAUNCH("fb_conv2d_wgrad_chain");
+    return FB_OK;
 }

@@ -123,6 +123,23 @@ extern "C" int fb_mt_accumulate(float* avg, const float* g, int64_t group_stride
     return FB_OK;
 }
 
+// ---- running mean advanced by a whole batch of chunks from their sum (chunk-chained weight gradients) ------------------------------------
+__global__ __launch_bounds__(256) void mt_accumulate_sum_kernel(float* __restrict__ avg, const float* __restrict__ gsum, long long n, float n_groups, float inv) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float a = avg[i];
+        avg[i] = a + (gsum[i] - n_groups * a) * inv;
+    }
+}
+
+extern "C" int fb_mt_accumulate_sum(float* avg, const float* gsum, int64_t n, int32_t counter0, int32_t n_groups, void* stream) {
+    if (!avg || !gsum) FB_FAIL(FB_ERR_ARG, "fb_mt_accumulate_sum: null pointer");
+    if (n_groups < 1 || counter0 < 0) FB_FAIL(FB_ERR_ARG, "fb_mt_accumulate_sum: n_groups=%d counter0=%d", n_groups, counter0);
+    hipLaunchKernelGGL(mt_accumulate_sum_kernel, dim3(mt_blocks(n)), dim3(256), 0, (hipStream_t)stream, avg, gsum, (long long)n, (float)n_groups,
+                       (float)(1.0 / (double)(counter0 + n_groups)));
+    FB_CHECK_LAUNCH("fb_mt_accumulate_sum");
+    return FB_OK;
+}
+
 // ---- finite-difference perturbation: theta[g] = theta0 + sign*eps_n[g]*(s*g[g] + acc*pre) ---------------------------------
 __global__ void mt_epsn_kernel(const float* __restrict__ vnorm2, float eps, float* __restrict__ eps_n, int n_groups) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;

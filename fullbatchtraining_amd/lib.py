@@ -10,7 +10,7 @@ import struct
 import torch
 
 FB_F32, FB_BF16 = 0, 1
-EXPECTED_ABI = 11         # fb_abi_version() the ctypes structs / signatures below were written for
+EXPECTED_ABI = 12         # fb_abi_version() the ctypes structs / signatures below were written for
 MT_BLOCKS = 1024
 _LIB_PATH = os.environ.get("FB_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libfbengine.so")     # (FB_LIB_PATH: A/B builds, tools/build_variant.py)
 
@@ -83,10 +83,12 @@ _SIGS = {
     "fb_mt_ema": [c_void_p, c_void_p, c_i64, c_float, c_float, c_void_p],
     "fb_mt_clip_scale": [c_void_p, c_i64, c_void_p, c_float, c_void_p],
     "fb_mt_grad_noise": [c_void_p, c_void_p, c_i64, c_float, c_int, c_void_p],
+    "fb_conv2d_wgrad_chain": [C.POINTER(WgradArgs), c_int, c_void_p, c_void_p, c_void_p],
+    "fb_mt_accumulate_sum": [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p],
 }
 EXPORTS = tuple(_SIGS) + ("fb_last_error_string", "fb_abi_version", "fb_profile_enable", "fb_profile_read", "fb_ws_conv_stat_floats",
                           "fb_ws_wgrad_slab_floats", "fb_ws_bn_partial_floats", "fb_ws_mt_floats", "fb_bn_bwd_reduce_rows", "fb_conv_masked_addend_supported", "fb_conv_bwd_stat_supported",
-                          "fb_bn_apply_can_pool", "fb_ws_bn_amax_floats", "fb_profile_read_launches", "fb_cmd_fn_id", "fb_cmd_fn_nargs", "fb_event_new", "fb_event_count", "fb_bn_bwd_fused_supported", "fb_ws_bn_bwd_fused_floats", "fb_ws_bn_bwd_fused_ints", "fb_wgrad_bn_fused_supported",
+                          "fb_bn_apply_can_pool", "fb_ws_bn_amax_floats", "fb_profile_read_launches", "fb_cmd_fn_id", "fb_cmd_fn_nargs", "fb_event_new", "fb_event_count", "fb_bn_bwd_fused_supported", "fb_ws_bn_bwd_fused_floats", "fb_ws_bn_bwd_fused_ints", "fb_wgrad_bn_fused_supported", "fb_wgrad_chain_supported",
                           "fb_event_record", "fb_event_wait", "fb_cmdlist_create", "fb_cmdlist_destroy", "fb_cmdlist_size", "fb_cmdlist_add_call",
                           "fb_cmdlist_add_event", "fb_cmdlist_replay")
 PROF_CLASSES = ("igemm_fwd", "igemm_dgrad", "wgrad", "bn_apply", "bn_bwd_reduce", "bn_bwd_apply", "bn_bwd_fused")
@@ -164,6 +166,7 @@ def load():
         lib.fb_ws_bn_bwd_fused_floats.argtypes, lib.fb_ws_bn_bwd_fused_floats.restype = [c_i64, c_int, c_i64, c_int], c_i64
         lib.fb_ws_bn_bwd_fused_ints.argtypes, lib.fb_ws_bn_bwd_fused_ints.restype = [c_i64], c_i64
         lib.fb_wgrad_bn_fused_supported.argtypes, lib.fb_wgrad_bn_fused_supported.restype = [C.POINTER(WgradArgs)], c_int
+        lib.fb_wgrad_chain_supported.argtypes, lib.fb_wgrad_chain_supported.restype = [C.POINTER(WgradArgs)], c_int
         lib.fb_cmd_fn_id.argtypes, lib.fb_cmd_fn_id.restype = [C.c_char_p], c_int
         lib.fb_cmd_fn_nargs.argtypes, lib.fb_cmd_fn_nargs.restype = [c_int], c_int
         lib.fb_event_new.argtypes, lib.fb_event_new.restype = [], c_int

@@ -136,6 +136,15 @@ typedef struct {
 } fb_wgrad_args;
 int32_t fb_wgrad_bn_fused_supported(const fb_wgrad_args* a);
 int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream);
+/* Chunk-chained weight gradient (ABI v12; bf16, 3x3 / stride 1 / pad 1 on 4x4 maps, chunks = imgs_per_group of 4k images;
+ * fb_wgrad_chain_supported): the SUM over the chunks of what fb_conv2d_wgrad writes per chunk, plus every chunk's sum of squares -- the two
+ * things the accumulate-over-all-chunks loop keeps of a chunk gradient (running mean: reference training.py:45-47,163-165; grad_norms:
+ * training.py:162).  Workgroup (tile, s) walks chunks s, s + n_chains, ... and writes ONE fp32 tile:
+ *   slabs   [n_chains][Cd][9][Cs]        partial sums; fb_wgrad_reduce(slabs, out, 0, 1, n_chains, Cd, 9, Cs, Cs) adds them in fixed order
+ *   sq_part [n_img/imgs_per_group][(Cd/64)*(Cs/64)][8]   per chunk: partial sums of squares of that chunk's gradient (sum them per chunk)
+ * a->dw_partial, split_k and group_stride are ignored.  The sum differs from adding the per-chunk results one by one only in rounding. */
+int32_t fb_wgrad_chain_supported(const fb_wgrad_args* a);
+int fb_conv2d_wgrad_chain(const fb_wgrad_args* a, int32_t n_chains, float* slabs, float* sq_part, void* stream);
 
 /* Workspace sizes (in floats) of the caller-owned scratch buffers the entry points below take; host-side arithmetic only,
  * no launch.  The library never allocates device memory.
@@ -282,6 +291,9 @@ int fb_mt_sqnorm(const float* x, int64_t group_stride, int32_t n_groups, int64_t
  * If sq_out != NULL also writes sq_out[j] = |g[j]|^2 (fused, one pass). */
 int fb_mt_accumulate(float* avg, const float* g, int64_t group_stride, int32_t n_groups, int64_t n, int32_t counter0,
                      float* sq_out, float* ws, void* stream);
+/* the running mean advanced by n_groups chunks at once from their SUM (fb_conv2d_wgrad_chain + fb_wgrad_reduce):
+ * avg += (gsum - n_groups*avg) / (counter0 + n_groups) -- what n_groups steps of fb_mt_accumulate's recurrence amount to (ABI v12) */
+int fb_mt_accumulate_sum(float* avg, const float* gsum, int64_t n, int32_t counter0, int32_t n_groups, void* stream);
 /* eps_n[g] = eps / sqrt(vnorm2[g]);  theta_out[g] = theta0 + (sign*eps_n[g]) * (s*g[g] + acc*pre)   (modules.py:217-226;
  * pre = the pre-computed full gradient of the acc_strength pre-pass, training.py:128-142, NULL without it) */
 int fb_mt_fd_perturb(const float* theta0, const float* g, int64_t group_stride, int32_t n_groups, int64_t n, float s,

@@ -244,6 +244,38 @@ def test_conv_wgrad(dtype, cin, cout, k, stride, hw, ipg, groups, split, monkeyp
         assert bool(torch.isnan(arena[:, :8]).all()) and bool(torch.isnan(arena[:, 8 + cout * k * k * cin:]).all())
 
 
+@pytest.mark.parametrize("cin,cout,ipg,chunks,chains", [(64, 64, 8, 5, 2), (128, 64, 16, 7, 3), (64, 128, 4, 6, 6), (512, 512, 128, 9, 4), (256, 128, 12, 3, 1)])
+def test_conv_wgrad_chunk_chain(cin, cout, ipg, chunks, chains):
+    """fb_conv2d_wgrad_chain (ABI v12): the sum over the chunks of the per-chunk weight gradients and every chunk's sum of squares, against the
+    per-chunk kernel (whose chunk gradients are held to torch by test_conv_wgrad): same products, the sum taken in another order."""
+    lib = _lib()
+    torch.manual_seed(5)
+    n = ipg * chunks
+    x = q(torch.randn(n, cin, 4, 4), torch.bfloat16)
+    dy = q(torch.randn(n, cout, 4, 4), torch.bfloat16)
+    xd, dyd = nhwc(x).to(torch.bfloat16).cuda(), nhwc(dy).to(torch.bfloat16).cuda()
+    per = torch.full((chunks, 1, cout, 9, cin), float("nan"), device="cuda")
+    lib.conv2d_wgrad(xd, dyd, per, 3, 3, 1, 1, ipg, 1)
+    per = per[:, 0].double()
+    a = lib.WgradArgs(xd.data_ptr(), dyd.data_ptr(), None, n, 4, 4, cin, 4, 4, cout, 3, 3, 1, 1, ipg, 1, lib.dtype_code(torch.bfloat16), 0)
+    assert lib.load().fb_wgrad_chain_supported(lib.C.byref(a))
+    tiles = (cout // 64) * (cin // 64)
+    slabs = torch.full((chains, cout, 9, cin), float("nan"), device="cuda")
+    sqp = torch.full((chunks, tiles, 8), float("nan"), device="cuda")
+    lib.call("fb_conv2d_wgrad_chain", lib.C.byref(a), chains, slabs.data_ptr(), sqp.data_ptr())
+    total = torch.full((cout, 9, cin), float("nan"), device="cuda")
+    lib.wgrad_reduce(slabs, total, 0, 1, chains, cout, 9, cin, cin)
+    want = per.sum(0)
+    assert float((total.double() - want).norm() / want.norm()) < 2e-6
+    sq = sqp.double().sum((1, 2))
+    ref = per.pow(2).sum((1, 2, 3))
+    assert float(((sq - ref).abs() / ref).max()) < 1e-5, (sq, ref)
+    # a chain's slab = the sum of ITS chunks
+    for s_ in range(chains):
+        w = per[s_::chains].sum(0)
+        assert float((slabs[s_].double() - w).norm() / w.norm()) < 2e-6
+
+
 @pytest.mark.parametrize("magnitude", [1.0, 2e-6])
 @pytest.mark.parametrize("cin,cout,k,stride,hw,ipg,groups,split", [(64, 64, 3, 1, 8, 8, 2, 3), (64, 128, 3, 2, 8, 8, 1, 2), (256, 256, 3, 1, 4, 16, 2, 1),
                                                                   (128, 256, 1, 1, 4, 16, 1, 2), (32, 64, 1, 1, 8, 4, 2, 1), (64, 64, 3, 1, 32, 4, 2, 2),
