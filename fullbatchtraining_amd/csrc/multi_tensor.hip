@@ -61,9 +61,12 @@ extern "C" int fb_mt_sqnorm(const float* x, int64_t group_stride, int32_t n_grou
 // ---- running mean over the chunks of a group batch (+ fused per-chunk squared norms) --------------------------------------
 // Up to 8 chunks per launch are folded into the running mean in registers (static unroll keeps the per-chunk norm
 // accumulators out of scratch); the host wrapper walks larger batches 8 at a time.
+// (skip: up to four ranges [lo, hi) of 16-byte vectors that the pass leaves alone -- the layers whose running mean comes from their group sum,
+// fb_mt_accumulate_sum; their arena rows hold nothing)
+struct MtSkip { long long lo[4], hi[4]; };
 template <bool SQ>
 __global__ __launch_bounds__(256) void mt_accumulate_kernel(float* __restrict__ avg, const float* __restrict__ g, long long gstride, int n_groups,
-                                                            long long n, int counter0, float* __restrict__ ws) {
+                                                            long long n, int counter0, float* __restrict__ ws, const MtSkip skip) {
     constexpr int NG = 8;
     __shared__ float sm[8 * NG];
     const long long n4 = n / 4;
@@ -71,6 +74,7 @@ __global__ __launch_bounds__(256) void mt_accumulate_kernel(float* __restrict__ 
 #pragma unroll
     for (int j = 0; j < NG; ++j) { sq[j] = 0.f; inv[j] = (float)(1.0 / (double)(counter0 + j + 1)); }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        if ((i >= skip.lo[0] && i < skip.hi[0]) || (i >= skip.lo[1] && i < skip.hi[1]) || (i >= skip.lo[2] && i < skip.hi[2]) || (i >= skip.lo[3] && i < skip.hi[3])) continue;
         float4 a = ((float4*)avg)[i];
 #pragma unroll
         for (int j = 0; j < NG; ++j)
@@ -102,8 +106,8 @@ __global__ __launch_bounds__(256) void mt_accumulate_kernel(float* __restrict__ 
     }
 }
 
-extern "C" int fb_mt_accumulate(float* avg, const float* g, int64_t group_stride, int32_t n_groups, int64_t n, int32_t counter0, float* sq_out,
-                                float* ws, void* stream) {
+static int mt_accumulate_impl(float* avg, const float* g, int64_t group_stride, int32_t n_groups, int64_t n, int32_t counter0, float* sq_out,
+                              float* ws, const MtSkip& skip, void* stream) {
     if (!avg || !g) FB_FAIL(FB_ERR_ARG, "fb_mt_accumulate: null pointer");
     if (sq_out && !ws) FB_FAIL(FB_ERR_ARG, "fb_mt_accumulate: workspace required for norms");
     if (((uintptr_t)avg & 15) || ((uintptr_t)g & 15) || (group_stride & 3)) FB_FAIL(FB_ERR_ARG, "fb_mt_accumulate: 16-byte alignment required");
@@ -113,14 +117,33 @@ extern "C" int fb_mt_accumulate(float* avg, const float* g, int64_t group_stride
         const float* gj = g + (long long)j0 * group_stride;
         if (sq_out)
             hipLaunchKernelGGL((mt_accumulate_kernel<true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, avg, gj, (long long)group_stride, ng,
-                               (long long)n, counter0 + j0, ws + (long long)j0 * FB_MT_BLOCKS);
+                               (long long)n, counter0 + j0, ws + (long long)j0 * FB_MT_BLOCKS, skip);
         else
             hipLaunchKernelGGL((mt_accumulate_kernel<false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, avg, gj, (long long)group_stride, ng,
-                               (long long)n, counter0 + j0, ws);
+                               (long long)n, counter0 + j0, ws, skip);
     }
     if (sq_out) hipLaunchKernelGGL(mt_finalize_kernel, dim3(n_groups), dim3(256), 0, (hipStream_t)stream, ws, sq_out, nb, n_groups);
     FB_CHECK_LAUNCH("fb_mt_accumulate");
     return FB_OK;
+}
+
+extern "C" int fb_mt_accumulate(float* avg, const float* g, int64_t group_stride, int32_t n_groups, int64_t n, int32_t counter0, float* sq_out,
+                                float* ws, void* stream) {
+    return mt_accumulate_impl(avg, g, group_stride, n_groups, n, counter0, sq_out, ws, MtSkip{{0, 0, 0, 0}, {0, 0, 0, 0}}, stream);
+}
+
+// fb_mt_accumulate over [0, n) except up to four ranges [skip_lo[k], skip_hi[k]) (multiples of 4 floats; lo == hi: unused): neither read nor
+// written, and they do not enter the norms -- the layers that take their mean from fb_mt_accumulate_sum (ABI v12)
+extern "C" int fb_mt_accumulate_skip(float* avg, const float* g, int64_t group_stride, int32_t n_groups, int64_t n, int32_t counter0, float* sq_out,
+                                     float* ws, int64_t lo0, int64_t hi0, int64_t lo1, int64_t hi1, int64_t lo2, int64_t hi2, int64_t lo3, int64_t hi3,
+                                     void* stream) {
+    const int64_t lo[4] = {lo0, lo1, lo2, lo3}, hi[4] = {hi0, hi1, hi2, hi3};
+    MtSkip skip;
+    for (int k = 0; k < 4; ++k) {
+        if (lo[k] < 0 || hi[k] < lo[k] || hi[k] > n || (lo[k] & 3) || (hi[k] & 3)) FB_FAIL(FB_ERR_ARG, "fb_mt_accumulate_skip: range %d = [%lld, %lld) of %lld", k, (long long)lo[k], (long long)hi[k], (long long)n);
+        skip.lo[k] = lo[k] / 4; skip.hi[k] = hi[k] / 4;
+    }
+    return mt_accumulate_impl(avg, g, group_stride, n_groups, n, counter0, sq_out, ws, skip, stream);
 }
 
 // ---- running mean advanced by a whole batch of chunks from their sum (chunk-chained weight gradients) ------------------------------------

@@ -377,6 +377,37 @@ class Engine:
                 n_img=n, imgs_per_group=self.chunk, split_k=L.split_k, Cd=L.cout, R=L.R, S=L.S, Cs=L.cin_pad))))
         self.stat_ws = torch.empty(max_part, **f32)
         self.slab_ws = torch.empty(max_slab, **f32)
+        # Chunk-chained weight gradients (fb_conv2d_wgrad_chain; full_gradient's plain bf16 path): for the 3x3 layers on 4x4 maps -- 7 of the 11 M
+        # parameters of ResNet-18 -- the kernel leaves the SUM of the group's chunk gradients in ``gsum`` and every chunk's sum of squares in
+        # ``L.chain_sq`` instead of one fp32 gradient per chunk in the arena (2.8 GB per group written there and read again by the running mean).
+        self.chain_layers, self.chain_on = [], False
+        # OPT-IN (FB_WGRAD_CHAIN=1): the running-mean pass drops from 4.0 to 1.7 ms/step, but the chained kernel -- one 8-wave workgroup per CU with
+        # two accumulator sets -- takes 840 us where the per-chunk kernel with two independent 4-wave workgroups takes 692 (profiles/r4_notes.md)
+        if dt == torch.bfloat16 and os.environ.get("FB_WGRAD_CHAIN", "0") == "1":
+            for L in self.plan.layers:
+                a = lib.WgradArgs(None, None, None, n, L.hin, L.win, L.cin_pad, L.hout, L.wout, L.cout, L.R, L.S, L.stride, L.pad, self.chunk, 1, self.dtc, 0)
+                # (at most four: fb_mt_accumulate_skip leaves four ranges of the arena alone)
+                if (len(self.chain_layers) < 4 and L.split_k == 1 and L.cin_pad == L.cin_real and L.w_off % 4 == 0
+                        and bool(lib.load().fb_wgrad_chain_supported(lib.C.byref(a)))):
+                    L.chain_tiles = (L.cout // 64) * (L.cin_pad // 64)
+                    # one 8-wave workgroup per CU and chain; FB_WGRAD_CHAINS overrides the number of chains per tile
+                    L.n_chains = int(os.environ.get("FB_WGRAD_CHAINS", "0")) or max(1, 512 // L.chain_tiles)
+                    L.chain_sq = torch.zeros(self.G, L.chain_tiles * 8, **f32)
+                    self.chain_layers.append(L)
+        if self.chain_layers:
+            self.chain_ws = torch.empty(max(min(L.n_chains, self.G) * L.cout * L.taps * L.cin_pad for L in self.chain_layers), **f32)
+            self.gsum = torch.zeros(self.plan.P, **f32)
+            # the arena ranges that stay per chunk: [0, P) minus the chained layers' weights
+            cuts, lo = [], 0
+            for L in sorted(self.chain_layers, key=lambda l: l.w_off):
+                if L.w_off > lo:
+                    cuts.append((lo, L.w_off))
+                lo = L.w_off + L.cout * L.taps * L.cin_real
+            if lo < self.plan.P:
+                cuts.append((lo, self.plan.P))
+            assert all(a % 4 == 0 for a, _ in cuts), cuts
+            self.plain_segments = cuts
+            self.sq_seg = torch.zeros(len(cuts), self.G, **f32)
         self.stem_out = torch.empty(n, self.plan.stem.hout, self.plan.stem.wout, 64, device=dev, dtype=dt)
         if self.plan.stem_pool:
             hp = (self.plan.stem.hout + 1) // 2
@@ -764,6 +795,25 @@ class Engine:
         n = G * self.chunk
         if bn is not None:
             dx = bn[0]
+        if self.chain_on and bn is None and any(L is c for c in self.chain_layers):
+            # the group's SUM into gsum[w_off:] + the chunks' sums of squares into L.chain_sq (no arena rows for this layer)
+            S = min(L.n_chains, G)
+            a = lib.WgradArgs(src.data_ptr(), dx.data_ptr(), None, n, L.hin, L.win, L.cin_pad, L.hout, L.wout, L.cout, L.R, L.S, L.stride, L.pad,
+                              self.chunk, 1, self.dtc, 0)
+
+            def launch_chain():
+                call("fb_conv2d_wgrad_chain", lib.C.byref(a), S, self.chain_ws.data_ptr(), L.chain_sq.data_ptr())
+                call("fb_wgrad_reduce", self.chain_ws.data_ptr(), self.gsum.data_ptr() + 4 * L.w_off, 0, 1, S, L.cout, L.taps, L.cin_pad, L.cin_real)
+
+            if self.wstream is None:
+                launch_chain()
+                return
+            ready = self.events.record()
+            with torch.cuda.stream(self.wstream):
+                self.events.wait(ready)
+                launch_chain()
+                self._wgrad_event = self.events.record()
+            return
         # one K slice and no channel padding: the kernel writes the per-chunk gradients straight into the arena rows
         direct = L.split_k == 1 and L.cin_pad == L.cin_real
         am_x = am_dy = None
@@ -964,7 +1014,33 @@ class Engine:
         if on_block_done is not None or getattr(self, "_eval", False):
             return body()                            # (a host callback inside the sequence: the multi-GPU late bucket)
         self._replayable(("group", patches.data_ptr(), labels.data_ptr(), G, gout.data_ptr(), wsets, theta.data_ptr(), pidx, self.chunk, self.valid,
-                          float(self.label_smoothing), bool(self.only_incorrect), self.fuse_bwd_stat), body)
+                          float(self.label_smoothing), bool(self.only_incorrect), self.fuse_bwd_stat, self.chain_on), body)
+
+    def _fold(self, gbuf, g_n, lo, hi, counter, sq_out, ws):
+        """The running mean over [lo, hi) of the arena advanced by the ``g_n`` chunks in ``gbuf`` (+ their squared norms over that range into
+        ``sq_out[:g_n]``): fb_mt_accumulate; with chained weight gradients the chained layers from their group sum (fb_mt_accumulate_sum), the
+        rest per chunk with those ranges left alone (fb_mt_accumulate_skip), the norms as the sum of the two kinds of parts."""
+        P = self.plan.P
+        if not self.chain_on:
+            call("fb_mt_accumulate", self.avg.data_ptr() + 4 * lo, gbuf.data_ptr() + 4 * lo, P, g_n, hi - lo, counter, _ptr(sq_out), ws.data_ptr())
+            return
+        parts, skips = [], []
+        for L in self.chain_layers:
+            size = L.cout * L.taps * L.cin_real
+            if lo <= L.w_off and L.w_off + size <= hi:
+                call("fb_mt_accumulate_sum", self.avg.data_ptr() + 4 * L.w_off, self.gsum.data_ptr() + 4 * L.w_off, size, counter, g_n)
+                parts.append(L.chain_sq[:g_n].sum(1))
+                skips += [L.w_off - lo, L.w_off - lo + size]
+            elif L.w_off < hi and L.w_off + size > lo:
+                raise lib.EngineError("a chained layer straddles the bucket boundary")
+        if len(skips) > 8:
+            raise lib.EngineError("more than four chained layers in one range")
+        skips += [0] * (8 - len(skips))
+        call("fb_mt_accumulate_skip", self.avg.data_ptr() + 4 * lo, gbuf.data_ptr() + 4 * lo, P, g_n, hi - lo, counter,
+             self.sq_seg[0].data_ptr() if sq_out is not None else None, ws.data_ptr(), *skips)
+        parts.append(self.sq_seg[0, :g_n])
+        if sq_out is not None:
+            sq_out[:g_n].copy_(torch.stack(parts).sum(0))
 
     # --------------------------------------------------------------------------------------- full-batch gradient + step --
     def full_gradient(self, patches, labels, lr, block_strength=0.0, eps=1e-2, implementation="forward-differences",
@@ -1047,6 +1123,8 @@ class Engine:
         if overlap and getattr(self, "g_alt", None) is None:
             self.g_alt, self.acc_ws = torch.zeros_like(self.g), torch.zeros_like(self.mt_ws)
         done, group_idx = 0, 0
+        # chained weight gradients: only where nothing needs a chunk's gradient itself (no regulariser, no per-chunk clip)
+        self.chain_on = bool(self.chain_layers) and not fd and batch_clip is None
         if late_bucket is not None and getattr(self, "side", None) is None:
             self.side = torch.cuda.Stream(device=self.device)
             self.sq_late, self.ws_late = torch.zeros_like(self.sq), torch.zeros_like(self.mt_ws)
@@ -1075,8 +1153,7 @@ class Engine:
                         self.side.wait_event(ev)
                     n_late = P - lb
                     if not fd:
-                        call("fb_mt_accumulate", self.avg.data_ptr() + 4 * lb, self.g.data_ptr() + 4 * lb, P, _g_n, n_late, counter0 + _done,
-                             self.sq_late.data_ptr(), self.ws_late.data_ptr())
+                        self._fold(self.g, _g_n, lb, P, counter0 + _done, self.sq_late, self.ws_late)
                     else:
                         gb = self.g_fd[1] if central else self.g
                         call("fb_mt_fd_combine_accumulate", self.avg.data_ptr() + 4 * lb, self.g.data_ptr() + 4 * lb, self.g_fd[0].data_ptr() + 4 * lb,
@@ -1092,16 +1169,14 @@ class Engine:
                 ready = torch.cuda.current_stream().record_event()
                 with torch.cuda.stream(self.wstream):
                     self.wstream.wait_event(ready)
-                    call("fb_mt_accumulate", self.avg.data_ptr(), gbuf.data_ptr(), P, g_n, P, counter0 + done, sq_all.data_ptr() + 4 * done,
-                         self.acc_ws.data_ptr())
+                    self._fold(gbuf, g_n, 0, P, counter0 + done, sq_all[done:done + g_n], self.acc_ws)
             elif not fd and batch_clip is not None:
                 call("fb_mt_sqnorm", self.g.data_ptr(), P, g_n, P, 1.0, None, 0.0, self.sq.data_ptr(), self.mt_ws.data_ptr())
                 call("fb_mt_chunk_clip", self.g.data_ptr(), P, g_n, P, self.sq.data_ptr(), float(batch_clip), self.clipped.data_ptr())
                 call("fb_mt_accumulate", self.avg.data_ptr(), self.g.data_ptr(), P, g_n, P, counter0 + done, None, self.mt_ws.data_ptr())
             elif not fd:
                 # (with an early late bucket the slice [lb, P) has been folded on the side stream; |g_k|^2 is the sum of the two parts)
-                call("fb_mt_accumulate", self.avg.data_ptr(), self.g.data_ptr(), P, g_n, lb if early else P, counter0 + done, self.sq.data_ptr(),
-                     self.mt_ws.data_ptr())
+                self._fold(self.g, g_n, 0, lb if early else P, counter0 + done, self.sq, self.mt_ws)
                 if early:
                     torch.cuda.current_stream().wait_stream(self.side)
                     self.sq[:g_n].add_(self.sq_late[:g_n])
@@ -1144,6 +1219,7 @@ class Engine:
             done += g_n
         if overlap:
             torch.cuda.current_stream().wait_stream(self.wstream)
+        self.chain_on = False
         return loss_all, correct_all, sq_all
 
     def check_device_errors(self):

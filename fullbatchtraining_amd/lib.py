@@ -85,6 +85,7 @@ _SIGS = {
     "fb_mt_grad_noise": [c_void_p, c_void_p, c_i64, c_float, c_int, c_void_p],
     "fb_conv2d_wgrad_chain": [C.POINTER(WgradArgs), c_int, c_void_p, c_void_p, c_void_p],
     "fb_mt_accumulate_sum": [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p],
+    "fb_mt_accumulate_skip": [c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_void_p, c_void_p] + [c_i64] * 8 + [c_void_p],
 }
 EXPORTS = tuple(_SIGS) + ("fb_last_error_string", "fb_abi_version", "fb_profile_enable", "fb_profile_read", "fb_ws_conv_stat_floats",
                           "fb_ws_wgrad_slab_floats", "fb_ws_bn_partial_floats", "fb_ws_mt_floats", "fb_bn_bwd_reduce_rows", "fb_conv_masked_addend_supported", "fb_conv_bwd_stat_supported",

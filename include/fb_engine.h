@@ -294,6 +294,11 @@ int fb_mt_accumulate(float* avg, const float* g, int64_t group_stride, int32_t n
 /* the running mean advanced by n_groups chunks at once from their SUM (fb_conv2d_wgrad_chain + fb_wgrad_reduce):
  * avg += (gsum - n_groups*avg) / (counter0 + n_groups) -- what n_groups steps of fb_mt_accumulate's recurrence amount to (ABI v12) */
 int fb_mt_accumulate_sum(float* avg, const float* gsum, int64_t n, int32_t counter0, int32_t n_groups, void* stream);
+/* fb_mt_accumulate over [0, n) except up to four ranges [lo_k, hi_k) (multiples of 4 floats; lo == hi: unused), which are neither read nor
+ * written and do not enter sq_out: the layers whose mean comes from fb_mt_accumulate_sum (ABI v12) */
+int fb_mt_accumulate_skip(float* avg, const float* g, int64_t group_stride, int32_t n_groups, int64_t n, int32_t counter0, float* sq_out,
+                          float* ws, int64_t lo0, int64_t hi0, int64_t lo1, int64_t hi1, int64_t lo2, int64_t hi2, int64_t lo3, int64_t hi3,
+                          void* stream);
 /* eps_n[g] = eps / sqrt(vnorm2[g]);  theta_out[g] = theta0 + (sign*eps_n[g]) * (s*g[g] + acc*pre)   (modules.py:217-226;
  * pre = the pre-computed full gradient of the acc_strength pre-pass, training.py:128-142, NULL without it) */
 int fb_mt_fd_perturb(const float* theta0, const float* g, int64_t group_stride, int32_t n_groups, int64_t n, float s,

@@ -577,3 +577,29 @@ def test_chunk_must_fill_whole_statistics_blocks():
     from fullbatchtraining_amd.lib import EngineError
     with pytest.raises(EngineError, match="multiple of 128"):
         _build(18, 96, 32, 1, torch.float32, stem="standard")       # 3x3 maps: 32 * 9 pixels per chunk
+
+
+def test_chunk_chained_weight_gradients_opt_in(monkeypatch):
+    """FB_WGRAD_CHAIN=1 (ABI v12: fb_conv2d_wgrad_chain + fb_mt_accumulate_sum / _skip): the 3x3 layers on 4x4 maps leave the SUM of a group's chunk
+    gradients and every chunk's sum of squares instead of one gradient per chunk in the arena.  The running mean, the per-chunk gradient norms
+    and the losses of full_gradient must agree with the per-chunk path to rounding (the sums are taken in another order), over two groups (the
+    second one shorter) and a non-zero chunk counter."""
+    pixels, chunk, G, n_chunks = 32, 32, 8, 13         # (8 chunks per group: one K slice per chunk on the 4x4 maps, as at the benchmark's 98)
+    x, y = make_data(chunk * n_chunks, pixels)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FB_WGRAD_CHAIN", mode)
+        cfg, model, eng, stem_patches = _build(18, pixels, chunk, G, torch.bfloat16)
+        assert bool(eng.chain_layers) == (mode == "1")
+        patches = stem_patches(x.cuda(), eng.plan.stem, torch.bfloat16)
+        loss, correct, sq = eng.full_gradient(patches, y.cuda(), 0.1)
+        torch.cuda.synchronize()
+        out[mode] = (eng.avg.double().cpu().clone(), sq.double().cpu().clone(), loss.double().cpu().clone())
+    (a0, s0, l0), (a1, s1, l1) = out["0"], out["1"]
+    assert torch.equal(l0, l1)
+    assert float((a0 - a1).norm() / a0.norm()) < 2e-6
+    assert float(((s0 - s1).abs() / s0).max()) < 1e-5
+    # the chained layers carry most of the parameters: their slice of the mean alone
+    L = eng.chain_layers[0]
+    sl = slice(L.w_off, L.w_off + L.cout * L.taps * L.cin_real)
+    assert float((a0[sl] - a1[sl]).norm() / a0[sl].norm()) < 2e-6

@@ -244,6 +244,35 @@ def test_conv_wgrad(dtype, cin, cout, k, stride, hw, ipg, groups, split, monkeyp
         assert bool(torch.isnan(arena[:, :8]).all()) and bool(torch.isnan(arena[:, 8 + cout * k * k * cin:]).all())
 
 
+def test_mt_accumulate_skip_and_sum():
+    """fb_mt_accumulate_skip = fb_mt_accumulate with up to four ranges left alone (mean untouched there, norms without them);
+    fb_mt_accumulate_sum = the same recurrence advanced by a group's chunks at once from their sum."""
+    lib = _lib()
+    torch.manual_seed(3)
+    P, G, c0 = 4096 + 64, 5, 3
+    g = torch.randn(G, P, device="cuda")
+    avg0 = torch.randn(P, device="cuda")
+    ws = torch.zeros(int(lib.load().fb_ws_mt_floats(G)), device="cuda")
+    ref, sq_ref = avg0.clone(), torch.zeros(G, device="cuda")
+    lib.call("fb_mt_accumulate", ref.data_ptr(), g.data_ptr(), P, G, P, c0, sq_ref.data_ptr(), ws.data_ptr())
+    skips = [(128, 640), (1024, 1028), (4000, 4160)]
+    got, sq = avg0.clone(), torch.zeros(G, device="cuda")
+    flat = [v for r in skips for v in r] + [0, 0]
+    lib.call("fb_mt_accumulate_skip", got.data_ptr(), g.data_ptr(), P, G, P, c0, sq.data_ptr(), ws.data_ptr(), *flat)
+    keep = torch.ones(P, dtype=torch.bool, device="cuda")
+    for a, b in skips:
+        keep[a:b] = False
+    assert torch.equal(got[keep], ref[keep]) and torch.equal(got[~keep], avg0[~keep])
+    want = (g.double() ** 2 * keep).sum(1)
+    assert float(((sq.double() - want).abs() / want).max()) < 1e-6
+    # the skipped ranges from the group sum: what G steps of the recurrence amount to
+    for a, b in skips:
+        gs = g[:, a:b].sum(0).contiguous()
+        part = avg0[a:b].clone()
+        lib.call("fb_mt_accumulate_sum", part.data_ptr(), gs.data_ptr(), b - a, c0, G)
+        assert float((part.double() - ref[a:b].double()).abs().max()) < 2e-6 * float(ref[a:b].abs().max() + 1)
+
+
 @pytest.mark.parametrize("cin,cout,ipg,chunks,chains", [(64, 64, 8, 5, 2), (128, 64, 16, 7, 3), (64, 128, 4, 6, 6), (512, 512, 128, 9, 4), (256, 128, 12, 3, 1)])
 def test_conv_wgrad_chunk_chain(cin, cout, ipg, chunks, chains):
     """fb_conv2d_wgrad_chain (ABI v12): the sum over the chunks of the per-chunk weight gradients and every chunk's sum of squares, against the
