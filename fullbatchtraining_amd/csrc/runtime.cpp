@@ -25,14 +25,20 @@ extern "C" int64_t fb_ws_mt_floats(int32_t n_groups) { return (int64_t)(n_groups
 // persistent convolution on EVERY CU a kernel of another stream (the gradient exchange's RCCL kernels under the last backward pass) only gets
 // a slot when a whole launch ends; a reserve leaves that many CUs' worth of slots open (measured: bench.py `exchange`).
 int fb_persistent_cus() {
-    static int n = 0;
+    // per DEVICE (a process may drive several: the first caller's device must not size the grids of all of them); hipGetDevice is a
+    // thread-local read, so the lookup stays out of the launch path's cost
+    static int per_dev[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int n = per_dev[dev];
     if (n == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         const char* r = getenv("FB_CU_RESERVE");
         const int reserve = r ? atoi(r) : 0;
         n = cus - (reserve > 0 ? reserve : 0);
         if (n < 8) n = 8;
+        per_dev[dev] = n;
     }
     return n;
 }

@@ -13,6 +13,7 @@ with conv weights in KRSC order ``[Cout][R*S][Cin]``; NHWC activations in the co
 """
 import math
 import os
+import warnings
 
 import torch
 
@@ -324,7 +325,7 @@ class Engine:
         # static sequence -- recorded the first time, replayed with one host call afterwards (FB_REPLAY=0: every launch through ctypes)
         self.use_replay = os.environ.get("FB_REPLAY", "1") != "0"
         self.cmdlists, self.replays, self.MAX_CMDLISTS = {}, 0, int(os.environ.get("FB_MAX_CMDLISTS", "256"))
-        self.cmd_evictions, self.record_new = 0, True
+        self.cmd_evictions, self.record_new, self.unrecorded_runs, self._warned_record_off, self._off_misses = 0, True, 0, False, 0
         self.masks = {}
         self.fuse_bwd_stat = os.environ.get("FB_FUSED_BWD_STAT", "0") != "0"     # BN-backward reduction in the input-gradient epilogues: built, parity-tested,
         # measured SLOWER at step level (profiles/r2_notes.md: the separate HBM-bound reduction overlaps the weight-gradient stream) -> off
@@ -407,7 +408,9 @@ class Engine:
                 cuts.append((lo, self.plan.P))
             assert all(a % 4 == 0 for a, _ in cuts), cuts
             self.plain_segments = cuts
-            self.sq_seg = torch.zeros(len(cuts), self.G, **f32)
+            # scratch rows for the per-chunk norms of the non-chained ranges: one per caller of _fold that may be in flight at the same time
+            # (row 0: the main / weight-gradient stream, row 1: the side stream of the multi-GPU late bucket)
+            self.sq_seg = torch.zeros(2, self.G, **f32)
         self.stem_out = torch.empty(n, self.plan.stem.hout, self.plan.stem.wout, 64, device=dev, dtype=dt)
         if self.plan.stem_pool:
             hp = (self.plan.stem.hout + 1) // 2
@@ -987,9 +990,20 @@ class Engine:
             self.cmdlists[key] = cl                      # most recently used last
             cl.replay(streams)
             self.replays += 1
+            # hits pay the eviction count back: a transient phase of keys that never repeat (evaluation over varying shapes, another engine's
+            # buffers) must not switch recording off for the steady-state groups that follow it
+            if self.cmd_evictions:
+                self.cmd_evictions -= 1
+                if not self.record_new and self.cmd_evictions <= self.MAX_CMDLISTS // 2:
+                    self.record_new = True
             return
         if not self.record_new:
-            return body()
+            # ... and a cache full of lists nobody replays any more never hits: after a cache worth of interpreted runs recording is tried again
+            self.unrecorded_runs += 1
+            self._off_misses += 1
+            if self._off_misses < self.MAX_CMDLISTS:
+                return body()
+            self.record_new, self._off_misses, self.cmd_evictions = True, 0, self.MAX_CMDLISTS // 2
         if len(self.cmdlists) >= self.MAX_CMDLISTS:
             # Keys that never repeat (buffers re-allocated every step) or a working set beyond the cache: the least recently used list goes, its
             # event ids are handed to the next recordings -- and once a whole cache worth of lists has been dropped recording stops paying
@@ -999,6 +1013,10 @@ class Engine:
             self.cmd_evictions += 1
             if self.cmd_evictions >= self.MAX_CMDLISTS:
                 self.record_new = False
+                if not self._warned_record_off:
+                    self._warned_record_off = True
+                    warnings.warn(f"fullbatchtraining_amd.Engine: {self.cmd_evictions} command lists evicted without a replay in between -- new launch "
+                                  "sequences run through the interpreter until recorded ones are replayed again (FB_MAX_CMDLISTS raises the cache size)")
         with lib.Recorder(streams) as rec:
             body()
         self.cmdlists[key] = rec.finish()
@@ -1016,10 +1034,12 @@ class Engine:
         self._replayable(("group", patches.data_ptr(), labels.data_ptr(), G, gout.data_ptr(), wsets, theta.data_ptr(), pidx, self.chunk, self.valid,
                           float(self.label_smoothing), bool(self.only_incorrect), self.fuse_bwd_stat, self.chain_on), body)
 
-    def _fold(self, gbuf, g_n, lo, hi, counter, sq_out, ws):
+    def _fold(self, gbuf, g_n, lo, hi, counter, sq_out, ws, seg_row=0):
         """The running mean over [lo, hi) of the arena advanced by the ``g_n`` chunks in ``gbuf`` (+ their squared norms over that range into
         ``sq_out[:g_n]``): fb_mt_accumulate; with chained weight gradients the chained layers from their group sum (fb_mt_accumulate_sum), the
-        rest per chunk with those ranges left alone (fb_mt_accumulate_skip), the norms as the sum of the two kinds of parts."""
+        rest per chunk with those ranges left alone (fb_mt_accumulate_skip), the norms as the sum of the two kinds of parts.  ``seg_row``: the
+        caller's own row of ``self.sq_seg`` (two folds of one step run on different streams with no order between them: the late bucket's on the
+        side stream, the early range's on the main stream -- each needs scratch of its own)."""
         P = self.plan.P
         if not self.chain_on:
             call("fb_mt_accumulate", self.avg.data_ptr() + 4 * lo, gbuf.data_ptr() + 4 * lo, P, g_n, hi - lo, counter, _ptr(sq_out), ws.data_ptr())
@@ -1037,8 +1057,8 @@ class Engine:
             raise lib.EngineError("more than four chained layers in one range")
         skips += [0] * (8 - len(skips))
         call("fb_mt_accumulate_skip", self.avg.data_ptr() + 4 * lo, gbuf.data_ptr() + 4 * lo, P, g_n, hi - lo, counter,
-             self.sq_seg[0].data_ptr() if sq_out is not None else None, ws.data_ptr(), *skips)
-        parts.append(self.sq_seg[0, :g_n])
+             self.sq_seg[seg_row].data_ptr() if sq_out is not None else None, ws.data_ptr(), *skips)
+        parts.append(self.sq_seg[seg_row, :g_n])
         if sq_out is not None:
             sq_out[:g_n].copy_(torch.stack(parts).sum(0))
 
@@ -1128,98 +1148,100 @@ class Engine:
         if late_bucket is not None and getattr(self, "side", None) is None:
             self.side = torch.cuda.Stream(device=self.device)
             self.sq_late, self.ws_late = torch.zeros_like(self.sq), torch.zeros_like(self.mt_ws)
-        while done < n_chunks:
-            g_n = min(G, n_chunks - done)
-            lo = (k_first + done) * chunk
-            xb, yb = patches[lo:lo + g_n * chunk], labels[lo:lo + g_n * chunk]
-            gbuf = self.g_alt if (overlap and group_idx & 1) else self.g
-            group_idx += 1
-            # early completion of the late bucket: only for the last group, and only where the running mean is folded in one piece
-            early = late_bucket is not None and done + g_n == n_chunks and not overlap and batch_clip is None
-            lb = late_bucket[0] if early else 0
-            central = fd and implementation == "central-differences"
-            legacy = fd and implementation == "forward-differences-legacy"
-            cf = (lr / 4 * (block_strength if legacy else 1.0)) if fd else 0.0
+        try:
+            while done < n_chunks:
+                g_n = min(G, n_chunks - done)
+                lo = (k_first + done) * chunk
+                xb, yb = patches[lo:lo + g_n * chunk], labels[lo:lo + g_n * chunk]
+                gbuf = self.g_alt if (overlap and group_idx & 1) else self.g
+                group_idx += 1
+                # early completion of the late bucket: only for the last group, and only where the running mean is folded in one piece
+                early = late_bucket is not None and done + g_n == n_chunks and not overlap and batch_clip is None
+                lb = late_bucket[0] if early else 0
+                central = fd and implementation == "central-differences"
+                legacy = fd and implementation == "forward-differences-legacy"
+                cf = (lr / 4 * (block_strength if legacy else 1.0)) if fd else 0.0
 
-            def finish_late(bi, _g_n=g_n, _done=done):
-                """Called by the last backward pass of the group: gradients of the arena slice [lb, P) are complete."""
-                if bi != self.plan.late_block:
-                    return
-                ready = [torch.cuda.current_stream().record_event()]
-                if self.wstream is not None:
-                    ready.append(self.wstream.record_event())
-                with torch.cuda.stream(self.side):
-                    for ev in ready:
-                        self.side.wait_event(ev)
-                    n_late = P - lb
-                    if not fd:
-                        self._fold(self.g, _g_n, lb, P, counter0 + _done, self.sq_late, self.ws_late)
-                    else:
-                        gb = self.g_fd[1] if central else self.g
-                        call("fb_mt_fd_combine_accumulate", self.avg.data_ptr() + 4 * lb, self.g.data_ptr() + 4 * lb, self.g_fd[0].data_ptr() + 4 * lb,
-                             gb.data_ptr() + 4 * lb, P, _g_n, n_late, self.eps_n.data_ptr(), cf, counter0 + _done)
-                    late_bucket[1]()
+                def finish_late(bi, _g_n=g_n, _done=done):
+                    """Called by the last backward pass of the group: gradients of the arena slice [lb, P) are complete."""
+                    if bi != self.plan.late_block:
+                        return
+                    ready = [torch.cuda.current_stream().record_event()]
+                    if self.wstream is not None:
+                        ready.append(self.wstream.record_event())
+                    with torch.cuda.stream(self.side):
+                        for ev in ready:
+                            self.side.wait_event(ev)
+                        n_late = P - lb
+                        if not fd:
+                            self._fold(self.g, _g_n, lb, P, counter0 + _done, self.sq_late, self.ws_late, seg_row=1)
+                        else:
+                            gb = self.g_fd[1] if central else self.g
+                            call("fb_mt_fd_combine_accumulate", self.avg.data_ptr() + 4 * lb, self.g.data_ptr() + 4 * lb, self.g_fd[0].data_ptr() + 4 * lb,
+                                 gb.data_ptr() + 4 * lb, P, _g_n, n_late, self.eps_n.data_ptr(), cf, counter0 + _done)
+                        late_bucket[1]()
 
-            hook = finish_late if early else None
-            self.group_gradient(xb, yb, g_n, gbuf, 1, self.theta, 0, on_block_done=hook if not fd else None)
-            loss_all[done:done + g_n].copy_(self.loss[:g_n])
-            correct_all[done:done + g_n].copy_(self.correct[:g_n])
-            n_passes = 1
-            if overlap:
-                ready = torch.cuda.current_stream().record_event()
-                with torch.cuda.stream(self.wstream):
-                    self.wstream.wait_event(ready)
-                    self._fold(gbuf, g_n, 0, P, counter0 + done, sq_all[done:done + g_n], self.acc_ws)
-            elif not fd and batch_clip is not None:
-                call("fb_mt_sqnorm", self.g.data_ptr(), P, g_n, P, 1.0, None, 0.0, self.sq.data_ptr(), self.mt_ws.data_ptr())
-                call("fb_mt_chunk_clip", self.g.data_ptr(), P, g_n, P, self.sq.data_ptr(), float(batch_clip), self.clipped.data_ptr())
-                call("fb_mt_accumulate", self.avg.data_ptr(), self.g.data_ptr(), P, g_n, P, counter0 + done, None, self.mt_ws.data_ptr())
-            elif not fd:
-                # (with an early late bucket the slice [lb, P) has been folded on the side stream; |g_k|^2 is the sum of the two parts)
-                self._fold(self.g, g_n, 0, lb if early else P, counter0 + done, self.sq, self.mt_ws)
-                if early:
-                    torch.cuda.current_stream().wait_stream(self.side)
-                    self.sq[:g_n].add_(self.sq_late[:g_n])
-            else:
-                s = 1.0 if legacy else float(block_strength)
-                # finite-difference direction v = s*g_k + acc*pre (modules.py:217-221; the legacy variant ignores pre, :243-245)
-                vpre, vacc = (None, 0.0) if (legacy or pre is None) else (pre.data_ptr(), float(acc_strength))
-                call("fb_mt_sqnorm", self.g.data_ptr(), P, g_n, P, 1.0, None, 0.0, self.sq.data_ptr(), self.mt_ws.data_ptr())
-                call("fb_mt_sqnorm", self.g.data_ptr(), P, g_n, P, s, vpre, vacc, self.vnorm2.data_ptr(), self.mt_ws.data_ptr())
-                call("fb_mt_fd_perturb", self.theta.data_ptr(), self.g.data_ptr(), P, g_n, P, s, float(eps), 0.5 if central else 1.0,
-                     self.vnorm2.data_ptr(), self.eps_n.data_ptr(), vpre, vacc, self.theta_k.data_ptr())
-                self.prep_weights(self.theta_k, g_n, per_chunk=True)
-                self.group_gradient(xb, yb, g_n, self.g_fd[0], 2, self.theta_k, 1, on_block_done=None if central else hook)
-                n_passes = 2
-                if central:
-                    call("fb_mt_fd_perturb", self.theta.data_ptr(), self.g.data_ptr(), P, g_n, P, s, float(eps), -0.5,
-                         self.vnorm2.data_ptr(), self.eps_n.data_ptr(), vpre, vacc, self.theta_k.data_ptr())
-                    self.prep_weights(self.theta_k, g_n, per_chunk=True)
-                    self.group_gradient(xb, yb, g_n, self.g_fd[1], 2, self.theta_k, 2, on_block_done=hook)
-                    n_passes = 3
-                gb = self.g_fd[1] if central else self.g                 # vhp = (g(theta+) - g(theta-)) / eps_n  or  (g(theta+) - g) / eps_n
-                if batch_clip is None:
-                    call("fb_mt_fd_combine_accumulate", self.avg.data_ptr(), self.g.data_ptr(), self.g_fd[0].data_ptr(), gb.data_ptr(), P, g_n,
-                         lb if early else P, self.eps_n.data_ptr(), cf, counter0 + done)
+                hook = finish_late if early else None
+                self.group_gradient(xb, yb, g_n, gbuf, 1, self.theta, 0, on_block_done=hook if not fd else None)
+                loss_all[done:done + g_n].copy_(self.loss[:g_n])
+                correct_all[done:done + g_n].copy_(self.correct[:g_n])
+                n_passes = 1
+                if overlap:
+                    ready = torch.cuda.current_stream().record_event()
+                    with torch.cuda.stream(self.wstream):
+                        self.wstream.wait_event(ready)
+                        self._fold(gbuf, g_n, 0, P, counter0 + done, sq_all[done:done + g_n], self.acc_ws)
+                elif not fd and batch_clip is not None:
+                    call("fb_mt_sqnorm", self.g.data_ptr(), P, g_n, P, 1.0, None, 0.0, self.sq.data_ptr(), self.mt_ws.data_ptr())
+                    call("fb_mt_chunk_clip", self.g.data_ptr(), P, g_n, P, self.sq.data_ptr(), float(batch_clip), self.clipped.data_ptr())
+                    call("fb_mt_accumulate", self.avg.data_ptr(), self.g.data_ptr(), P, g_n, P, counter0 + done, None, self.mt_ws.data_ptr())
+                elif not fd:
+                    # (with an early late bucket the slice [lb, P) has been folded on the side stream; |g_k|^2 is the sum of the two parts)
+                    self._fold(self.g, g_n, 0, lb if early else P, counter0 + done, self.sq, self.mt_ws)
                     if early:
                         torch.cuda.current_stream().wait_stream(self.side)
-                else:      # the regularised chunk gradients are materialised, clipped one by one, then averaged
-                    call("fb_mt_fd_combine", self.g.data_ptr(), self.g_fd[0].data_ptr(), gb.data_ptr(), P, g_n, P, self.eps_n.data_ptr(), cf)
-                    call("fb_mt_sqnorm", self.g.data_ptr(), P, g_n, P, 1.0, None, 0.0, self.vnorm2.data_ptr(), self.mt_ws.data_ptr())
-                    call("fb_mt_chunk_clip", self.g.data_ptr(), P, g_n, P, self.vnorm2.data_ptr(), float(batch_clip), self.clipped.data_ptr())
-                    call("fb_mt_accumulate", self.avg.data_ptr(), self.g.data_ptr(), P, g_n, P, counter0 + done, None, self.mt_ws.data_ptr())
-            if not overlap:
-                sq_all[done:done + g_n].copy_(self.sq[:g_n])
-            if batch_clip is not None:
-                self.clipped_all[done:done + g_n].copy_(self.clipped[:g_n])
-            call("fb_bn_running_update", self.running_mean.data_ptr(), self.running_var.data_ptr(), self.mean_tab.data_ptr(),
-                 self.var_tab.data_ptr(), n_passes, self.G * self.plan.ch_total, self.unbias.data_ptr(), g_n, self.plan.ch_total,
-                 BN_MOMENTUM)
-            self.num_batches_tracked += g_n * n_passes
-            done += g_n
-        if overlap:
-            torch.cuda.current_stream().wait_stream(self.wstream)
-        self.chain_on = False
+                        self.sq[:g_n].add_(self.sq_late[:g_n])
+                else:
+                    s = 1.0 if legacy else float(block_strength)
+                    # finite-difference direction v = s*g_k + acc*pre (modules.py:217-221; the legacy variant ignores pre, :243-245)
+                    vpre, vacc = (None, 0.0) if (legacy or pre is None) else (pre.data_ptr(), float(acc_strength))
+                    call("fb_mt_sqnorm", self.g.data_ptr(), P, g_n, P, 1.0, None, 0.0, self.sq.data_ptr(), self.mt_ws.data_ptr())
+                    call("fb_mt_sqnorm", self.g.data_ptr(), P, g_n, P, s, vpre, vacc, self.vnorm2.data_ptr(), self.mt_ws.data_ptr())
+                    call("fb_mt_fd_perturb", self.theta.data_ptr(), self.g.data_ptr(), P, g_n, P, s, float(eps), 0.5 if central else 1.0,
+                         self.vnorm2.data_ptr(), self.eps_n.data_ptr(), vpre, vacc, self.theta_k.data_ptr())
+                    self.prep_weights(self.theta_k, g_n, per_chunk=True)
+                    self.group_gradient(xb, yb, g_n, self.g_fd[0], 2, self.theta_k, 1, on_block_done=None if central else hook)
+                    n_passes = 2
+                    if central:
+                        call("fb_mt_fd_perturb", self.theta.data_ptr(), self.g.data_ptr(), P, g_n, P, s, float(eps), -0.5,
+                             self.vnorm2.data_ptr(), self.eps_n.data_ptr(), vpre, vacc, self.theta_k.data_ptr())
+                        self.prep_weights(self.theta_k, g_n, per_chunk=True)
+                        self.group_gradient(xb, yb, g_n, self.g_fd[1], 2, self.theta_k, 2, on_block_done=hook)
+                        n_passes = 3
+                    gb = self.g_fd[1] if central else self.g                 # vhp = (g(theta+) - g(theta-)) / eps_n  or  (g(theta+) - g) / eps_n
+                    if batch_clip is None:
+                        call("fb_mt_fd_combine_accumulate", self.avg.data_ptr(), self.g.data_ptr(), self.g_fd[0].data_ptr(), gb.data_ptr(), P, g_n,
+                             lb if early else P, self.eps_n.data_ptr(), cf, counter0 + done)
+                        if early:
+                            torch.cuda.current_stream().wait_stream(self.side)
+                    else:      # the regularised chunk gradients are materialised, clipped one by one, then averaged
+                        call("fb_mt_fd_combine", self.g.data_ptr(), self.g_fd[0].data_ptr(), gb.data_ptr(), P, g_n, P, self.eps_n.data_ptr(), cf)
+                        call("fb_mt_sqnorm", self.g.data_ptr(), P, g_n, P, 1.0, None, 0.0, self.vnorm2.data_ptr(), self.mt_ws.data_ptr())
+                        call("fb_mt_chunk_clip", self.g.data_ptr(), P, g_n, P, self.vnorm2.data_ptr(), float(batch_clip), self.clipped.data_ptr())
+                        call("fb_mt_accumulate", self.avg.data_ptr(), self.g.data_ptr(), P, g_n, P, counter0 + done, None, self.mt_ws.data_ptr())
+                if not overlap:
+                    sq_all[done:done + g_n].copy_(self.sq[:g_n])
+                if batch_clip is not None:
+                    self.clipped_all[done:done + g_n].copy_(self.clipped[:g_n])
+                call("fb_bn_running_update", self.running_mean.data_ptr(), self.running_var.data_ptr(), self.mean_tab.data_ptr(),
+                     self.var_tab.data_ptr(), n_passes, self.G * self.plan.ch_total, self.unbias.data_ptr(), g_n, self.plan.ch_total,
+                     BN_MOMENTUM)
+                self.num_batches_tracked += g_n * n_passes
+                done += g_n
+            if overlap:
+                torch.cuda.current_stream().wait_stream(self.wstream)
+        finally:                                     # (an exception inside a group must not leave later group_gradient / evaluate calls chained)
+            self.chain_on = False
         return loss_all, correct_all, sq_all
 
     def check_device_errors(self):

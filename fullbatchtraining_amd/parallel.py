@@ -53,6 +53,8 @@ def _reduce_scatter_sum(out_shard, full, group=None):
         dist.all_reduce(full, group=group)
         n = out_shard.numel()
         out_shard.copy_(full[dist.get_rank(group) * n:(dist.get_rank(group) + 1) * n])
+        if os.environ.get("FB_EXCHANGE_POISON", "1") != "0":
+            full.fill_(float("nan"))            # RCCL leaves ``full`` un-reduced: nothing may read it again (see BucketExchange.start)
     else:
         dist.reduce_scatter_tensor(out_shard, full, op=dist.ReduceOp.SUM, group=group)
 
@@ -128,10 +130,13 @@ class BucketExchange:
             t1 = torch.cuda.Event(enable_timing=True)
             t1.record()
             self.stamps[i] = [t0, t1, None]
-        if os.environ.get("FB_EXCHANGE_POISON") == "1":
-            # test switch: once the bucket has left, nothing may read this rank's LOCAL values of it again (finish() consumes ``shard``; the
-            # ranges of ``avg`` a rank does not own are undefined until gather_sharded_state()).  Overwrite them with NaN behind the
-            # collective, on the stream it was started from: any later consumer of the stale slice poisons the step.
+        poison = os.environ.get("FB_EXCHANGE_POISON")
+        if poison == "1" or (poison is None and work is None):
+            # Once the bucket has left, nothing may read this rank's LOCAL values of it again (finish() consumes ``shard``; the ranges of ``avg``
+            # a rank does not own are undefined until gather_sharded_state()).  Overwrite them with NaN behind the collective, on the stream it
+            # was started from: any later consumer of the stale slice poisons the step.  FB_EXCHANGE_POISON=1: a test switch on RCCL; on the
+            # gloo stand-in (tests and shared-device development runs only) it is the DEFAULT -- gloo's all-reduce leaves the reduced values in
+            # every range, which would let a read of a range the rank does not own pass every gloo test and fail only on real RCCL.
             if work is not None:
                 work.wait()
             part.fill_(float("nan"))

@@ -116,6 +116,10 @@ def optim_interface(model, cfg_hyp):
         raise ValueError(f"Invalid scheduler {sched} provided.")
     if cfg_hyp.warmup > 0:
         scheduler = GradualWarmupScheduler(optimizer, multiplier=1.0, total_epoch=cfg_hyp.warmup, after_scheduler=scheduler)
+    # The torch optimizer is a STATE CONTAINER here (param_groups / momentum buffers in the checkpoint layout): the update itself is the engine's
+    # fb_mt_clip_sgd on the arena, so ``optimizer.step()`` is never called -- tell the schedulers that updates do happen, or the first
+    # ``scheduler.step()`` warns "lr_scheduler.step() before optimizer.step()" on every run
+    optimizer._opt_called = True
     return wrapped, scheduler            # the scheduler drives the wrapped SGD (reference optimizers.py:67 `optimizer.optim`)
 
 
@@ -405,12 +409,7 @@ class FullBatchTrainer:
         self.cfg, self.model = cfg, model
         self.device = torch.device(setup["device"]) if not isinstance(setup["device"], torch.device) else setup["device"]
         self.optimizer, self.scheduler = optim_interface(model, cfg.hyp)
-        # the engine applies the update on its arena (fb_mt_clip_sgd); the torch optimizer is the state container the checkpoint layout wants.
-        # Tell the scheduler that updates do happen, or it warns "lr_scheduler.step() before optimizer.step()" on its first step
-        opt = self.optimizer
-        while opt is not None:
-            opt._opt_called = True
-            opt = getattr(opt, "optim", None) or getattr(opt, "base_optimizer", None)
+        # (the engine applies the update on its arena, fb_mt_clip_sgd; the torch optimizer is the state container the checkpoint layout wants)
         self.loss_fn = get_loss_fn(cfg.hyp, cfg.data.batch_size)
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
         self.rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0

@@ -33,6 +33,35 @@ def hyp_from_cfg(cfg):
                 batch_clip=cfg.hyp.batch_clip)
 
 
+def torch_bf16_chunk_grads(model, x, y, chunk, device="cpu"):
+    """The INDEPENDENT bf16 yardstick: torch's own ``autocast(bfloat16)`` evaluation of the same model on the same chunks -- the reference's
+    ``_compute_batched_gradient`` under ``impl.mixed_precision`` (fullbatch/training/training.py:76-83: forward + CrossEntropyLoss inside
+    autocast, ``torch.autograd.grad`` outside).  Plain torch: it touches neither ``libfbengine`` nor ``oracle/``.  Returns
+    [(gradient list in ``model.parameters()`` order (fp32, host), loss)] per chunk."""
+    import copy
+
+    dev = torch.device(device)
+    m = copy.deepcopy(model).to(dev).float().train()
+    params = list(m.parameters())
+    out = []
+    for k in range(x.shape[0] // chunk):
+        xb, yb = x[k * chunk:(k + 1) * chunk].to(dev), y[k * chunk:(k + 1) * chunk].to(dev)
+        with torch.autocast(device_type=dev.type, dtype=torch.bfloat16):
+            loss = torch.nn.functional.cross_entropy(m(xb), yb)
+        grads = torch.autograd.grad(loss, params)
+        out.append(([g.detach().float().cpu() for g in grads], float(loss.detach())))
+    return out
+
+
+def flat64(tensors):
+    return torch.cat([t.detach().reshape(-1).double().cpu() for t in tensors])
+
+
+def err_cos(a, truth):
+    """(relative L2 distance, cosine) of flat float64 vectors."""
+    return float((a - truth).norm() / truth.norm()), float((a * truth).sum() / (a.norm() * truth.norm()))
+
+
 def rel_err(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))

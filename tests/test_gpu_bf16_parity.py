@@ -113,3 +113,31 @@ def test_bf16_training_trajectory_tracks_f32(tmp_path):
     assert rel_l.max() < 0.10 and rel_l[:10].max() < 0.02, rel_l
     assert rel_g.max() < 0.15, rel_g
     assert abs(runs[True]["valid_acc"][-1] - runs[False]["valid_acc"][-1]) < 0.03
+
+
+def test_bench_mean_gradient_bf16_within_its_stated_bound(tmp_path):
+    """The figure bench.py prints as ``parity.bf16_vs_f32`` through bench.py's OWN functions (``_side_trainer`` / ``_mean_gradient`` / ``_rel``) at the
+    benchmark's real shape, on 64 chunks of 128 images: the bf16 trainer's mean gradient against the fp32 (bf16x6: exact products) trainer's at the
+    same parameters must sit inside the bound the line states, 0.5 / sqrt(K) -- asserted here, and enforced by bench.py itself on all 390 chunks."""
+    import argparse
+
+    import bench
+
+    K = 64
+    gen = torch.Generator().manual_seed(1234)
+    X = torch.randn(K * 128, 3, 32, 32, generator=gen)
+    Y = torch.randint(0, 10, (K * 128,), generator=gen)
+    args = argparse.Namespace(chunk_group=16)
+    dev = torch.device("cuda:0")
+    tr16 = bench._side_trainer(args, dev, X, Y, ["hyp=fb1", "hyp.warmup=0", "hyp.steps=4", "impl.mixed_precision=True"], "parity16")
+    tr32 = bench._side_trainer(args, dev, X, Y, ["hyp=fb1", "hyp.warmup=0", "hyp.steps=4", "impl.mixed_precision=False"], "parity32",
+                               env={"FB_F32_SPLIT": "bf16x6"})
+    assert tr16.dtype == torch.bfloat16 and tr32.dtype == torch.float32 and tr32.engine.f32_split == "bf16x6"
+    tr16.step()                                          # away from the initialisation, like the benchmark's figure (taken after its timed steps)
+    e16, e32 = tr16.engine, tr32.engine
+    e32.theta.copy_(e16.theta), e32.running_mean.copy_(e16.running_mean), e32.running_var.copy_(e16.running_var)
+    g16, g32 = bench._mean_gradient(tr16, K), bench._mean_gradient(tr32, K)
+    rel = bench._rel(g16, g32, K)
+    print(f"bench parity on {K} chunks: {rel}")
+    assert rel["bound"] == round(0.5 / K ** 0.5, 5) and rel["within_bound"] and rel["rel_l2"] <= 0.5 / K ** 0.5, rel
+    assert rel["cosine"] > 0.997, rel

@@ -84,6 +84,20 @@ def test_resnet18_chunk_gradients_vs_oracle(dtype, gtol, ltol):
         assert cos > (0.99999 if dtype == torch.float32 else 0.9), cos
         # the classifier gradient is well conditioned: tight in fp32, bf16 activation rounding (2^-9) in bf16
         assert rel_err(got[g][-2].numpy(), truth[g][0][-2].numpy()) < (1e-4 if dtype == torch.float32 else 5e-2)
+    if dtype == torch.bfloat16:
+        # the independent yardstick: torch's own bf16 autocast of the same model on the same chunks (plain torch -- neither libfbengine nor
+        # oracle/; the reference's impl.mixed_precision path, training.py:76-83).  The engine may be no noisier than that: distance to the
+        # float64 truth <= 1.15 x torch-bf16's, cosine no more than 0.01 below it, chunk by chunk.
+        from tests.helpers import err_cos, flat64, torch_bf16_chunk_grads
+        yard = torch_bf16_chunk_grads(model, x, y, chunk)
+        for g in range(G):
+            t = flat64(truth[g][0])
+            e_eng, c_eng = err_cos(flat64(got[g]), t)
+            e_tch, c_tch = err_cos(flat64(yard[g][0]), t)
+            print(f"[bf16 yardstick] chunk {g}: engine {e_eng:.3f} / cos {c_eng:.4f}; torch autocast(bf16) {e_tch:.3f} / cos {c_tch:.4f}")
+            assert e_eng <= 1.15 * e_tch, (g, e_eng, e_tch)
+            assert c_eng >= c_tch - 0.01, (g, c_eng, c_tch)
+            assert abs(float(eng.loss[g]) - yard[g][1]) < 2e-2 * max(1.0, abs(yard[g][1]))
     # batch statistics of the first and last BN layers (chunk 0) against torch
     L = eng.plan.stem
     mean0 = eng.mean_tab[0, 0, L.ch_off:L.ch_off + 64].cpu()
@@ -368,6 +382,7 @@ def test_replayed_command_lists_equal_interpreted_launches(dtype, fd, monkeypatc
     assert a[5] == b[5]
 
 
+@pytest.mark.filterwarnings("ignore:fullbatchtraining_amd.Engine")
 def test_command_list_cache_is_bounded_and_stops_recording_when_it_thrashes(monkeypatch):
     """More (group, pass) keys than the cache holds, visited cyclically -- the shape of ResNet-152 with the regulariser on one GPU (~196 keys), or
     of a feed that re-allocates its buffers every step: the least recently used list is dropped, its library events are REUSED by the next
@@ -390,7 +405,9 @@ def test_command_list_cache_is_bounded_and_stops_recording_when_it_thrashes(monk
             counts.append(lib.event_count())
         torch.cuda.synchronize()
         if mode == "1":
-            assert len(eng.cmdlists) <= 4 and eng.cmd_evictions >= 4 and not eng.record_new
+            # recording was switched off at least once (misses ran through the interpreter, one warning), and hits pay the eviction count
+            # back so that it can come on again (a transient thrash must not disable recording for the rest of the process)
+            assert len(eng.cmdlists) <= 4 and eng.unrecorded_runs > 0 and eng._warned_record_off
             # 8 keys cycle through 4 slots: recordings reuse the ids of dropped lists; once recording has stopped the interpreted launches
             # draw from the engine's ring of 1024 eager events, and the table stops growing altogether
             from fullbatchtraining_amd.engine import _Events
@@ -399,6 +416,14 @@ def test_command_list_cache_is_bounded_and_stops_recording_when_it_thrashes(monk
             assert counts[1] - counts[0] <= 6 * per_list, (counts, per_list)        # step 1 records 8 lists into 4 slots: at most 5 of them on fresh events
             assert counts[-1] <= counts[1] + _Events.RING and len(eng.events.ring) <= _Events.RING, counts
         out[mode] = (eng.theta.clone(), eng.running_mean.clone())
+        if mode == "1":
+            # steady state on a working set that fits (2 chunks: prep + 2 group keys): every launch sequence is replayed again
+            for step in range(6):
+                eng.full_gradient(patches[: 2 * chunk], yd[: 2 * chunk], 0.1)
+            torch.cuda.synchronize()
+            before = eng.replays
+            eng.full_gradient(patches[: 2 * chunk], yd[: 2 * chunk], 0.1)
+            assert eng.record_new and eng.replays == before + 3, (eng.record_new, eng.replays - before)
     assert torch.equal(out["0"][0], out["1"][0]) and torch.equal(out["0"][1], out["1"][1])
 
 

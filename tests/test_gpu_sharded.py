@@ -39,6 +39,7 @@ def _run(rank, world, port, out_dir, grad_reg, backend="gloo", tag=None):
     one = ["impl.engine.chunk_group=8"]
     extra = {False: [], True: ["hyp.grad_reg.block_strength=0.5"], "options": OPTIONS, "shuffle": [], "ckpt": [], "ckpt_resume": ["hyp.steps=5"],
              "onegroup": one, "onegroup_gradreg": one + ["hyp.grad_reg.block_strength=0.5"],
+             "onegroup_bf16_px32": one + ["impl.mixed_precision=True", "data.pixels=32"],
              "onegroup_central": one + ["hyp.grad_reg.block_strength=0.5", "hyp.grad_reg.implementation=central-differences"],
              "acc": ["hyp.grad_reg.block_strength=0.0", "hyp.grad_reg.acc_strength=0.5", "hyp.grad_reg.implementation=central-differences"]}
     over = list(OVERRIDES) + extra[grad_reg]
@@ -49,7 +50,7 @@ def _run(rank, world, port, out_dir, grad_reg, backend="gloo", tag=None):
     cfg = compose(over, original_cwd=out_dir, name="sharded")
     torch.manual_seed(SEED)
     model = construct_model(cfg.model, 3, 10)
-    x, y = make_data(N, PIXELS)
+    x, y = make_data(N, 32 if "px32" in str(grad_reg) else PIXELS)
     setup = dict(device=torch.device("cuda", dev), dtype=torch.float, memory_format=torch.contiguous_format)
     feed = (x, y)
     if "ckpt" in str(grad_reg):                # checkpoint written by rank 0 of a sharded run / resumed by every rank
@@ -129,6 +130,33 @@ def test_rccl_collectives_one_rank(tmp_path, monkeypatch):
             # switches; bit-identical when the two clip norms happen to round alike, as they do with f16x2).  NaN from a poisoned slice fails either way
             a, b = (torch.cat([t.reshape(-1) for t in side["grads"]]).double() for side in (got, ref))
             assert bool(torch.isfinite(a).all()) and float((a - b).norm() / b.norm()) < 3e-2, mode
+
+
+def test_chained_weight_gradients_under_the_early_late_bucket(tmp_path, monkeypatch):
+    """FB_WGRAD_CHAIN=1 (the 4x4 layers' weight gradients as group sums + per-chunk sums of squares) in the sharded step whose late bucket is
+    folded on the side stream while the main stream folds the early range: the two folds must not share scratch (round 4's ``sq_seg[0]`` was
+    written and read by both with no order between them -- the per-chunk norms of one range could come out as the other's).  One RCCL rank,
+    bf16 at 32 px (the shape that has 4x4 maps), chained vs unchained: same per-chunk gradient norms, same mean gradient."""
+    out = str(tmp_path)
+    mode = "onegroup_bf16_px32"
+    monkeypatch.setenv("FB_FORCE_DIST", "1")
+    monkeypatch.delenv("FB_WGRAD_CHAIN", raising=False)
+    _ranks(1, out, mode, "nccl", "plain")
+    monkeypatch.setenv("FB_WGRAD_CHAIN", "1")
+    for rep in range(2):                                 # (a race: twice)
+        _ranks(1, out, mode, "nccl", f"chain{rep}")
+    ref = torch.load(os.path.join(out, "plain_r0.pt"))
+    for rep in range(2):
+        got = torch.load(os.path.join(out, f"chain{rep}_r0.pt"))
+        # the chained kernel sums a chunk group in another order (a chain of chunks per tile): last bits of the bf16 step, amplified by
+        # two updates -- statistics to 1e-3, the per-chunk norms of every step included
+        for key in ("train_loss", "grad_norm", "full_loss", "preclip_gradnorm", "param_norm"):
+            assert np.allclose(got["stats"][key], ref["stats"][key], rtol=2e-3, atol=1e-6), (rep, key, got["stats"][key], ref["stats"][key])
+        keys = [k for k in ref["stats"] if k.startswith("grad_norm_train_")] or []
+        for key in keys:
+            assert np.allclose(got["stats"][key], ref["stats"][key], rtol=2e-3), (rep, key)
+        a, b = (torch.cat([t.reshape(-1) for t in side["grads"]]).double() for side in (got, ref))
+        assert bool(torch.isfinite(a).all()) and float((a - b).norm() / b.norm()) < 5e-3, rep
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL wants one device per rank")

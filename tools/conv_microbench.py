@@ -37,6 +37,7 @@ def main():
     dtype = torch.bfloat16 if os.environ.get("DT", "bf16") == "bf16" else torch.float32
     for name in names:
         cin, cout, k, stride, hw, n = CASES[name]
+        n = int(os.environ.get("IMGS", n))                           # (IMGS=1024: the chunk group of the ResNet-152 step)
         pad = k // 2
         ho = (hw + 2 * pad - k) // stride + 1
         x = torch.randn(n, hw, hw, cin, device="cuda").to(dtype)
