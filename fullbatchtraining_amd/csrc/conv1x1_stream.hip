@@ -40,6 +40,18 @@ __device__ __forceinline__ int s1_xcd_remap(int b, int n) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
+// 16-byte buffer load through inline asm: invisible to hipcc's wait bookkeeping (it neither waits for it nor drains the LDS-DMA queue for it);
+// the consumer waits with s1_wait_addend4 below.  FIRST: the descriptor's words may come straight from v_readfirstlane (5 wait states).
+template <bool FIRST> __device__ __forceinline__ void s1_addend_load(s1_u32x4& dst, unsigned voff, s1_u32x4 rs) {
+    if constexpr (FIRST) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rs) : "memory");
+    else asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rs) : "memory");
+}
+// counted wait that names the four destinations it releases (no consumer of them can be scheduled above it)
+template <int N> __device__ __forceinline__ void s1_wait_addend4(s1_u32x4& a, s1_u32x4& b, s1_u32x4& c, s1_u32x4& d) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 struct S1Params {
     const char* src; const char* wgt; char* dst; const char* addend; float* stat;
     long long M; int Cd; int n_blocks; int n_co; int n_workers; int n_mblocks;
@@ -49,7 +61,13 @@ struct S1Params {
 // K input channels, CW output channels per wave.  One "unit" = 128 pixels (a statistics block) or one sub-tile of PXT pixels, whichever is larger.
 // NWC waves share the channels of the workgroup (NWC x CW of them), the other factor of the 8 waves shares the pixels of a sub-tile.
 // NW waves per workgroup (4: two workgroups per CU, one computes while the other waits for its loads and store acknowledgements).
-template <int K, int CW, int NWC, int NW>
+// ADD (input gradient with a same-shape addend, CW = 32): the addend fragments of a sub-tile are requested as 16-byte loads in the layout of the
+// STORES (8 consecutive channels per lane, `v_permlane16_swap` brings them back to the accumulator layout) right after the sub-tile's other memory
+// operations have been issued, and waited for with a counted `vmcnt` in the epilogue -- their latency runs under the sub-tile's MFMAs.  (As 8-byte
+// loads issued where they were consumed, every epilogue drained the whole memory queue first -- the next sub-tile's LDS-DMA and the late stores:
+// hipcc waits `vmcnt(0)` for an ordinary load beside LDS-DMA -- and the wave sat out the load's full latency: 333 us against 186 without addend
+// on 256 -> 1024 @14x14, 1024 images.)
+template <int K, int CW, int NWC, int NW, bool ADD = false>
 __global__ __launch_bounds__(NW * 64) void conv1x1_stream_kernel(const S1Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NS = K / 64;                       // 128-byte channel slices per pixel row
@@ -126,6 +144,9 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_stream_kernel(const S1Params 
 
     constexpr int JG = 4;                             // pixel fragments per accumulator group (64 pixels)
     const long long n_units = (p.M + UNIT - 1) / UNIT;
+    static_assert(!ADD || FI == 2, "the addend path pairs two 16-channel fragments per 16-byte load");
+    s1_u32x4 ad[ADD ? FJ : 1];                        // addend of this sub-tile, store layout: channels co0 + {0, 16, 8, 24}[g] .. + 7 of pixel j * 16 + col
+    const unsigned ad_lane = (unsigned)(((px0 + col) * p.Cd + co0 + (g & 1) * 16 + (g >> 1) * 8) * 2);
     long long unit = worker;
     if (unit < n_units) issue(unit * UNIT, 0);
     int stage = 0;
@@ -139,6 +160,19 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_stream_kernel(const S1Params 
             if (sb + 1 < NSUB) issue(m0u + (sb + 1) * PXT, stage ^ 1);
             else if (unit + p.n_workers < n_units) issue((unit + p.n_workers) * UNIT, stage ^ 1);
             if (sb == 0 && pk_m0 >= 0) { store_unit(pk_m0); pk_m0 = -1; }     // previous unit's outputs leave under this unit's MFMAs
+            if constexpr (ADD) {
+                // a descriptor per unit (rows past M read zeros; 32-bit offsets whatever the tensor's size); asm loads: hipcc must neither count nor drain them
+                const long long left = p.M - m0u;
+                const unsigned long long base = (unsigned long long)(p.addend + m0u * p.Cd * 2);
+                const s1_u32x4 rs = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base),
+                                     (unsigned)__builtin_amdgcn_readfirstlane((int)((base >> 32) & 0xffffu)),
+                                     (unsigned)__builtin_amdgcn_readfirstlane((int)((left < UNIT ? left : UNIT) * p.Cd * 2)), 0x00020000u};
+                s1_static_for<0, FJ>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    const unsigned voff = ad_lane + (unsigned)((sb * PXT + j * 16) * p.Cd * 2);
+                    s1_addend_load<j == 0>(ad[j], voff, rs);
+                });
+            }
             const unsigned r0 = rd0 + stage * TILE, r1 = rd1 + stage * TILE;
             s1_static_for<0, FJ / JG>([&](auto jgc) {
                 constexpr int jg = decltype(jgc)::value;
@@ -168,16 +202,31 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_stream_kernel(const S1Params 
                                                                                 acc[f][j], 0, 0, 0);
                 });
                 // epilogue of the group: (+ addend) -> packed bf16 kept for the late store; statistics per 128-pixel block
+                if constexpr (ADD) {                  // this group's addend fragments have landed: only the later groups' loads may still be in flight
+                    constexpr int later = FJ - (jg + 1) * JG;
+                    static_assert(JG == 4, "the wait below names four fragments");
+                    s1_wait_addend4<later>(ad[ADD ? jg * JG : 0], ad[ADD ? jg * JG + 1 : 0], ad[ADD ? jg * JG + 2 : 0], ad[ADD ? jg * JG + 3 : 0]);
+                }
 #pragma unroll
                 for (int jj = 0; jj < JG; ++jj) {
                     constexpr int jbase = jg * JG;
                     const int j = jbase + jj;
                     const int pix_in_unit = sb * PXT + px0 + j * 16;
                     const long long m = m0u + pix_in_unit + col;
+                    unsigned aw[2][2] = {{0u, 0u}, {0u, 0u}};          // addend words in the accumulator layout: [fragment][channel pair]
+                    if constexpr (ADD) {
+                        const s1_u32x4 a = ad[ADD ? j : 0];
+                        const s1_u32x2 lo = __builtin_amdgcn_permlane16_swap(a[0], a[2], false, false);      // the inverse of the store's exchange (an involution)
+                        const s1_u32x2 hi = __builtin_amdgcn_permlane16_swap(a[1], a[3], false, false);
+                        aw[0][0] = lo[0]; aw[1][0] = lo[1]; aw[0][1] = hi[0]; aw[1][1] = hi[1];
+                    }
 #pragma unroll
                     for (int f = 0; f < FI; ++f) {
                         float v[4] = {acc[f][jj][0], acc[f][jj][1], acc[f][jj][2], acc[f][jj][3]};
-                        if (p.addend != nullptr && m < p.M) {
+                        if constexpr (ADD) {
+                            v[0] += __uint_as_float(aw[f & 1][0] << 16); v[1] += __uint_as_float(aw[f & 1][0] & 0xffff0000u);
+                            v[2] += __uint_as_float(aw[f & 1][1] << 16); v[3] += __uint_as_float(aw[f & 1][1] & 0xffff0000u);
+                        } else if (p.addend != nullptr && m < p.M) {
                             const uint2 a = *(const uint2*)(p.addend + (m * p.Cd + co0 + f * 16 + g * 4) * 2);
                             v[0] += __uint_as_float(a.x << 16); v[1] += __uint_as_float(a.x & 0xffff0000u);
                             v[2] += __uint_as_float(a.y << 16); v[3] += __uint_as_float(a.y & 0xffff0000u);
@@ -216,8 +265,8 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_stream_kernel(const S1Params 
 #endif
 }
 
-template <int K, int CW, int NWC, int NW> static void s1_launch(const S1Params& p, int grid, hipStream_t st) {
-    hipLaunchKernelGGL((conv1x1_stream_kernel<K, CW, NWC, NW>), dim3(grid), dim3(NW * 64), 0, st, p);
+template <int K, int CW, int NWC, int NW, bool ADD = false> static void s1_launch(const S1Params& p, int grid, hipStream_t st) {
+    hipLaunchKernelGGL((conv1x1_stream_kernel<K, CW, NWC, NW, ADD>), dim3(grid), dim3(NW * 64), 0, st, p);
 }
 
 // returns 1 if the kernel handled the call: bf16 1x1 convolution (forward or input gradient), 64 / 128 / 256 input channels, output channels a
@@ -240,7 +289,9 @@ int fb_try_conv1x1_stream(const fb_conv_args* a, hipStream_t st) {
     // measured (tools/conv_microbench.py, profiles/r3_notes.md): 8-wave workgroups (one per CU) are 5-10 % faster for the forward shapes, 4-wave
     // ones (two per CU: one computes while the other waits for its loads and store acknowledgements) for most input gradients
     static const int nw_env = getenv("FB_C1S_NW") ? atoi(getenv("FB_C1S_NW")) : 0;
-    const int nw = nw_env ? nw_env : (a->mode == 0 ? 8 : 4);
+    const bool add_asm = !(getenv("FB_C1S_ADD_ASM") && atoi(getenv("FB_C1S_ADD_ASM")) == 0);      // A/B (read per call): the addend by in-place 8-byte loads
+    const bool add = a->addend != nullptr && add_asm;
+    const int nw = add ? 4 : (nw_env ? nw_env : (a->mode == 0 ? 8 : 4));
     const int CW = (nw == 8 && a->Cs != 64 && a->Cd % 256 != 0) ? 16 : 32;
     const int NWC = nw == 8 ? (a->Cs == 64 ? 4 : 8) : (a->Cs == 64 ? 2 : 4);
     const int pxt = 16384 / a->Cs, unit = pxt > 128 ? pxt : 128;
@@ -261,6 +312,10 @@ int fb_try_conv1x1_stream(const fb_conv_args* a, hipStream_t st) {
         if (a->Cs == 64) s1_launch<64, 32, 4, 8>(p, grid, st);
         else if (a->Cs == 128) { if (CW == 32) s1_launch<128, 32, 8, 8>(p, grid, st); else s1_launch<128, 16, 8, 8>(p, grid, st); }
         else { if (CW == 32) s1_launch<256, 32, 8, 8>(p, grid, st); else s1_launch<256, 16, 8, 8>(p, grid, st); }
+    } else if (add) {
+        if (a->Cs == 64) s1_launch<64, 32, 2, 4, true>(p, grid, st);
+        else if (a->Cs == 128) s1_launch<128, 32, 4, 4, true>(p, grid, st);
+        else s1_launch<256, 32, 4, 4, true>(p, grid, st);
     } else {
         if (a->Cs == 64) s1_launch<64, 32, 2, 4>(p, grid, st);
         else if (a->Cs == 128) s1_launch<128, 32, 4, 4>(p, grid, st);

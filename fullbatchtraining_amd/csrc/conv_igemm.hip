@@ -198,6 +198,7 @@ int fb_conv3x3_halo5_takes(const fb_conv_args* a);
 int fb_try_conv3x3s2_dgrad_quad(const fb_conv_args* a, hipStream_t st);   // conv3x3s2_dgrad_quad.hip
 int fb_try_conv1x1_k32(const fb_conv_args* a, hipStream_t st);     // conv1x1_k32.hip (the stem on pre-gathered patches)
 int fb_try_conv1x1_stream(const fb_conv_args* a, hipStream_t st);  // conv1x1_stream.hip (short-K 1x1 convolutions)
+int fb_try_conv1x1_pipe(const fb_conv_args* a, hipStream_t st);    // conv1x1_pipe.hip (the same with the epilogue threaded through the next group's MFMAs)
 
 // 1 if fb_conv2d accepts `addend_mask` for these arguments (only the resident-filter 64-channel kernel applies the mask so far)
 extern "C" int32_t fb_conv_masked_addend_supported(const fb_conv_args* a) {
@@ -282,6 +283,7 @@ extern "C" int fb_conv2d(const fb_conv_args* a, void* stream) {
     static const bool v1 = getenv("FB_IGEMM_V1") != nullptr;
     int kernel = 0;
     if (fb_try_conv1x1_k32(a, st)) kernel = FB_K_CONV1X1_K32;
+    else if (fb_try_conv1x1_pipe(a, st)) kernel = FB_K_CONV1X1_PIPE;
     else if (fb_try_conv1x1_stream(a, st)) kernel = FB_K_CONV1X1_STREAM;
     else if (fb_try_conv3x3s2_dgrad_quad(a, st)) kernel = FB_K_S2_DGRAD_QUAD;
     else if (fb_try_conv3x3_halo5(a, st)) kernel = FB_K_HALO5;

@@ -4,10 +4,13 @@ f32 kernels (exact-f32 MFMA) are held to accumulation-order roundoff; bf16 kerne
 evaluated on bf16-rounded inputs with fp32 accumulation (tolerance = bf16 output rounding, 2^-8 relative).
 """
 import ctypes as C
+import os
 
 import pytest
 import torch
 import torch.nn.functional as F
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -75,6 +78,13 @@ def test_conv_fwd_and_stats(dtype, cin, cout, k, stride, hw, n, monkeypatch):
     refn = nhwc(ref).reshape(-1, cout)
     assert rel(stat[0].sum(0).cpu(), refn.sum(0)) < 1e-4
     assert rel(stat[1].sum(0).cpu(), (refn * refn).sum(0)) < 1e-4
+    if k == 1 and dtype == torch.bfloat16 and cin in (64, 128, 256) and cout % 128 == 0:
+        # the pipelined streaming kernel (round 5) against the round-3 form: same products in the same order, same per-lane order of the statistics' sums
+        monkeypatch.setenv("FB_C1S_PIPE", "0")
+        out2, stat2 = torch.empty_like(out), torch.zeros_like(stat)
+        lib.conv2d(xd, wd, out2, k, k, stride, pad, 0, stat_partial=stat2)
+        monkeypatch.delenv("FB_C1S_PIPE")
+        assert torch.equal(out, out2) and torch.equal(stat, stat2)
     if stride == 2 and dtype == torch.bfloat16:
         # implicit GEMM: the double-buffered two-workgroup form (FB_IGEMM_STAGES=2) multiplies the same K-steps in the same order
         monkeypatch.setenv("FB_IGEMM_STAGES", "2")
@@ -133,6 +143,17 @@ def test_conv_dgrad(dtype, cin, cout, k, stride, hw, n, amode, monkeypatch):
         out2 = torch.empty_like(out)
         lib.conv2d(dyd, wt, out2, k, k, stride, pad, 1, addend=add_d, addend_mode=amode)
         assert torch.equal(out, out2)
+    if k == 1 and amode in (0, 1) and dtype == torch.bfloat16 and cout <= 256 and cin % 128 == 0:
+        # 1x1 input gradients, three forms of one arithmetic (same MFMA order, the addend added in fp32 before the one rounding): the pipelined
+        # streaming kernel (round 5: epilogue threaded through the next group's MFMAs, addend as prefetched 16-byte loads), the round-3 streaming
+        # kernel with prefetched addend, and with the addend as 8-byte loads where it is consumed -- same bits
+        for env in ({"FB_C1S_PIPE": "0"}, {"FB_C1S_PIPE": "0", "FB_C1S_ADD_ASM": "0"}):
+            for key, val in env.items():
+                monkeypatch.setenv(key, val)
+            out2 = torch.empty_like(out)
+            lib.conv2d(dyd, wt, out2, k, k, stride, pad, 1, addend=add_d, addend_mode=amode)
+            assert torch.equal(out, out2), env
+        monkeypatch.delenv("FB_C1S_PIPE"), monkeypatch.delenv("FB_C1S_ADD_ASM")
     if stride == 2 and dtype == torch.bfloat16:
         # the quad kernel's double-buffered one-workgroup form (FB_S2Q_STAGES=2) accumulates in the same order: same bits
         monkeypatch.setenv("FB_S2Q_STAGES", "2")
