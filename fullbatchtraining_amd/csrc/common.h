@@ -181,6 +181,34 @@ template <int NJ> __device__ __forceinline__ void mma_split6_row(const split3_t&
         asm volatile("" : "+v"(c[j]));      // pin the sum here: LLVM otherwise sinks the whole add chain below the K loop and spills every t
     }
 }
+// The same with `valu_per_mfma` independent vector instructions of the caller (issued in program order BEFORE this call: the split of the next
+// operand) threaded through the 6 NJ MFMAs: the request sits between the MFMAs and the pinned sums -- an `asm volatile` ends the scheduler's
+// region, so a request behind the pins would find no MFMA to interleave with
+template <int NJ, int VPM> __device__ __forceinline__ void mma_split6_row_mix(const split3_t& a, const split3_t (&b)[NJ], f32x4_t (&c)[NJ]) {
+    f32x4_t t[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) t[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b[j].h, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) t[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b[j].l, t[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) t[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b[j].m, t[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) t[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b[j].h, t[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) t[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b[j].m, t[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) t[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b[j].h, t[j], 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 6 * NJ; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        c[j] += t[j];
+        asm volatile("" : "+v"(c[j]));
+    }
+}
 template <typename T> struct is_split { static constexpr bool value = false; };
 template <> struct is_split<f32s_tag> { static constexpr bool value = true; };
 

@@ -1,0 +1,228 @@
+// 1x1 convolutions with K >= 512 input channels (the channel-reducing convolutions of the Bottleneck blocks and their input gradients,
+// reference resnets.py:289-291: 1024 -> 256 @14x14, 512 -> 128 @28x28, 2048 -> 512 @7x7 ...), bf16, forward and input gradient.
+//
+// These went to the implicit GEMM (conv_igemm_glds.hip: 128 x 128 tiles, ONE 32 KiB stage, three workgroups per CU), where the counters show a
+// latency-bound kernel (round 5, 1024 -> 256 @14x14, 1024 images, 155 us = 678 TFLOP/s: 53 % of the wave cycles in s_waitcnt / s_barrier, matrix
+// pipe busy a third of the time): every K-step waits for the loads it has just issued, and a tile lives through 16 of them.  Here:
+//   * persistent workgroups (one per CU, 8 waves) walk a list of 256-pixel x 128-channel tiles; the K-steps of ALL their tiles form one stream
+//     through a RING OF THREE 48 KiB LDS stages (256 pixel rows + 128 filter rows of 128 bytes, `buffer_load ... lds`, XOR-swizzled on the
+//     source side): the loads of step t + 2 are issued while step t is multiplied, across tile boundaries, and every wait is a counted
+//     `s_waitcnt vmcnt(N)` -- the queue is never drained (all memory operations are issued unconditionally; rows past the tensor's end and
+//     steps past the workgroup's last tile read zeros / store nothing through the range check of per-tile descriptors)
+//   * a wave owns 128 pixels x 32 channels (16 accumulator fragments): 20 fragment reads per 32 MFMAs, a whole 128-pixel statistics block per
+//     wave (BatchNorm partial sums by DPP row sums, no cross-wave reduction), 16-byte stores after `v_permlane16_swap`
+//   * co-tiles of one pixel tile are neighbours in the tile list: they run at the same time on one XCD and share the pixel rows in its L2
+#include "common.h"
+#include "conv_params.h"
+
+#include <type_traits>
+
+namespace {
+typedef __attribute__((ext_vector_type(4))) unsigned g1_u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned g1_u32x2;
+typedef __attribute__((ext_vector_type(4))) float g1_f32x4;
+template <int N> __device__ __forceinline__ void g1_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void g1_wait_lgkmcnt() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int OFF> __device__ __forceinline__ uint4 g1_lds_read16(unsigned byte_addr) {
+    g1_u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(OFF));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+template <int I, int N, typename F> __device__ __forceinline__ void g1_static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); g1_static_for<I + 1, N>(f); }
+}
+__device__ __forceinline__ int g1_xcd_remap(int b, int n) {
+    const int q = n >> 3, r = n & 7, xcd = b & 7, slot = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+constexpr unsigned G1_OOB = 0x80000000u;
+constexpr int G1_BM = 256, G1_BN = 128, G1_STAGE = (G1_BM + G1_BN) * 128, G1_NSTAGE = 3, G1_NDMA = (G1_BM + G1_BN) / 8 / 8;   // 6 LDS-DMA pieces per wave and K-step
+
+struct G1Params {
+    const char* src; const char* wgt; char* dst; float* stat;
+    long long M; int K; int Cd; int n_co; int n_tiles; int n_workers; int n_mblocks;
+};
+}  // namespace
+
+template <bool STAT>
+__global__ __launch_bounds__(512) void conv1x1_gemm_kernel(const G1Params p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int FI = 2, FJ = 8, NST = FJ + (STAT ? 4 : 0);      // stores of one tile's epilogue per wave
+    __shared__ __attribute__((aligned(16))) char lds[G1_NSTAGE * G1_STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, g = lane >> 4;
+    const int worker = __builtin_amdgcn_readfirstlane(g1_xcd_remap(blockIdx.x, gridDim.x));
+    const int wp = wave >> 2, wc = wave & 3;                        // pixel half / channel quarter of the tile
+    const int KS = p.K >> 6;                                        // K-steps per tile
+    const int rowA_b = p.K * 2, row_b = p.Cd * 2;
+
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    // LDS-DMA piece q = 6 wave + i: rows 8 q .. 8 q + 7 of the stage (pixels first, then filter rows); lane -> row (lane >> 3), logical chunk (lane & 7) ^ (row & 7)
+    const unsigned dma_lane = (unsigned)((lane >> 3) * rowA_b + (((lane & 7) ^ (lane >> 3)) * 16));
+    // fragment reads: row (16 j + col) of the wave's pixel half / (16 i + col) of its channel quarter, logical chunk g + 4 h
+    unsigned pa[2], pb[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        pa[h] = lds0 + (wp * 128 + col) * 128 + (((g + 4 * h) ^ (col & 7)) * 16);
+        pb[h] = lds0 + (G1_BM + wc * 32 + col) * 128 + (((g + 4 * h) ^ (col & 7)) * 16);
+    }
+    // stores: pixel wp * 128 + 16 j + col of the tile, 8 channels wc * 32 + {0, 16, 8, 24}[g] .. + 7 (after the lane-row exchange)
+    const unsigned voffS = (unsigned)((wp * 128 + col) * row_b + (wc * 32 + (g & 1) * 16 + (g >> 1) * 8) * 2);
+    const unsigned voffT = col == 0 ? (unsigned)((wc * 32 + g * 4) * 4) : G1_OOB;
+
+    const int n_my = worker < p.n_tiles ? (p.n_tiles - worker + p.n_workers - 1) / p.n_workers : 0;      // tiles of this workgroup
+    if (n_my == 0) return;
+
+    // the LDS-DMA round of step (tile index ti of this workgroup, K-step ks); ti >= n_my: empty descriptors (zeros into a stage nobody multiplies)
+    auto issue_round = [&](const int ti, const int ks, const int stage) {
+        const int tile = worker + ti * p.n_workers;
+        const bool live = ti < n_my;
+        const int mt = live ? tile / p.n_co : 0, co = live ? tile - mt * p.n_co : 0;
+        const long long m0 = (long long)mt * G1_BM;
+        long long rows = p.M - m0;
+        rows = !live || rows < 0 ? 0 : (rows > G1_BM ? G1_BM : rows);
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.src + m0 * rowA_b), 0, (int)(rows * rowA_b), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.wgt + (long long)co * G1_BN * rowA_b), 0, live ? G1_BN * rowA_b : 0, 0x00020000);
+        char* base = lds + stage * G1_STAGE;
+#pragma unroll
+        for (int i = 0; i < G1_NDMA; ++i) {
+            const int q = wave * G1_NDMA + i;                       // wave-uniform
+            __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(base + q * 1024);
+            if (q < G1_BM / 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, dst, 16, dma_lane + (unsigned)(q * 8 * rowA_b), ks * 128, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, dst, 16, dma_lane + (unsigned)((q - G1_BM / 8) * 8 * rowA_b), ks * 128, 0, 0);
+        }
+    };
+
+    f32x4_t acc[FI][FJ];
+    // prologue: the rounds of steps 0 and 1 (KS >= 8: both belong to the first tile)
+    int dma_ti = 0, dma_ks = 0;                          // the next round to issue: always two steps ahead of the step that is multiplied
+    issue_round(0, 0, 0);
+    issue_round(0, 1, 1);
+    dma_ks = 2;
+    int stage = 0;
+    int after_epilogue = 0;                              // steps whose wait must still count the previous tile's stores (they sit between two rounds in the queue)
+    for (int ti = 0; ti < n_my; ++ti) {
+        for (int ks = 0; ks < KS; ++ks) {
+            // this step's round has landed: younger are the next step's round (and, behind an epilogue, its stores)
+            if (after_epilogue > 0) { g1_wait_vmcnt<G1_NDMA + NST>(); --after_epilogue; } else g1_wait_vmcnt<G1_NDMA>();
+            __builtin_amdgcn_s_barrier();                // ... everybody's share; everybody has left the stage the next round goes into (step t - 1's)
+            issue_round(dma_ti, dma_ks, stage == 0 ? 2 : stage - 1);
+            if (++dma_ks == KS) { dma_ks = 0; ++dma_ti; }
+            const unsigned so = stage * G1_STAGE;
+            uint4 wb[2][FI], px[2][FJ];
+            g1_static_for<0, 2>([&](auto hc) {
+                constexpr int h = decltype(hc)::value;
+                g1_static_for<0, FI>([&](auto ic) { constexpr int i = decltype(ic)::value; wb[h][i] = g1_lds_read16<i * 2048>(pb[h] + so); });
+                g1_static_for<0, FJ>([&](auto jc) { constexpr int j = decltype(jc)::value; px[h][j] = g1_lds_read16<j * 2048>(pa[h] + so); });
+            });
+            g1_wait_lgkmcnt<FI + FJ>();
+            if (ks == 0) {
+#pragma unroll
+                for (int i = 0; i < FI; ++i)
+#pragma unroll
+                    for (int j = 0; j < FJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wb[0][i]), __builtin_bit_cast(bf16x8_t, px[0][j]), (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < FI; ++i)
+#pragma unroll
+                    for (int j = 0; j < FJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wb[0][i]), __builtin_bit_cast(bf16x8_t, px[0][j]), acc[i][j], 0, 0, 0);
+            }
+            g1_wait_lgkmcnt<0>();
+#pragma unroll
+            for (int i = 0; i < FI; ++i)
+#pragma unroll
+                for (int j = 0; j < FJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wb[1][i]), __builtin_bit_cast(bf16x8_t, px[1][j]), acc[i][j], 0, 0, 0);
+            stage = stage == 2 ? 0 : stage + 1;
+        }
+        // ---- epilogue of the tile: bf16 outputs (16-byte stores of 8 consecutive channels), BatchNorm partial sums of the wave's 128-pixel block ----
+        const int tile = worker + ti * p.n_workers;
+        const int mt = tile / p.n_co, co = tile - mt * p.n_co;
+        const long long m0 = (long long)mt * G1_BM;
+        long long rows = p.M - m0;
+        rows = rows > G1_BM ? G1_BM : rows;
+        const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dst + m0 * row_b + co * G1_BN * 2), 0, (int)(rows * row_b), 0x00020000);
+        float ssum[FI][4], ssq[FI][4];
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) {
+            unsigned q[FI][2];
+#pragma unroll
+            for (int i = 0; i < FI; ++i) {
+                const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                q[i][0] = pack_bf16x2(v[0], v[1]); q[i][1] = pack_bf16x2(v[2], v[3]);
+                if constexpr (STAT) {
+                    if (j == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { ssum[i][r] = v[r]; ssq[i][r] = v[r] * v[r]; }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { ssum[i][r] += v[r]; ssq[i][r] = fmaf(v[r], v[r], ssq[i][r]); }
+                    }
+                }
+            }
+            const g1_u32x2 lo = __builtin_amdgcn_permlane16_swap(q[0][0], q[1][0], false, false);
+            const g1_u32x2 hi = __builtin_amdgcn_permlane16_swap(q[0][1], q[1][1], false, false);
+            const g1_u32x4 o = {lo[0], hi[0], lo[1], hi[1]};
+            __builtin_amdgcn_raw_buffer_store_b128(o, rsD, voffS + (unsigned)(j * 16 * row_b), 0, 0);
+            store_b128_guard(o);
+        }
+        if constexpr (STAT) {
+            const long long blk = (m0 >> 7) + wp;
+            const bool ok = blk < p.n_mblocks;
+            const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc((void*)(p.stat + (ok ? blk : 0) * p.Cd + co * G1_BN), 0,
+                                                                                ok ? (int)((p.n_mblocks + 1LL) * p.Cd * 4) : 0, 0x00020000);
+            const int plane = p.n_mblocks * p.Cd * 4;
+#pragma unroll
+            for (int i = 0; i < FI; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ssum[i][r] = row16_sum(ssum[i][r]); ssq[i][r] = row16_sum(ssq[i][r]); }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(g1_u32x4, (g1_f32x4){ssum[i][0], ssum[i][1], ssum[i][2], ssum[i][3]}), rsT, voffT + i * 64, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(g1_u32x4, (g1_f32x4){ssq[i][0], ssq[i][1], ssq[i][2], ssq[i][3]}), rsT, voffT + i * 64, plane, 0);
+            }
+        }
+        after_epilogue = 2;
+    }
+    g1_wait_vmcnt<0>();                                  // (the two rounds past the end: nothing may land in LDS after the workgroup has left)
+#endif
+}
+
+// returns 1 if the kernel handled the call: bf16 1x1 convolution (forward or input gradient), K a multiple of 64 and >= 512, output channels a multiple of
+// 128, one shared weight set, no addend, optional BatchNorm partial sums (forward).  FB_C1G=0: the implicit GEMM takes these calls.
+int fb_try_conv1x1_gemm(const fb_conv_args* a, hipStream_t st) {
+    // OPT-IN (FB_C1G=1: forward calls, FB_C1G=2: input gradients too; read per call: the tests compare the two kernels inside one process).  Built, bit-identical to
+    // the implicit GEMM, and measured WITHOUT effect where it counts: ResNet-152 @224, 2048 images per step, same box: 5775 / 5809 images/s with it,
+    // 5789 / 5780 without, 5790 with the input gradients too.
+    const char* sw = getenv("FB_C1G");
+    if (sw == nullptr || atoi(sw) == 0) return 0;
+    if (a->R != 1 || a->S != 1 || a->stride != 1 || a->pad != 0 || a->dtype != FB_BF16) return 0;
+    if (a->Hs != a->Hd || a->Ws != a->Wd) return 0;
+    if (a->Cs < 512 || a->Cs % 64 != 0 || a->Cs > 4096 || a->Cd % G1_BN != 0) return 0;
+    if (a->wset_stride != 0 && a->imgs_per_wset > 0 && a->imgs_per_wset < a->n_img) return 0;
+    if (a->addend || a->addend_mask || a->bst_x) return 0;
+    if (a->mode == 1 && a->stat_partial) return 0;
+    // Measured against the implicit GEMM (1024 images, same box, us): forward 1024 -> 256 @14x14 147 / 158, 512 -> 2048 @7x7 149 / 177, 512 -> 128 @28x28
+    // 210 / 219, 2048 -> 512 @7x7 140 / 138; input gradients 154 / 154, 137 / 132, 211 / 215, 129 / 133: the ring removes the waits but the 48 LDS-DMA
+    // instructions a K-step needs cost a wave ~100 cycles each to ISSUE -- as much as its 32 MFMAs -- so the matrix pipe is no busier than before.
+    // (alone on the device; inside the step the difference disappears, see above)
+    if (a->mode == 1 && !(sw != nullptr && atoi(sw) == 2)) return 0;
+    const long long M = (long long)a->n_img * a->Hd * a->Wd;
+    if ((M + G1_BM - 1) / G1_BM * (a->Cd / G1_BN) >= (1LL << 31) || (M / 128 + 2) * a->Cd * 8 >= (1LL << 31)) return 0;
+    G1Params p;
+    p.src = (const char*)a->src; p.wgt = (const char*)a->wgt; p.dst = (char*)a->dst; p.stat = a->stat_partial;
+    p.M = M; p.K = a->Cs; p.Cd = a->Cd;
+    p.n_co = a->Cd / G1_BN;
+    p.n_tiles = (int)((M + G1_BM - 1) / G1_BM) * p.n_co;
+    p.n_mblocks = (int)((M + 127) / 128);
+    const int n_cu = fb_persistent_cus();
+    p.n_workers = p.n_tiles < n_cu ? p.n_tiles : n_cu;
+    if (a->stat_partial) hipLaunchKernelGGL((conv1x1_gemm_kernel<true>), dim3(p.n_workers), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((conv1x1_gemm_kernel<false>), dim3(p.n_workers), dim3(512), 0, st, p);
+    return 1;
+}

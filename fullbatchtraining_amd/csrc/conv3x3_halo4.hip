@@ -388,12 +388,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
                     split3_t sp[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) sp[j] = split_f32x8(pf0[j], pf1[j]);
+#ifndef FB_H4_SPLIT_PIPE
+#define FB_H4_SPLIT_PIPE 1
+#endif
+#if FB_H4_SPLIT_PIPE
+                    // One weight fragment at a time, four zero-started chains in flight -- and the split of fragment i + 1 (44 VALU) threaded through the 24
+                    // MFMAs of fragment i: with the split in front of its MFMAs (round 2-4) the two waves of a SIMD, which leave the per-tap barrier together,
+                    // ran their split phases against each other and then their MFMA phases (MFMA time + VALU time, not the larger of the two)
+                    split3_t sw = split_f32x8(wf0[0], wf1[0]);
+                    h4_static_for<0, FI>([&](auto ic) {
+                        constexpr int I = decltype(ic)::value;
+                        split3_t swn = sw;
+                        if constexpr (I + 1 < FI) {
+                            swn = split_f32x8(wf0[I + 1], wf1[I + 1]);
+                            mma_split6_row_mix<4, 2>(sw, sp, acc[I]);
+                        } else {
+                            mma_split6_row<4>(sw, sp, acc[I]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        sw = swn;
+                    });
+#else
 #pragma unroll
                     for (int i = 0; i < FI; ++i) {                 // one weight fragment split at a time: four zero-started chains in flight
                         const split3_t sw = split_f32x8(wf0[i], wf1[i]);
                         mma_split6_row<4>(sw, sp, acc[i]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
+#endif
                 } else {
 #ifdef FB_H4_MFMA32
                 // TIMING-ONLY experiment (tools/h4_trace.hip -DFB_H4_MFMA32; results are wrong): the same fragment reads and the same FLOP per

@@ -198,6 +198,7 @@ int fb_conv3x3_halo5_takes(const fb_conv_args* a);
 int fb_try_conv3x3s2_dgrad_quad(const fb_conv_args* a, hipStream_t st);   // conv3x3s2_dgrad_quad.hip
 int fb_try_conv1x1_k32(const fb_conv_args* a, hipStream_t st);     // conv1x1_k32.hip (the stem on pre-gathered patches)
 int fb_try_conv1x1_stream(const fb_conv_args* a, hipStream_t st);  // conv1x1_stream.hip (short-K 1x1 convolutions)
+int fb_try_conv1x1_gemm(const fb_conv_args* a, hipStream_t st);    // conv1x1_gemm.hip (K >= 512: persistent tiles, three-stage LDS ring)
 int fb_try_conv1x1_pipe(const fb_conv_args* a, hipStream_t st);    // conv1x1_pipe.hip (the same with the epilogue threaded through the next group's MFMAs)
 
 // 1 if fb_conv2d accepts `addend_mask` for these arguments (only the resident-filter 64-channel kernel applies the mask so far)
@@ -285,6 +286,7 @@ extern "C" int fb_conv2d(const fb_conv_args* a, void* stream) {
     if (fb_try_conv1x1_k32(a, st)) kernel = FB_K_CONV1X1_K32;
     else if (fb_try_conv1x1_pipe(a, st)) kernel = FB_K_CONV1X1_PIPE;
     else if (fb_try_conv1x1_stream(a, st)) kernel = FB_K_CONV1X1_STREAM;
+    else if (fb_try_conv1x1_gemm(a, st)) kernel = FB_K_CONV1X1_GEMM;
     else if (fb_try_conv3x3s2_dgrad_quad(a, st)) kernel = FB_K_S2_DGRAD_QUAD;
     else if (fb_try_conv3x3_halo5(a, st)) kernel = FB_K_HALO5;
     else if (fb_try_conv3x3_halo4(a, st)) kernel = FB_K_HALO4;

@@ -199,15 +199,24 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(const ConvParams p, 
                     for (int j = 0; j < FJ; ++j) acc[i][j] = mma_split3h(sw[i], sp[j], acc[i][j], hs_inv);
             } else if constexpr (is_split<T>::value) {      // fp32 operands as three bf16 pieces each, six MFMAs per fragment pair (common.h)
                 wait_lgkmcnt<0>();
-                split3_t sw[FI], sp[FJ];
-#pragma unroll
-                for (int i = 0; i < FI; ++i) sw[i] = split_f32x8(wf0[i], wf1[i]);
+                split3_t sp[FJ];
 #pragma unroll
                 for (int j = 0; j < FJ; ++j) sp[j] = split_f32x8(pf0[j], pf1[j]);
-#pragma unroll
-                for (int i = 0; i < FI; ++i)
-#pragma unroll
-                    for (int j = 0; j < FJ; ++j) acc[i][j] = mma_split6(sw[i], sp[j], acc[i][j]);
+                // one weight fragment at a time, FJ zero-started chains in flight, the split of fragment i + 1 threaded through the MFMAs of fragment i
+                // (round 5; before: all eight splits, then 96 MFMAs as 16 chains of six DEPENDENT products)
+                split3_t sw = split_f32x8(wf0[0], wf1[0]);
+                static_for<0, FI>([&](auto ic) {
+                    constexpr int I = decltype(ic)::value;
+                    split3_t swn = sw;
+                    if constexpr (I + 1 < FI) {
+                        swn = split_f32x8(wf0[I + 1], wf1[I + 1]);
+                        mma_split6_row_mix<FJ, 2>(sw, sp, acc[I]);
+                    } else {
+                        mma_split6_row<FJ>(sw, sp, acc[I]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    sw = swn;
+                });
             } else {
             wait_lgkmcnt<FI + FJ>();                 // first half has landed (LDS returns in order)
 #pragma unroll

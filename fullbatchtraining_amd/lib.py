@@ -95,7 +95,7 @@ EXPORTS = tuple(_SIGS) + ("fb_last_error_string", "fb_abi_version", "fb_profile_
 PROF_CLASSES = ("igemm_fwd", "igemm_dgrad", "wgrad", "bn_apply", "bn_bwd_reduce", "bn_bwd_apply", "bn_bwd_fused")
 PROF_INFO = 11
 PROF_KERNELS = {0: "?", 1: "conv_igemm_kernel (register-staged)", 2: "conv_igemm_v3_kernel", 3: "conv3x3s1_halo4_kernel", 4: "conv3x3s1_c64_halo5_kernel",
-                5: "conv3x3s2_dgrad_quad_kernel", 6: "conv1x1_k32_kernel", 7: "conv1x1_stream_kernel", 8: "conv3x3s2_fwd_kernel", 9: "conv1x1_pipe_kernel",
+                5: "conv3x3s2_dgrad_quad_kernel", 6: "conv1x1_k32_kernel", 7: "conv1x1_stream_kernel", 8: "conv3x3s2_fwd_kernel", 9: "conv1x1_pipe_kernel", 10: "conv1x1_gemm_kernel",
                 16: "conv_wgrad_kernel", 17: "conv_wgrad3x3_kernel", 18: "conv_wgrad3x3_v2_kernel", 19: "conv_wgrad1x1_kernel"}
 
 

@@ -58,7 +58,10 @@ def krsc(w):  # [co, ci, kh, kw] -> [co, kh*kw, ci]
                                                    # short-K 1x1 convolutions: streaming kernel (bf16), every (K, channels-per-wave) variant, ragged pixel counts,
                                                    # several units per persistent workgroup
                                                    (64, 128, 1, 1, 16, 3), (128, 256, 1, 1, 8, 5), (256, 512, 1, 1, 4, 16), (256, 1024, 1, 1, 14, 2), (64, 256, 1, 1, 8, 3),
-                                                   (128, 128, 1, 1, 8, 40), (256, 128, 1, 1, 6, 3), (64, 128, 1, 1, 6, 3), (64, 128, 1, 1, 16, 700), (256, 256, 1, 1, 14, 300)])
+                                                   (128, 128, 1, 1, 8, 40), (256, 128, 1, 1, 6, 3), (64, 128, 1, 1, 6, 3), (64, 128, 1, 1, 16, 700), (256, 256, 1, 1, 14, 300),
+                                                   # 1x1 with K >= 512: persistent GEMM tiles through a three-stage LDS ring (bf16); ragged pixel counts, one and several
+                                                   # tiles per workgroup, one to sixteen channel tiles
+                                                   (512, 128, 1, 1, 8, 5), (1024, 256, 1, 1, 14, 3), (2048, 512, 1, 1, 7, 4), (512, 2048, 1, 1, 7, 2), (576, 128, 1, 1, 14, 400)])
 def test_conv_fwd_and_stats(dtype, cin, cout, k, stride, hw, n, monkeypatch):
     lib = _lib()
     torch.manual_seed(0)
@@ -85,6 +88,14 @@ def test_conv_fwd_and_stats(dtype, cin, cout, k, stride, hw, n, monkeypatch):
         lib.conv2d(xd, wd, out2, k, k, stride, pad, 0, stat_partial=stat2)
         monkeypatch.delenv("FB_C1S_PIPE")
         assert torch.equal(out, out2) and torch.equal(stat, stat2)
+    if k == 1 and dtype == torch.bfloat16 and cin >= 512:
+        # the K >= 512 GEMM kernel against the implicit GEMM: the same K-steps in the same order (same output bits); the statistics' fp32 sums associate
+        # differently (one wave per 128-pixel block here, two half-block waves there)
+        monkeypatch.setenv("FB_C1G", "1")                # (opt-in: measured without effect on the ResNet-152 step)
+        out2, stat2 = torch.empty_like(out), torch.zeros_like(stat)
+        lib.conv2d(xd, wd, out2, k, k, stride, pad, 0, stat_partial=stat2)
+        monkeypatch.delenv("FB_C1G")
+        assert torch.equal(out, out2) and rel(stat, stat2) < 1e-5
     if stride == 2 and dtype == torch.bfloat16:
         # implicit GEMM: the double-buffered two-workgroup form (FB_IGEMM_STAGES=2) multiplies the same K-steps in the same order
         monkeypatch.setenv("FB_IGEMM_STAGES", "2")
@@ -112,7 +123,9 @@ def test_conv_fwd_and_stats(dtype, cin, cout, k, stride, hw, n, monkeypatch):
                                                           # 1x1 input gradients: streaming kernel (K = the forward layer's output channels <= 256), with / without the
                                                           # same-shape addend; pooled addend and K = 512 stay on the implicit GEMM
                                                           (256, 128, 1, 1, 8, 5, 0), (1024, 256, 1, 1, 7, 4, 1), (512, 128, 1, 1, 8, 3, 1), (128, 64, 1, 1, 16, 300, 1),
-                                                          (256, 64, 1, 1, 8, 6, 2), (256, 512, 1, 1, 4, 16, 1)])
+                                                          (256, 64, 1, 1, 8, 6, 2), (256, 512, 1, 1, 4, 16, 1),
+                                                          # 1x1 input gradients with K >= 512 (the GEMM kernel; with an addend they stay on the implicit GEMM)
+                                                          (128, 512, 1, 1, 8, 5, 0), (256, 1024, 1, 1, 14, 3, 0), (512, 2048, 1, 1, 7, 6, 0), (256, 1024, 1, 1, 14, 3, 1)])
 def test_conv_dgrad(dtype, cin, cout, k, stride, hw, n, amode, monkeypatch):
     lib = _lib()
     torch.manual_seed(1)
@@ -154,6 +167,12 @@ def test_conv_dgrad(dtype, cin, cout, k, stride, hw, n, amode, monkeypatch):
             lib.conv2d(dyd, wt, out2, k, k, stride, pad, 1, addend=add_d, addend_mode=amode)
             assert torch.equal(out, out2), env
         monkeypatch.delenv("FB_C1S_PIPE"), monkeypatch.delenv("FB_C1S_ADD_ASM")
+    if k == 1 and amode == 0 and dtype == torch.bfloat16 and cout >= 512:
+        monkeypatch.setenv("FB_C1G", "2")                # K >= 512: the GEMM kernel (opt-in for input gradients) and the implicit GEMM multiply the same K-steps in the same order
+        out2 = torch.empty_like(out)
+        lib.conv2d(dyd, wt, out2, k, k, stride, pad, 1)
+        monkeypatch.delenv("FB_C1G")
+        assert torch.equal(out, out2)
     if stride == 2 and dtype == torch.bfloat16:
         # the quad kernel's double-buffered one-workgroup form (FB_S2Q_STAGES=2) accumulates in the same order: same bits
         monkeypatch.setenv("FB_S2Q_STAGES", "2")
