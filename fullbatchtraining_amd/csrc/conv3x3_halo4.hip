@@ -29,6 +29,7 @@ struct Halo4Params {
     int imgs_per_wset; long long wset_stride_bytes;
     int addend_mode, n_mblocks, n_ct, n_tiles;
     unsigned magic_ct, magic_wset;                          // ceil(2^32 / d), 0 for d == 1
+    int phase_mode, phase_sleeps;                           // FB_H4_PHASE (A/B switch): one of the two workgroups of a CU starts late by ~3.9 us x sleeps
 #ifdef FB_H4_TRACE
     long long* trace;                                       // tools/h4_trace.hip: 8 timestamps per tile
 #endif
@@ -101,6 +102,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
     constexpr int PITCH = G::PITCH, NGRP = G::NGRP;
     constexpr int CO_T = 16 * FI, NWL = FI / 2;                   // output channels per tile; weight LDS-DMA instructions per wave and tap
     constexpr int HALO_BYTES = NGRP * 1024, WT_BYTES = CO_T * 128, NW = 3, RED_BYTES = 4 * CO_T * 2 * 4;
+#ifndef FB_H4_COUNTED_TOP
+#define FB_H4_COUNTED_TOP 0                                 // A/B build switch (tools/build_variant.py top1 --only conv3x3_halo4.hip -DFB_H4_COUNTED_TOP=1): measured without effect
+#endif
 #ifndef FB_H4_LDS_PAD
 #define FB_H4_LDS_PAD 0                                     // tools/h4_trace.hip: pad to force one workgroup per CU
 #endif
@@ -313,6 +317,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
     // set by the per-CU load/store pipeline, not by idle workgroups.)
     int L = h4_xcd_remap(blockIdx.x, NB);
     if (L >= p.n_tiles) return;
+    if (p.phase_mode != 0) {
+        // (verdict r4 item 8) The two workgroups of a CU start together and walk tiles of equal length: are they in their epilogues together, with the
+        // matrix pipe idle?  Delay one of them by about half a tile.  Which two share a CU is not documented: mode 1 = the second half of an XCD's
+        // workgroups (round-robin placement), mode 2 = every other one (packed placement).
+        const int k = blockIdx.x >> 3;
+        const bool second = p.phase_mode == 1 ? k >= (NB >> 4) : (k & 1) != 0;
+        if (second)
+            for (int i = 0; i < p.phase_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     auto scales_of = [&](const H4Tile& t) {
         if constexpr (is_hsplit<T>::value) {
             hs_src = fb_pow2_scale(p.amax_src[t.n0 / p.amax_imgs]);
@@ -320,6 +333,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
         }
     };
     H4Tile cur = decode(L);
+    bool first_tile = true;
     halo_issue(cur, 0);
     wt_issue(0, cur, 0, tap_of(0));
     wt_issue(1, cur, 0, tap_of(1));
@@ -334,7 +348,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
         H4Tile nxt = cur;
         if (has_next) nxt = decode(Ln);
         scales_of(cur);
-        h4_wait_vmcnt<0>();                                // halo slice 0 + weight taps 0, 1 (and the previous tile's stores)
+        // halo slice 0 + weight taps 0, 1 have landed (and, with `vmcnt(0)`, the previous tile's stores have been acknowledged).  The loads were requested
+        // BEFORE the previous tile's epilogue, so a counted wait would let its stores fly on (FB_H4_COUNTED_TOP=1: bf16 one 16-byte store per fragment pair
+        // and pixel fragment, fp32 one per fragment, + 2 statistics stores in the waves of the 2 CO_T reader threads; all issued unconditionally).  Built and
+        // measured in round 5, same box: 871 / 864 us (128 -> 128 @16x16 forward), 229.9 / 229.5 against 230.0 / 228.9 ms per step: the other workgroup of
+        // the CU already covers that wait.  Off.
+        if (first_tile || FB_H4_COUNTED_TOP == 0) h4_wait_vmcnt<0>();
+        else if (p.stat != nullptr && wave < 2 * CO_T / 64) h4_wait_vmcnt<(EB == 2 ? 2 * FI : 4 * FI) + 2>();
+        else h4_wait_vmcnt<(EB == 2 ? 2 * FI : 4 * FI)>();
+        first_tile = false;
         __builtin_amdgcn_s_barrier();
         convert_halo();
         H4_BN_FOLD(0, cur.n0);
@@ -681,6 +703,11 @@ int fb_try_conv3x3_halo4(const fb_conv_args* a, hipStream_t st) {
     p.n_tiles = n_pt * p.n_ct;
     p.magic_ct = h4_magic(p.n_ct);
     p.magic_wset = h4_magic(imgs_per_wset);
+    {
+        static const char* ph = getenv("FB_H4_PHASE");      // "mode,sleeps"
+        p.phase_mode = ph ? atoi(ph) : 0;
+        p.phase_sleeps = ph && strchr(ph, ',') ? atoi(strchr(ph, ',') + 1) : 2;
+    }
 #ifdef FB_H4_TRACE
     extern long long* g_h4_trace;
     p.trace = g_h4_trace;

@@ -181,6 +181,50 @@ def test_conv_dgrad(dtype, cin, cout, k, stride, hw, n, amode, monkeypatch):
         assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("cin,cout,hw,n", [(256, 1024, 14, 1024), (64, 256, 56, 256), (256, 512, 4, 12544), (128, 512, 28, 512)])
+def test_conv1x1_kernels_agree_at_full_size(cin, cout, hw, n, monkeypatch):
+    """The 1x1 kernels of round 5 at the sizes the benchmarks run (one ResNet-152 chunk group of 1024 images @14x14, the ResNet-18 shortcut of a 98-chunk
+    group; 50 000+ units per launch, every persistent workgroup walks tens of them): the pipelined streaming kernel, the round-3 streaming kernel and
+    the round-3 kernel with the addend as in-place 8-byte loads give the SAME BITS -- outputs, BatchNorm partial sums, input gradients with addend --
+    and the input gradient is linear in the addend's absence / presence (out(addend) - out(0) == addend wherever no rounding intervenes is too strong
+    for bf16; instead: out(addend = 0 tensor) == out(no addend))."""
+    lib = _lib()
+    torch.manual_seed(5)
+    dt = torch.bfloat16
+    x = torch.randn(n, hw, hw, cin, device="cuda").to(dt)
+    w = (torch.randn(cout, 1, cin, device="cuda") * 0.05).to(dt)
+    wt = (torch.randn(cin, 1, cout, device="cuda") * 0.05).to(dt)
+    dy = torch.randn(n, hw, hw, cout, device="cuda").to(dt)
+    add = torch.randn(n, hw, hw, cin, device="cuda").to(dt)
+    nblk = (n * hw * hw + 127) // 128
+
+    def run():
+        out, stat = torch.empty(n, hw, hw, cout, device="cuda", dtype=dt), torch.zeros(2, nblk, cout, device="cuda")
+        lib.conv2d(x, w, out, 1, 1, 1, 0, 0, stat_partial=stat)
+        dx0, dx1, dxz = (torch.empty(n, hw, hw, cin, device="cuda", dtype=dt) for _ in range(3))
+        if cin % 128 == 0:               # (input gradients onto 64 channels stay on the implicit GEMM)
+            lib.conv2d(dy, wt, dx0, 1, 1, 1, 0, 1)
+            lib.conv2d(dy, wt, dx1, 1, 1, 1, 0, 1, addend=add, addend_mode=1)
+            lib.conv2d(dy, wt, dxz, 1, 1, 1, 0, 1, addend=torch.zeros_like(add), addend_mode=1)
+        torch.cuda.synchronize()
+        return out, stat, dx0, dx1, dxz
+
+    new = run()
+    monkeypatch.setenv("FB_C1S_PIPE", "0")
+    old = run()
+    monkeypatch.setenv("FB_C1S_ADD_ASM", "0")
+    older = run()
+    for a, b, c in zip(new, old, older):
+        assert torch.equal(a, b) and torch.equal(b, c)
+    if cin % 128 == 0:
+        assert torch.equal(new[2], new[4])                                  # a zero addend changes nothing
+        assert not torch.equal(new[2], new[3])
+    # statistics of the whole launch against torch's own matmul of the same bf16 operands (fp32 accumulation)
+    ref = (x.reshape(-1, cin).float() @ w.reshape(cout, cin).float().t())
+    assert rel(new[1][0].sum(0), ref.sum(0)) < 2e-3 and rel(new[1][1].sum(0), (ref * ref).sum(0)) < 1e-4
+    assert rel(new[0].reshape(-1, cout).float(), ref) < tol(dt)
+
+
 @pytest.mark.parametrize("magnitude", [1.0, 3e-6, 4e4])
 @pytest.mark.parametrize("cin,cout,k,stride,hw,n", [(64, 64, 3, 1, 8, 8), (64, 128, 3, 2, 8, 8), (128, 256, 1, 1, 4, 16), (64, 64, 3, 1, 32, 2),
                                                    (128, 128, 3, 1, 16, 3), (256, 128, 3, 1, 8, 4), (512, 512, 3, 1, 4, 32), (96, 64, 3, 1, 6, 3)])
