@@ -376,6 +376,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+#ifndef FB_H4_SPLIT_PIPE
+#define FB_H4_SPLIT_PIPE 2                                  // 0: round 2-4 order; 1: next weight fragment's split under the MFMAs; 2: + next tap's pixel fragments
+#endif
+        constexpr bool XPIPE = is_split<T>::value && FB_H4_SPLIT_PIPE == 2;
+        split3_t spA[XPIPE ? 4 : 1], spB[XPIPE ? 4 : 1];    // XPIPE: the pixel pieces of the current / the next tap (roles alternate with the tap's parity)
         for (int cc = 0; cc < n_cc; ++cc) {
             const bool more = cc + 1 < n_cc;
             h4_static_for<0, 9>([&](auto uc) {
@@ -387,6 +392,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
                 else if (more) wt_issue(NBUF, cur, cc + 1, tap_of(U - 7));
                 else if (has_next) wt_issue(NBUF, nxt, 0, tap_of(U - 7));
                 else issued = false;
+                if constexpr (XPIPE) {
+                    // fp32 operands as three bf16 pieces (bf16x6), everything that can be split ahead IS split under MFMAs (round 5): while the 24 MFMAs of weight
+                    // fragment I run, the lane splits weight fragment I + 1 of this tap and pixel fragment I of the NEXT tap (the halo slice is resident for all
+                    // nine taps; the next tap's weights are not visible before the barrier that ends this one).  What stays exposed per tap: the first weight
+                    // fragment's read + split (and, at tap 0 of a slice, the four pixel fragments).  Reads are issued one block before their split, so the
+                    // `lgkmcnt(0)` in front of a block's VALU finds them landed.
+                    split3_t (&spc)[4] = (U & 1) ? spB : spA;
+                    split3_t (&spn)[4] = (U & 1) ? spA : spB;
+                    constexpr int UN = U + 1, AN = UN / 3, BN = UN % 3, PAN = CP ? UN : BN, PAC = CP ? U : B;
+                    uint4 wl[FI], wh[FI], pl[4], ph[4];
+                    if constexpr (U == 0) {
+                        h4_static_for<0, 4>([&](auto j) {
+                            constexpr int J = decltype(j)::value;
+                            pl[J] = h4_read16<(CP ? J * G::IMG_ROWS : A * PITCH + h4_frag_rows<W>(J)) * 128>(pa[PAC][0]);
+                            ph[J] = h4_read16<(CP ? J * G::IMG_ROWS : A * PITCH + h4_frag_rows<W>(J)) * 128>(pa[PAC][1]);
+                        });
+                        h4_wait_lgkmcnt<0>();
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) spc[j] = split_f32x8(pl[j], ph[j]);
+                    }
+                    auto rd_w = [&](auto ic) {
+                        constexpr int I = decltype(ic)::value;
+                        wl[I] = h4_read16<I * 2048 + BUF * WT_BYTES>(wa[0]); wh[I] = h4_read16<I * 2048 + BUF * WT_BYTES>(wa[1]);
+                    };
+                    auto rd_pn = [&](auto jc) {
+                        constexpr int J = decltype(jc)::value;
+                        pl[J] = h4_read16<(CP ? J * G::IMG_ROWS : AN * PITCH + h4_frag_rows<W>(J)) * 128>(pa[PAN % (CP ? 9 : 3)][0]);
+                        ph[J] = h4_read16<(CP ? J * G::IMG_ROWS : AN * PITCH + h4_frag_rows<W>(J)) * 128>(pa[PAN % (CP ? 9 : 3)][1]);
+                    };
+                    rd_w(std::integral_constant<int, 0>{});
+                    rd_w(std::integral_constant<int, 1>{});
+                    if constexpr (U < 8) rd_pn(std::integral_constant<int, 0>{});
+                    h4_wait_lgkmcnt<0>();
+                    split3_t sw = split_f32x8(wl[0], wh[0]);
+                    h4_static_for<0, FI>([&](auto ic) {
+                        constexpr int I = decltype(ic)::value;
+                        if constexpr (I + 2 < FI) rd_w(std::integral_constant<int, I + 2>{});            // split one block later
+                        if constexpr (U < 8 && I + 1 < 4) rd_pn(std::integral_constant<int, I + 1>{});
+                        split3_t swn = sw;
+                        if constexpr (I + 1 < FI) swn = split_f32x8(wl[I + 1], wh[I + 1]);
+                        if constexpr (U < 8) spn[I] = split_f32x8(pl[I], ph[I]);
+                        if constexpr (I + 1 < FI || U < 8) mma_split6_row_mix<4, (I + 1 < FI && U < 8) ? 4 : 2>(sw, spc, acc[I]);
+                        else mma_split6_row<4>(sw, spc, acc[I]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        h4_wait_lgkmcnt<0>();
+                        sw = swn;
+                    });
+                } else {
                 uint4 wf0[FI], pf0[4], wf1[FI], pf1[4];
                 h4_static_for<0, FI>([&](auto i) { wf0[decltype(i)::value] = h4_read16<decltype(i)::value * 2048 + BUF * WT_BYTES>(wa[0]); });
                 constexpr int PA = CP ? U : B;                 // which fragment address; the fragment / vertical-tap offset is an immediate
@@ -410,9 +463,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
                     split3_t sp[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) sp[j] = split_f32x8(pf0[j], pf1[j]);
-#ifndef FB_H4_SPLIT_PIPE
-#define FB_H4_SPLIT_PIPE 1
-#endif
 #if FB_H4_SPLIT_PIPE
                     // One weight fragment at a time, four zero-started chains in flight -- and the split of fragment i + 1 (44 VALU) threaded through the 24
                     // MFMAs of fragment i: with the split in front of its MFMAs (round 2-4) the two waves of a SIMD, which leave the per-tap barrier together,
@@ -471,6 +521,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
                     for (int j = 0; j < 4; ++j) acc[i][j] = mma_chunk<T>(wf1[i], pf1[j], acc[i][j]);
                 }
                 }
+                }   // (!XPIPE)
                 if constexpr (U == 8) {
                     __builtin_amdgcn_s_barrier();         // every wave is done with this halo slice
                     if (more) {
