@@ -381,6 +381,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
 #endif
         constexpr bool XPIPE = is_split<T>::value && FB_H4_SPLIT_PIPE == 2;
         split3_t spA[XPIPE ? 4 : 1], spB[XPIPE ? 4 : 1];    // XPIPE: the pixel pieces of the current / the next tap (roles alternate with the tap's parity)
+#ifndef FB_H4_PF_PIPE
+#define FB_H4_PF_PIPE 0                                     // bf16: the next tap's pixel fragments are read before the barrier that ends this tap (A/B build switch; measured without effect)
+#endif
+        // PFP (bf16, 64-channel tiles): the halo slice is resident for all nine taps, so the pixel fragments of tap U + 1 are requested at the END of tap U -- their LDS
+        // latency runs under the end-of-tap wait and barrier instead of in front of the next tap's first MFMA (the weight fragments cannot: the next
+        // tap's weights are only guaranteed behind that barrier).  32 more registers (two sets, alternating with the tap's parity).  Built and measured in
+        // round 5 (same bits): 12 544 images, us, with / without: 1018 / 1009, 1012 / 1015 (16 x 16 forward), 768 / 759, 761 / 768 (8 x 8), 705 / 709, 707 / 701 (4 x 4);
+        // headline step 228.9 / 229.4, 228.7 / 228.1 ms: nothing -- the LDS latency at a tap's start is already covered by the CU's other workgroup.  Off.
+        constexpr bool PFP = std::is_same<T, bf16_tag>::value && FI == 4 && FB_H4_PF_PIPE != 0;
+        uint4 pfc0[PFP ? 2 : 1][4], pfc1[PFP ? 2 : 1][4];
         for (int cc = 0; cc < n_cc; ++cc) {
             const bool more = cc + 1 < n_cc;
             h4_static_for<0, 9>([&](auto uc) {
@@ -443,9 +453,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
                 uint4 wf0[FI], pf0[4], wf1[FI], pf1[4];
                 h4_static_for<0, FI>([&](auto i) { wf0[decltype(i)::value] = h4_read16<decltype(i)::value * 2048 + BUF * WT_BYTES>(wa[0]); });
                 constexpr int PA = CP ? U : B;                 // which fragment address; the fragment / vertical-tap offset is an immediate
-                h4_static_for<0, 4>([&](auto j) { pf0[decltype(j)::value] = h4_read16<(CP ? decltype(j)::value * G::IMG_ROWS : A * PITCH + h4_frag_rows<W>(decltype(j)::value)) * 128>(pa[PA][0]); });
+                constexpr bool HAVE_PF = PFP && U > 0;          // this tap's pixel fragments were requested at the end of the previous tap
+                if constexpr (!HAVE_PF)
+                    h4_static_for<0, 4>([&](auto j) { pf0[decltype(j)::value] = h4_read16<(CP ? decltype(j)::value * G::IMG_ROWS : A * PITCH + h4_frag_rows<W>(decltype(j)::value)) * 128>(pa[PA][0]); });
                 h4_static_for<0, FI>([&](auto i) { wf1[decltype(i)::value] = h4_read16<decltype(i)::value * 2048 + BUF * WT_BYTES>(wa[1]); });
-                h4_static_for<0, 4>([&](auto j) { pf1[decltype(j)::value] = h4_read16<(CP ? decltype(j)::value * G::IMG_ROWS : A * PITCH + h4_frag_rows<W>(decltype(j)::value)) * 128>(pa[PA][1]); });
+                if constexpr (!HAVE_PF)
+                    h4_static_for<0, 4>([&](auto j) { pf1[decltype(j)::value] = h4_read16<(CP ? decltype(j)::value * G::IMG_ROWS : A * PITCH + h4_frag_rows<W>(decltype(j)::value)) * 128>(pa[PA][1]); });
+                if constexpr (HAVE_PF) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { pf0[j] = pfc0[PFP ? (U & 1) : 0][j]; pf1[j] = pfc1[PFP ? (U & 1) : 0][j]; }
+                }
                 if constexpr (is_hsplit<T>::value) {     // fp32 operands as two scaled fp16 pieces each, three MFMAs per fragment pair (common.h)
                     h4_wait_lgkmcnt<0>();
                     split2h_t sp[4];                       // both reads of a fragment are operands already: the halo was converted in place
@@ -509,7 +526,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
                 } else
 #endif
                 {
-                h4_wait_lgkmcnt<FI + 4>();
+                // (LDS returns in order) first half landed: with the pixel fragments requested a tap ago only the second half's FI weight reads may be outstanding
+                if constexpr (HAVE_PF) h4_wait_lgkmcnt<FI>(); else h4_wait_lgkmcnt<FI + 4>();
 #pragma unroll
                 for (int i = 0; i < FI; ++i)
 #pragma unroll
@@ -519,6 +537,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
                 for (int i = 0; i < FI; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = mma_chunk<T>(wf1[i], pf1[j], acc[i][j]);
+                if constexpr (PFP && U < 8) {                  // the next tap's pixel fragments, into the other register set
+                    constexpr int UN = U + 1, AN = UN / 3, PAN = CP ? UN : UN % 3;
+                    h4_static_for<0, 4>([&](auto j) {
+                        constexpr int J = decltype(j)::value;
+                        pfc0[PFP ? (UN & 1) : 0][J] = h4_read16<(CP ? J * G::IMG_ROWS : AN * PITCH + h4_frag_rows<W>(J)) * 128>(pa[PAN][0]);
+                        pfc1[PFP ? (UN & 1) : 0][J] = h4_read16<(CP ? J * G::IMG_ROWS : AN * PITCH + h4_frag_rows<W>(J)) * 128>(pa[PAN][1]);
+                    });
+                }
                 }
                 }
                 }   // (!XPIPE)

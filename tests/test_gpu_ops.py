@@ -201,7 +201,7 @@ def test_conv1x1_kernels_agree_at_full_size(cin, cout, hw, n, monkeypatch):
     def run():
         out, stat = torch.empty(n, hw, hw, cout, device="cuda", dtype=dt), torch.zeros(2, nblk, cout, device="cuda")
         lib.conv2d(x, w, out, 1, 1, 1, 0, 0, stat_partial=stat)
-        dx0, dx1, dxz = (torch.empty(n, hw, hw, cin, device="cuda", dtype=dt) for _ in range(3))
+        dx0, dx1, dxz = (torch.zeros(n, hw, hw, cin, device="cuda", dtype=dt) for _ in range(3))
         if cin % 128 == 0:               # (input gradients onto 64 channels stay on the implicit GEMM)
             lib.conv2d(dy, wt, dx0, 1, 1, 1, 0, 1)
             lib.conv2d(dy, wt, dx1, 1, 1, 1, 0, 1, addend=add, addend_mode=1)
