@@ -70,15 +70,17 @@ __global__ void maxpool3s2_fwd_kernel(const uint4* __restrict__ x, uint4* __rest
 // positions 4, 5, 7, 8; (a, b+1): 3, 6; (a+1, b): 1, 2; (a+1, b+1): 0), so a window's argmax is computed once per quad instead of once per
 // pixel it covers (the per-pixel gather walked 2.25 windows x 9 loads per pixel with index bookkeeping: 4.2 ms for 1024 images of the
 // ImageNet stem, 7x the 0.6 ms its 3.6 GB take at the HBM roofline).  Sums are added in the per-pixel kernel's window order.
-template <typename T>
+// IDX: the type of the flat item index -- 32-bit where the launch has fewer than 2^31 items (three 64-bit divisions by run-time values per item
+// are several hundred instructions on this hardware)
+template <typename T, typename IDX>
 __global__ void maxpool3s2_bwd_kernel(const uint4* __restrict__ x, const uint4* __restrict__ dy, uint4* __restrict__ dx, int n_img, int H,
                                       int W, int cvec) {
     constexpr int V = ET<T>::VEC;
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-    const long long total = (long long)n_img * Ho * Wo * cvec;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int cv = (int)(i % cvec); long long r = i / cvec;
-        const int b = (int)(r % Wo); r /= Wo; const int a = (int)(r % Ho); const long long n = r / Ho;
+    const IDX total = (IDX)n_img * Ho * Wo * cvec;
+    for (IDX i = (IDX)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (IDX)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % (IDX)cvec); IDX r = i / (IDX)cvec;
+        const int b = (int)(r % (IDX)Wo); r /= (IDX)Wo; const int a = (int)(r % (IDX)Ho); const long long n = (long long)(r / (IDX)Ho);
         float acc[4][V];                              // quad pixels (0,0), (0,1), (1,0), (1,1)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -144,8 +146,14 @@ extern "C" int fb_maxpool3s2_bwd(const void* x, const void* dy, void* dx, int32_
     const int V = dtype == FB_F32 ? 4 : 8, cvec = C / V;
     const long long total = (long long)n_img * ((H + 1) / 2) * ((W + 1) / 2) * cvec;        // one thread per 2x2 input quad and channel vector
     const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    if (dtype == FB_F32) hipLaunchKernelGGL((maxpool3s2_bwd_kernel<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (const uint4*)dy, (uint4*)dx, n_img, H, W, cvec);
-    else hipLaunchKernelGGL((maxpool3s2_bwd_kernel<bf16_tag>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (const uint4*)dy, (uint4*)dx, n_img, H, W, cvec);
+    const bool small = total + 65536LL * 256 < (1LL << 32) && !(getenv("FB_MAXPOOL_IDX64") != nullptr);
+    if (dtype == FB_F32) {
+        if (small) hipLaunchKernelGGL((maxpool3s2_bwd_kernel<float, unsigned>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (const uint4*)dy, (uint4*)dx, n_img, H, W, cvec);
+        else hipLaunchKernelGGL((maxpool3s2_bwd_kernel<float, long long>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (const uint4*)dy, (uint4*)dx, n_img, H, W, cvec);
+    } else {
+        if (small) hipLaunchKernelGGL((maxpool3s2_bwd_kernel<bf16_tag, unsigned>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (const uint4*)dy, (uint4*)dx, n_img, H, W, cvec);
+        else hipLaunchKernelGGL((maxpool3s2_bwd_kernel<bf16_tag, long long>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (const uint4*)dy, (uint4*)dx, n_img, H, W, cvec);
+    }
     FB_CHECK_LAUNCH("fb_maxpool3s2_bwd");
     return FB_OK;
 }
