@@ -183,8 +183,8 @@ __global__ __launch_bounds__(512) void conv1x1_gemm_kernel(const G1Params p) {
             for (int i = 0; i < FI; ++i) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { ssum[i][r] = row16_sum(ssum[i][r]); ssq[i][r] = row16_sum(ssq[i][r]); }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(g1_u32x4, (g1_f32x4){ssum[i][0], ssum[i][1], ssum[i][2], ssum[i][3]}), rsT, voffT + i * 64, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(g1_u32x4, (g1_f32x4){ssq[i][0], ssq[i][1], ssq[i][2], ssq[i][3]}), rsT, voffT + i * 64, plane, 0);
+                { const g1_u32x4 sv = __builtin_bit_cast(g1_u32x4, (g1_f32x4){ssum[i][0], ssum[i][1], ssum[i][2], ssum[i][3]}); __builtin_amdgcn_raw_buffer_store_b128(sv, rsT, voffT + i * 64, 0, 0); store_b128_guard(sv); }
+                { const g1_u32x4 sv = __builtin_bit_cast(g1_u32x4, (g1_f32x4){ssq[i][0], ssq[i][1], ssq[i][2], ssq[i][3]}); __builtin_amdgcn_raw_buffer_store_b128(sv, rsT, voffT + i * 64, plane, 0); store_b128_guard(sv); }
             }
         }
         after_epilogue = 2;

@@ -291,8 +291,8 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_pipe_kernel(const P1Params p)
             const int plane = p.n_mblocks * p.Cd * 4;
 #pragma unroll
             for (int f = 0; f < FI; ++f) {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p1_u32x4, (p1_f32x4){ssum[f][0], ssum[f][1], ssum[f][2], ssum[f][3]}), rsT, voffT + f * 64, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p1_u32x4, (p1_f32x4){ssq[f][0], ssq[f][1], ssq[f][2], ssq[f][3]}), rsT, voffT + f * 64, plane, 0);
+                { const p1_u32x4 sv = __builtin_bit_cast(p1_u32x4, (p1_f32x4){ssum[f][0], ssum[f][1], ssum[f][2], ssum[f][3]}); __builtin_amdgcn_raw_buffer_store_b128(sv, rsT, voffT + f * 64, 0, 0); store_b128_guard(sv); }
+                { const p1_u32x4 sv = __builtin_bit_cast(p1_u32x4, (p1_f32x4){ssq[f][0], ssq[f][1], ssq[f][2], ssq[f][3]}); __builtin_amdgcn_raw_buffer_store_b128(sv, rsT, voffT + f * 64, plane, 0); store_b128_guard(sv); }
             }
         }
         if constexpr (LATE) {
@@ -389,8 +389,8 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_pipe_kernel(const P1Params p)
             for (int f = 0; f < FI; ++f) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { ssum[f][r] = row16_sum(ssum[f][r]); ssq[f][r] = row16_sum(ssq[f][r]); }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p1_u32x4, (p1_f32x4){ssum[f][0], ssum[f][1], ssum[f][2], ssum[f][3]}), rsT, voffT + f * 64, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p1_u32x4, (p1_f32x4){ssq[f][0], ssq[f][1], ssq[f][2], ssq[f][3]}), rsT, voffT + f * 64, plane, 0);
+                { const p1_u32x4 sv = __builtin_bit_cast(p1_u32x4, (p1_f32x4){ssum[f][0], ssum[f][1], ssum[f][2], ssum[f][3]}); __builtin_amdgcn_raw_buffer_store_b128(sv, rsT, voffT + f * 64, 0, 0); store_b128_guard(sv); }
+                { const p1_u32x4 sv = __builtin_bit_cast(p1_u32x4, (p1_f32x4){ssq[f][0], ssq[f][1], ssq[f][2], ssq[f][3]}); __builtin_amdgcn_raw_buffer_store_b128(sv, rsT, voffT + f * 64, plane, 0); store_b128_guard(sv); }
             }
         }
     }
