@@ -74,8 +74,13 @@ constexpr unsigned P1_OOB = 0x80000000u;
 struct P1Params {
     const char* src; const char* wgt; char* dst; const char* addend; float* stat;
     long long M; int Cd; int n_co; int n_workers; int n_mblocks;
-    int exp;                             // timing experiments (FB_C1P_EXP, wrong results): 1 = every store into the first 256 rows, 2 = every LDS-DMA round from the first 256 rows
+    int exp;                             // timing experiments, only in builds with -DFB_C1P_EXPERIMENTS (WRONG results): FB_C1P_EXP & 1 = every store into the first 256 rows, & 2 = every LDS-DMA round from the first 256 rows
 };
+#ifdef FB_C1P_EXPERIMENTS
+#define P1_EXP(p) ((p).exp)
+#else
+#define P1_EXP(p) 0
+#endif
 }  // namespace
 
 // K input channels; NWC waves share the channels of the workgroup (32 each), NW / NWC the pixels of a sub-tile; STAT: BatchNorm partial sums
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_pipe_kernel(const P1Params p)
     }
     auto store_group = [&](const p1_u32x4 (&o)[JG], const long long m0) {
         // (no group: m0 < 0 -> an empty descriptor at the tensor's base: nothing is stored)
-        const __amdgpu_buffer_rsrc_t rsD = p1_rsrc(p.dst + (m0 < 0 ? 0 : ((p.exp & 1) ? (m0 & 255) : m0)) * row_b, m0 < 0 ? 0 : p.M - m0, 64, row_b);
+        const __amdgpu_buffer_rsrc_t rsD = p1_rsrc(p.dst + (m0 < 0 ? 0 : ((P1_EXP(p) & 1) ? (m0 & 255) : m0)) * row_b, m0 < 0 ? 0 : p.M - m0, 64, row_b);
 #pragma unroll
         for (int jj = 0; jj < JG; ++jj) {
             __builtin_amdgcn_raw_buffer_store_b128(o[jj], rsD, voffS[jj], 0, 2);
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_pipe_kernel(const P1Params p)
 #pragma unroll
                 for (int q = 0; q < NSLOT; ++q) store_group(outP[q], m0_out[q]);
             }
-            rs_dma = p1_rsrc(p.src + ((p.exp & 2) ? (m0_next_dma & 255) : m0_next_dma) * (K * 2), p.M - m0_next_dma, PXT, K * 2);
+            rs_dma = p1_rsrc(p.src + ((P1_EXP(p) & 2) ? (m0_next_dma & 255) : m0_next_dma) * (K * 2), p.M - m0_next_dma, PXT, K * 2);
             if constexpr (!SPREAD) {
 #pragma unroll
                 for (int i = 0; i < NDMA; ++i) issue_piece(rs_dma, i, stage ^ 1);
@@ -444,7 +449,11 @@ int fb_try_conv1x1_pipe(const fb_conv_args* a, hipStream_t st) {
     if (workers < 1) workers = 1;
     if (workers > n_units) workers = n_units;
     p.n_workers = (int)workers;
+#ifdef FB_C1P_EXPERIMENTS
     p.exp = getenv("FB_C1P_EXP") ? atoi(getenv("FB_C1P_EXP")) : 0;
+#else
+    p.exp = 0;
+#endif
     const int grid = p.n_workers * p.n_co;
     const bool stat = a->stat_partial != nullptr, add = a->addend != nullptr;
     if (nw == 8) {
