@@ -74,7 +74,7 @@ constexpr unsigned P1_OOB = 0x80000000u;
 struct P1Params {
     const char* src; const char* wgt; char* dst; const char* addend; float* stat;
     long long M; int Cd; int n_co; int n_workers; int n_mblocks;
-    int exp;                             // timing experiments, only in builds with -DFB_C1P_EXPERIMENTS (WRONG results): FB_C1P_EXP & 1 = every store into the first 256 rows, & 2 = every LDS-DMA round from the first 256 rows
+    int exp;                             // timing experiments, only in builds with -DFB_C1P_EXPERIMENTS (WRONG results): FB_C1P_EXP & 1 = every store into the first 256 rows, & 2 = every LDS-DMA round from the first 256 rows, & 4 = full 128-byte lines per store instruction (pixel pairs)
 };
 #ifdef FB_C1P_EXPERIMENTS
 #define P1_EXP(p) ((p).exp)
@@ -133,6 +133,14 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_pipe_kernel(const P1Params p)
     unsigned voffS[JG];
 #pragma unroll
     for (int jj = 0; jj < JG; ++jj) voffS[jj] = (unsigned)((jj * 16 + col) * row_b + (co0 + (g & 1) * 16 + (g >> 1) * 8) * 2);
+#ifdef FB_C1P_EXPERIMENTS
+    if (P1_EXP(p) & 4)                               // (timing experiment: the lanes of a pixel pair write the two halves of ONE 128-byte line)
+#pragma unroll
+        for (int jj = 0; jj < JG; ++jj) voffS[jj] = (unsigned)(((jj * 16 + col) & ~1) * row_b + ((co0 / 32) * 2 + (col & 1)) * 64 + ((g & 1) * 16 + (g >> 1) * 8) * 2);
+    if (P1_EXP(p) & 8)                               // (the two halves of a line from two CONSECUTIVE store instructions of the same wave)
+#pragma unroll
+        for (int jj = 0; jj < JG; ++jj) voffS[jj] = (unsigned)(((jj >> 1) * 32 + col * 2) * row_b + ((co0 / 32) * 2 + (jj & 1)) * 64 + ((g & 1) * 16 + (g >> 1) * 8) * 2);
+#endif
     // statistics: lanes col == 0 store 4 channels (16 bytes) of each of the two channel fragments
     const unsigned voffT = col == 0 ? (unsigned)((co0 + g * 4) * 4) : P1_OOB;
 
