@@ -39,19 +39,32 @@ __device__ __forceinline__ int g1_xcd_remap(int b, int n) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 constexpr unsigned G1_OOB = 0x80000000u;
-constexpr int G1_BM = 256, G1_BN = 128, G1_STAGE = (G1_BM + G1_BN) * 128, G1_NSTAGE = 3, G1_NDMA = (G1_BM + G1_BN) / 8 / 8;   // 6 LDS-DMA pieces per wave and K-step
+#ifndef G1_STAGGER
+#define G1_STAGGER 1         /* the two waves of a SIMD issue their LDS-DMA pieces at different points of a step (A/B builds: tools/build_variant.py) */
+#endif
+// 256 pixels x 256 channels per tile: (256 + 256) rows of 128 bytes per K-step = 64 KiB through the CU's load path (64 bytes / clock) per 2048 matrix-pipe
+// cycles -- half the path's capacity.  128 x 128 tiles (the implicit GEMM) need ALL of it, 256 x 128 three quarters: tools/l2_probe.hip.
+constexpr int G1_BM = 256, G1_BN = 256, G1_A_STAGE = G1_BM * 128, G1_B_STAGE = G1_BN * 128, G1_NA = 3, G1_NB = 2;
+constexpr int G1_PA = G1_BM / 8 / 8, G1_PB = G1_BN / 8 / 8;         // LDS-DMA pieces (8 rows) per wave and K-step: pixels / filter rows
 
 struct G1Params {
     const char* src; const char* wgt; char* dst; float* stat;
     long long M; int K; int Cd; int n_co; int n_tiles; int n_workers; int n_mblocks;
+    int exp;   // timing experiments, only in builds with -DFB_C1G_EXPERIMENTS (WRONG results): FB_C1G_EXP & 1 = pixel rows from the first 512 rows (L2), & 2 = stores into the first 256 rows, & 4 = no MFMAs, & 8 = no fragment reads either, & 16 = no LDS-DMA (stale stages are multiplied)
 };
+#ifdef FB_C1G_EXPERIMENTS
+#define G1_EXP(p) ((p).exp)
+#else
+#define G1_EXP(p) 0
+#endif
 }  // namespace
 
 template <bool STAT>
 __global__ __launch_bounds__(512) void conv1x1_gemm_kernel(const G1Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int FI = 2, FJ = 8, NST = FJ + (STAT ? 4 : 0);      // stores of one tile's epilogue per wave
-    __shared__ __attribute__((aligned(16))) char lds[G1_NSTAGE * G1_STAGE];
+    constexpr int FI = 4, FJ = 8;                                   // a wave: 64 channels x 128 pixels (32 accumulator fragments)
+    constexpr int NST = 2 * FJ + (STAT ? 2 * FI : 0);               // stores of one tile's epilogue per wave
+    __shared__ __attribute__((aligned(16))) char lds[G1_NA * G1_A_STAGE + G1_NB * G1_B_STAGE];   // 160 KiB: pixel ring (3 stages), filter ring (2)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -62,65 +75,100 @@ __global__ __launch_bounds__(512) void conv1x1_gemm_kernel(const G1Params p) {
     const int rowA_b = p.K * 2, row_b = p.Cd * 2;
 
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
-    // LDS-DMA piece q = 6 wave + i: rows 8 q .. 8 q + 7 of the stage (pixels first, then filter rows); lane -> row (lane >> 3), logical chunk (lane & 7) ^ (row & 7)
+    // LDS-DMA piece q = 4 wave + i of a ring stage: rows 8 q .. 8 q + 7; lane -> row (lane >> 3), logical chunk (lane & 7) ^ (row & 7)
     const unsigned dma_lane = (unsigned)((lane >> 3) * rowA_b + (((lane & 7) ^ (lane >> 3)) * 16));
     // fragment reads: row (16 j + col) of the wave's pixel half / (16 i + col) of its channel quarter, logical chunk g + 4 h
     unsigned pa[2], pb[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         pa[h] = lds0 + (wp * 128 + col) * 128 + (((g + 4 * h) ^ (col & 7)) * 16);
-        pb[h] = lds0 + (G1_BM + wc * 32 + col) * 128 + (((g + 4 * h) ^ (col & 7)) * 16);
+        pb[h] = lds0 + G1_NA * G1_A_STAGE + (wc * 64 + col) * 128 + (((g + 4 * h) ^ (col & 7)) * 16);
     }
-    // stores: pixel wp * 128 + 16 j + col of the tile, 8 channels wc * 32 + {0, 16, 8, 24}[g] .. + 7 (after the lane-row exchange)
-    const unsigned voffS = (unsigned)((wp * 128 + col) * row_b + (wc * 32 + (g & 1) * 16 + (g >> 1) * 8) * 2);
-    const unsigned voffT = col == 0 ? (unsigned)((wc * 32 + g * 4) * 4) : G1_OOB;
+    // stores: after the lane-row exchange of a fragment pair and the col / col ^ 8 exchange (conv1x1_k32.hip) a store instruction writes the wave's 64
+    // channels = one whole 128-byte line of 8 pixels: pixel wp * 128 + 16 j + (col & 7) [+ 8], channels wc * 64 + (col >> 3) * 32 + {0, 16, 8, 24}[g] .. + 7
+    const unsigned voffS = (unsigned)((wp * 128 + (col & 7)) * row_b + (wc * 64 + (col >> 3) * 32 + (g & 1) * 16 + (g >> 1) * 8) * 2);
+    const unsigned voffT = col == 0 ? (unsigned)((wc * 64 + g * 4) * 4) : G1_OOB;
 
     const int n_my = worker < p.n_tiles ? (p.n_tiles - worker + p.n_workers - 1) / p.n_workers : 0;      // tiles of this workgroup
     if (n_my == 0) return;
 
-    // the LDS-DMA round of step (tile index ti of this workgroup, K-step ks); ti >= n_my: empty descriptors (zeros into a stage nobody multiplies)
-    auto issue_round = [&](const int ti, const int ks, const int stage) {
+    // LDS-DMA rounds of step (tile index ti of this workgroup, K-step ks); ti >= n_my: empty descriptors (zeros into a stage nobody multiplies)
+    auto issue_a = [&](const int ti, const int ks, const int stage) {
         const int tile = worker + ti * p.n_workers;
         const bool live = ti < n_my;
-        const int mt = live ? tile / p.n_co : 0, co = live ? tile - mt * p.n_co : 0;
+        const int mt = live ? tile / p.n_co : 0;
         const long long m0 = (long long)mt * G1_BM;
         long long rows = p.M - m0;
         rows = !live || rows < 0 ? 0 : (rows > G1_BM ? G1_BM : rows);
-        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.src + m0 * rowA_b), 0, (int)(rows * rowA_b), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.wgt + (long long)co * G1_BN * rowA_b), 0, live ? G1_BN * rowA_b : 0, 0x00020000);
-        char* base = lds + stage * G1_STAGE;
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.src + ((G1_EXP(p) & 1) ? (m0 & 511) : m0) * rowA_b), 0, (int)(rows * rowA_b), 0x00020000);
+        char* base = lds + stage * G1_A_STAGE;
 #pragma unroll
-        for (int i = 0; i < G1_NDMA; ++i) {
-            const int q = wave * G1_NDMA + i;                       // wave-uniform
-            __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(base + q * 1024);
-            if (q < G1_BM / 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, dst, 16, dma_lane + (unsigned)(q * 8 * rowA_b), ks * 128, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, dst, 16, dma_lane + (unsigned)((q - G1_BM / 8) * 8 * rowA_b), ks * 128, 0, 0);
+        for (int i = 0; i < G1_PA; ++i) {
+            const int q = wave * G1_PA + i;                         // wave-uniform
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + q * 1024), 16, dma_lane + (unsigned)(q * 8 * rowA_b), ks * 128, 0, 0);
+        }
+    };
+    auto issue_b = [&](const int ti, const int ks, const int stage) {
+        const int tile = worker + ti * p.n_workers;
+        const bool live = ti < n_my;
+        const int co = live ? tile % p.n_co : 0;
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.wgt + (long long)co * G1_BN * rowA_b), 0, live ? G1_BN * rowA_b : 0, 0x00020000);
+        char* base = lds + G1_NA * G1_A_STAGE + stage * G1_B_STAGE;
+#pragma unroll
+        for (int i = 0; i < G1_PB; ++i) {
+            const int q = wave * G1_PB + i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(base + q * 1024), 16, dma_lane + (unsigned)(q * 8 * rowA_b), ks * 128, 0, 0);
         }
     };
 
     f32x4_t acc[FI][FJ];
-    // prologue: the rounds of steps 0 and 1 (KS >= 8: both belong to the first tile)
-    int dma_ti = 0, dma_ks = 0;                          // the next round to issue: always two steps ahead of the step that is multiplied
-    issue_round(0, 0, 0);
-    issue_round(0, 1, 1);
-    dma_ks = 2;
-    int stage = 0;
-    int after_epilogue = 0;                              // steps whose wait must still count the previous tile's stores (they sit between two rounds in the queue)
+    // Queue order (per wave, all counts follow from it): step t issues [filter round t + 1] [pixel round t + 2]; the top of step t needs pixel round t (issued
+    // in step t - 2) and filter round t (step t - 1) and leaves pixel round t + 1 (step t - 1, BEHIND filter round t) in flight: vmcnt(G1_PA).
+    // Prologue: [pixels 0] [filter 0] [pixels 1]  (KS >= 8: all of the first tile)
+    issue_a(0, 0, 0);
+    issue_b(0, 0, 0);
+    issue_a(0, 1, 1);
+    int b_ti = 0, b_ks = 1, a_ti = 0, a_ks = 2;          // the next rounds to issue
+    int sa = 0, sb = 0;                                  // ring stages of the step that is multiplied
+    int after_epilogue = 0;                              // the first step of a tile: the previous tile's stores sit behind pixel round 1 in the queue (one step: the
+                                                         // second step's filter round was issued behind them, so its wait retires them anyway)
     for (int ti = 0; ti < n_my; ++ti) {
         for (int ks = 0; ks < KS; ++ks) {
-            // this step's round has landed: younger are the next step's round (and, behind an epilogue, its stores)
-            if (after_epilogue > 0) { g1_wait_vmcnt<G1_NDMA + NST>(); --after_epilogue; } else g1_wait_vmcnt<G1_NDMA>();
-            __builtin_amdgcn_s_barrier();                // ... everybody's share; everybody has left the stage the next round goes into (step t - 1's)
-            issue_round(dma_ti, dma_ks, stage == 0 ? 2 : stage - 1);
-            if (++dma_ks == KS) { dma_ks = 0; ++dma_ti; }
-            const unsigned so = stage * G1_STAGE;
+            if (after_epilogue > 0) { g1_wait_vmcnt<G1_PA + NST>(); --after_epilogue; } else g1_wait_vmcnt<G1_PA>();
+            __builtin_amdgcn_s_barrier();                // ... everybody's share has landed; everybody has left the stages the next rounds go into
+            // An LDS-DMA instruction holds its wave at issue while the CU's load path works the queue off (64 of them per step: ~2000 cycles with all eight
+            // waves issuing together and the matrix pipe idle -- as long as the step's MFMAs).  So the two waves of a SIMD take turns: waves 0-3 (one per
+            // SIMD) issue their pieces here, waves 4-7 between the two halves of their MFMAs -- while one is held, the other one multiplies.
+            const bool early = !G1_STAGGER || wave < 4;
+            if (early) {
+                issue_b((G1_EXP(p) & 16) ? n_my : b_ti, b_ks, sb ^ 1);
+                issue_a((G1_EXP(p) & 16) ? n_my : a_ti, a_ks, sa == 0 ? 2 : sa - 1);
+            }
+#ifdef FB_C1G_EXPERIMENTS
+            if (G1_EXP(p) & 8) { if (ks == 0) for (int i = 0; i < FI; ++i) for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; sa = sa == 2 ? 0 : sa + 1; sb ^= 1; if (!early) { issue_b(b_ti, b_ks, sb); issue_a(a_ti, a_ks, sa == 2 ? 0 : sa + 1); } if (++b_ks == KS) { b_ks = 0; ++b_ti; } if (++a_ks == KS) { a_ks = 0; ++a_ti; } continue; }
+#endif
+            const unsigned soa = sa * G1_A_STAGE, sob = sb * G1_B_STAGE;
             uint4 wb[2][FI], px[2][FJ];
             g1_static_for<0, 2>([&](auto hc) {
                 constexpr int h = decltype(hc)::value;
-                g1_static_for<0, FI>([&](auto ic) { constexpr int i = decltype(ic)::value; wb[h][i] = g1_lds_read16<i * 2048>(pb[h] + so); });
-                g1_static_for<0, FJ>([&](auto jc) { constexpr int j = decltype(jc)::value; px[h][j] = g1_lds_read16<j * 2048>(pa[h] + so); });
+                g1_static_for<0, FI>([&](auto ic) { constexpr int i = decltype(ic)::value; wb[h][i] = g1_lds_read16<i * 2048>(pb[h] + sob); });
+                g1_static_for<0, FJ>([&](auto jc) { constexpr int j = decltype(jc)::value; px[h][j] = g1_lds_read16<j * 2048>(pa[h] + soa); });
             });
             g1_wait_lgkmcnt<FI + FJ>();
+#ifdef FB_C1G_EXPERIMENTS
+            if (G1_EXP(p) & 4) {
+                g1_wait_lgkmcnt<0>();
+                if (ks == 0) for (int i = 0; i < FI; ++i) for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                unsigned x = 0;
+                for (int h = 0; h < 2; ++h) { for (int i = 0; i < FI; ++i) x ^= wb[h][i].x ^ wb[h][i].w; for (int j = 0; j < FJ; ++j) x ^= px[h][j].y ^ px[h][j].z; }
+                acc[0][0][0] += __uint_as_float(x);
+                if (!early) { issue_b(b_ti, b_ks, sb ^ 1); issue_a(a_ti, a_ks, sa == 0 ? 2 : sa - 1); }
+                if (++b_ks == KS) { b_ks = 0; ++b_ti; }
+                if (++a_ks == KS) { a_ks = 0; ++a_ti; }
+                sa = sa == 2 ? 0 : sa + 1; sb ^= 1;
+                continue;
+            }
+#endif
             if (ks == 0) {
 #pragma unroll
                 for (int i = 0; i < FI; ++i)
@@ -134,22 +182,32 @@ __global__ __launch_bounds__(512) void conv1x1_gemm_kernel(const G1Params p) {
                     for (int j = 0; j < FJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wb[0][i]), __builtin_bit_cast(bf16x8_t, px[0][j]), acc[i][j], 0, 0, 0);
             }
+            if (!early) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue_b((G1_EXP(p) & 16) ? n_my : b_ti, b_ks, sb ^ 1);
+                issue_a((G1_EXP(p) & 16) ? n_my : a_ti, a_ks, sa == 0 ? 2 : sa - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (++b_ks == KS) { b_ks = 0; ++b_ti; }
+            if (++a_ks == KS) { a_ks = 0; ++a_ti; }
             g1_wait_lgkmcnt<0>();
 #pragma unroll
             for (int i = 0; i < FI; ++i)
 #pragma unroll
                 for (int j = 0; j < FJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wb[1][i]), __builtin_bit_cast(bf16x8_t, px[1][j]), acc[i][j], 0, 0, 0);
-            stage = stage == 2 ? 0 : stage + 1;
+            sa = sa == 2 ? 0 : sa + 1;
+            sb ^= 1;
         }
-        // ---- epilogue of the tile: bf16 outputs (16-byte stores of 8 consecutive channels), BatchNorm partial sums of the wave's 128-pixel block ----
+        // ---- epilogue of the tile: bf16 outputs (whole 128-byte lines per store instruction), BatchNorm partial sums of the wave's 128-pixel block ----
         const int tile = worker + ti * p.n_workers;
         const int mt = tile / p.n_co, co = tile - mt * p.n_co;
         const long long m0 = (long long)mt * G1_BM;
         long long rows = p.M - m0;
         rows = rows > G1_BM ? G1_BM : rows;
-        const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dst + m0 * row_b + co * G1_BN * 2), 0, (int)(rows * row_b), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dst + ((G1_EXP(p) & 2) ? (m0 & 255) : m0) * row_b + co * G1_BN * 2), 0, (int)(rows * row_b), 0x00020000);
         float ssum[FI][4], ssq[FI][4];
+        const bool upper = col >= 8;
 #pragma unroll
         for (int j = 0; j < FJ; ++j) {
             unsigned q[FI][2];
@@ -167,11 +225,28 @@ __global__ __launch_bounds__(512) void conv1x1_gemm_kernel(const G1Params p) {
                     }
                 }
             }
-            const g1_u32x2 lo = __builtin_amdgcn_permlane16_swap(q[0][0], q[1][0], false, false);
-            const g1_u32x2 hi = __builtin_amdgcn_permlane16_swap(q[0][1], q[1][1], false, false);
-            const g1_u32x4 o = {lo[0], hi[0], lo[1], hi[1]};
-            __builtin_amdgcn_raw_buffer_store_b128(o, rsD, voffS + (unsigned)(j * 16 * row_b), 0, 0);
-            store_b128_guard(o);
+            // fragment pairs (0, 1) / (2, 3): 8 consecutive channels per lane ({0, 16, 8, 24}[g] of the pair's 32); lanes col and col ^ 8 then trade one
+            // piece each, so that s1 / s2 are the two 32-channel halves' pieces of pixel (col & 7) / (col & 7) + 8 and col >> 3 picks the half
+            g1_u32x4 a0, a2;
+            {
+                const g1_u32x2 lo = __builtin_amdgcn_permlane16_swap(q[0][0], q[1][0], false, false);
+                const g1_u32x2 hi = __builtin_amdgcn_permlane16_swap(q[0][1], q[1][1], false, false);
+                a0 = (g1_u32x4){lo[0], hi[0], lo[1], hi[1]};
+                const g1_u32x2 lo2 = __builtin_amdgcn_permlane16_swap(q[2][0], q[3][0], false, false);
+                const g1_u32x2 hi2 = __builtin_amdgcn_permlane16_swap(q[2][1], q[3][1], false, false);
+                a2 = (g1_u32x4){lo2[0], hi2[0], lo2[1], hi2[1]};
+            }
+            g1_u32x4 give, got, s1, s2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) give[e] = upper ? a0[e] : a2[e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) got[e] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)give[e], 0x128, 0xf, 0xf, false);   // row_ror:8
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s1[e] = upper ? got[e] : a0[e]; s2[e] = upper ? a2[e] : got[e]; }
+            __builtin_amdgcn_raw_buffer_store_b128(s1, rsD, voffS + (unsigned)(j * 16 * row_b), 0, 0);
+            store_b128_guard(s1);
+            __builtin_amdgcn_raw_buffer_store_b128(s2, rsD, voffS + (unsigned)((j * 16 + 8) * row_b), 0, 0);
+            store_b128_guard(s2);
         }
         if constexpr (STAT) {
             const long long blk = (m0 >> 7) + wp;
@@ -187,9 +262,9 @@ __global__ __launch_bounds__(512) void conv1x1_gemm_kernel(const G1Params p) {
                 { const g1_u32x4 sv = __builtin_bit_cast(g1_u32x4, (g1_f32x4){ssq[i][0], ssq[i][1], ssq[i][2], ssq[i][3]}); __builtin_amdgcn_raw_buffer_store_b128(sv, rsT, voffT + i * 64, plane, 0); store_b128_guard(sv); }
             }
         }
-        after_epilogue = 2;
+        after_epilogue = 1;
     }
-    g1_wait_vmcnt<0>();                                  // (the two rounds past the end: nothing may land in LDS after the workgroup has left)
+    g1_wait_vmcnt<0>();                                  // (the rounds past the end: nothing may land in LDS after the workgroup has left)
 #endif
 }
 
@@ -220,6 +295,10 @@ int fb_try_conv1x1_gemm(const fb_conv_args* a, hipStream_t st) {
     p.n_co = a->Cd / G1_BN;
     p.n_tiles = (int)((M + G1_BM - 1) / G1_BM) * p.n_co;
     p.n_mblocks = (int)((M + 127) / 128);
+    p.exp = 0;
+#ifdef FB_C1G_EXPERIMENTS
+    p.exp = getenv("FB_C1G_EXP") ? atoi(getenv("FB_C1G_EXP")) : 0;
+#endif
     const int n_cu = fb_persistent_cus();
     p.n_workers = p.n_tiles < n_cu ? p.n_tiles : n_cu;
     if (a->stat_partial) hipLaunchKernelGGL((conv1x1_gemm_kernel<true>), dim3(p.n_workers), dim3(512), 0, st, p);
