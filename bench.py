@@ -672,7 +672,8 @@ def main():
             "vs_baseline": None, "dtype": "bf16" if trainer.dtype == torch.bfloat16 else ("f32" if eng.f32_split != "f16x2" else "f32-22bit"), "data": "synthetic",
             "config": {"workload": f"{'ResNet-18 CIFAR-10' if headline else args.model + ' ' + str(args.pixels) + 'px'} full-batch GD step, {trainer.n_chunks} chunks x {trainer.chunk} = {images_per_step} "
                                    f"images/step (drop_last), grad_reg block_strength={args.grad_reg}, fp32 master/accumulate",
-                       "chunk_group": eng.G, "parallelism": f"dp{world} (contiguous chunk ranges, reduce-scatter + all-gather)"},
+                       "chunk_group": eng.G, "streams": 1 if eng.wstream is None else 2,
+                       "parallelism": f"dp{world} (contiguous chunk ranges, reduce-scatter + all-gather)"},
             "train_loss_last": loss_last,
             # host time from the start of a step until its last kernel is queued (mean over the timed steps): launch overhead that the
             # GPU hides as long as it stays below ms_per_step

@@ -1,21 +1,28 @@
-// 1x1 convolutions with K >= 512 input channels (the channel-reducing convolutions of the Bottleneck blocks and their input gradients,
-// reference resnets.py:289-291: 1024 -> 256 @14x14, 512 -> 128 @28x28, 2048 -> 512 @7x7 ...), bf16, forward and input gradient.
+// 1x1 convolutions with K >= 512 input channels and a multiple of 256 output channels (the channel-reducing convolutions of the Bottleneck blocks and
+// their input gradients, reference resnets.py:289-291: 1024 -> 256 @14x14, 2048 -> 512 @7x7 ...), bf16, forward and input gradient.
 //
-// These went to the implicit GEMM (conv_igemm_glds.hip: 128 x 128 tiles, ONE 32 KiB stage, three workgroups per CU), where the counters show a
-// latency-bound kernel (round 5, 1024 -> 256 @14x14, 1024 images, 155 us = 678 TFLOP/s: 53 % of the wave cycles in s_waitcnt / s_barrier, matrix
-// pipe busy a third of the time): every K-step waits for the loads it has just issued, and a tile lives through 16 of them.  Here:
-//   * persistent workgroups (one per CU, 8 waves) walk a list of 256-pixel x 128-channel tiles; the K-steps of ALL their tiles form one stream
-//     through a RING OF THREE 48 KiB LDS stages (256 pixel rows + 128 filter rows of 128 bytes, `buffer_load ... lds`, XOR-swizzled on the
-//     source side): the loads of step t + 2 are issued while step t is multiplied, across tile boundaries, and every wait is a counted
-//     `s_waitcnt vmcnt(N)` -- the queue is never drained (all memory operations are issued unconditionally; rows past the tensor's end and
-//     steps past the workgroup's last tile read zeros / store nothing through the range check of per-tile descriptors)
-//   * a wave owns 128 pixels x 32 channels (16 accumulator fragments): 20 fragment reads per 32 MFMAs, a whole 128-pixel statistics block per
-//     wave (BatchNorm partial sums by DPP row sums, no cross-wave reduction), 16-byte stores after `v_permlane16_swap`
+// These went to the implicit GEMM (conv_igemm_glds.hip: 128 x 128 tiles, ONE 32 KiB stage, three workgroups per CU: 1024 -> 256 @14x14, 1024 images,
+// 155-160 us = 3.2 TB/s, matrix pipe busy a third of the time).  Two things hold that form down (round 5, tools/l2_probe.hip and the timing experiments
+// of this file): a 128 x 128 tile stages 32 KiB per 512 matrix-pipe cycles -- ALL of the 64 bytes / clock a CU's load path moves -- and its phases run
+// one after the other (an LDS-DMA instruction holds its wave at issue while the load path works the queue off, and all waves of a workgroup issue
+// together).  Here:
+//   * 256-pixel x 256-channel tiles (8 waves, one persistent workgroup per CU; a wave: 128 pixels x 64 channels = 32 accumulator fragments, 24
+//     fragment reads per 64 MFMAs): 64 KiB through the load path per 2048 matrix-pipe cycles, half its capacity
+//   * the K-steps of ALL tiles of a workgroup form one stream through two LDS rings -- pixel rows: three 32 KiB stages, filter rows: two (160 KiB,
+//     `buffer_load ... lds`, XOR-swizzled on the source side); every wait is a counted `s_waitcnt vmcnt(N)`, nothing drains the queue (all memory
+//     operations are issued unconditionally; rows past the tensor's end and steps past the last tile read zeros / store nothing: per-tile descriptors)
+//   * PING-PONG: the two waves of every SIMD run half a step apart and split the loading -- see the comment at the loops
+//   * whole 128-byte lines per store instruction (lane-row exchange + the col / col ^ 8 exchange of conv1x1_k32.hip): half-line stores of two waves
+//     reach memory as 1.25x the bytes (round 5, tools/pmc_hbm_case.sh); a whole 128-pixel statistics block per wave (DPP row sums, no cross-wave reduction)
 //   * co-tiles of one pixel tile are neighbours in the tile list: they run at the same time on one XCD and share the pixel rows in its L2
+// A step's timeline: tools/g1_trace.hip.
 #include "common.h"
 #include "conv_params.h"
 
 #include <type_traits>
+#ifdef FB_C1G_TRACE
+extern long long* g_g1_trace;        // tools/g1_trace.hip
+#endif
 
 namespace {
 typedef __attribute__((ext_vector_type(4))) unsigned g1_u32x4;
@@ -39,19 +46,33 @@ __device__ __forceinline__ int g1_xcd_remap(int b, int n) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 constexpr unsigned G1_OOB = 0x80000000u;
-#ifndef G1_STAGGER
-#define G1_STAGGER 1         /* the two waves of a SIMD issue their LDS-DMA pieces at different points of a step (A/B builds: tools/build_variant.py) */
+#ifndef G1_DMA_FIRST
+#define G1_DMA_FIRST 0       /* 1: a step's LDS-DMA pieces are issued before its fragment reads (A/B builds) */
+#endif
+#ifndef G1_IQ
+#define G1_IQ 2              /* 16-channel fragment rows (8 MFMAs each) of a step multiplied BEFORE its middle barrier (A/B builds: tools/build_variant.py) */
 #endif
 // 256 pixels x 256 channels per tile: (256 + 256) rows of 128 bytes per K-step = 64 KiB through the CU's load path (64 bytes / clock) per 2048 matrix-pipe
 // cycles -- half the path's capacity.  128 x 128 tiles (the implicit GEMM) need ALL of it, 256 x 128 three quarters: tools/l2_probe.hip.
 constexpr int G1_BM = 256, G1_BN = 256, G1_A_STAGE = G1_BM * 128, G1_B_STAGE = G1_BN * 128, G1_NA = 3, G1_NB = 2;
-constexpr int G1_PA = G1_BM / 8 / 8, G1_PB = G1_BN / 8 / 8;         // LDS-DMA pieces (8 rows) per wave and K-step: pixels / filter rows
+constexpr int G1_PA = G1_BM / 8 / 4, G1_PB = G1_BN / 8 / 4;         // LDS-DMA pieces (8 rows) per wave of the loading group and K-step: pixels / filter rows
 
 struct G1Params {
     const char* src; const char* wgt; char* dst; float* stat;
     long long M; int K; int Cd; int n_co; int n_tiles; int n_workers; int n_mblocks;
+#ifdef FB_C1G_TRACE
+    long long* trace;
+#endif
     int exp;   // timing experiments, only in builds with -DFB_C1G_EXPERIMENTS (WRONG results): FB_C1G_EXP & 1 = pixel rows from the first 512 rows (L2), & 2 = stores into the first 256 rows, & 4 = no MFMAs, & 8 = no fragment reads either, & 16 = no LDS-DMA (stale stages are multiplied)
 };
+#ifdef FB_C1G_TRACE
+// tools/g1_trace.hip: waves 0 and 4 of workgroup 0 stamp the shader clock (s_memtime) at 8 points of steps G1_T0 .. G1_T0 + 15
+#define G1_T0 20
+#define G1_STAMP(grp, k) do { if (worker == 0 && gw == 0 && tstep >= G1_T0 && tstep < G1_T0 + 16) { const long long t_ = __builtin_amdgcn_s_memtime(); \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) p.trace[(((grp) * 16 + (tstep - G1_T0)) * 8) + (k)] = t_; } } while (0)
+#else
+#define G1_STAMP(grp, k) do { } while (0)
+#endif
 #ifdef FB_C1G_EXPERIMENTS
 #define G1_EXP(p) ((p).exp)
 #else
@@ -92,114 +113,76 @@ __global__ __launch_bounds__(512) void conv1x1_gemm_kernel(const G1Params p) {
     const int n_my = worker < p.n_tiles ? (p.n_tiles - worker + p.n_workers - 1) / p.n_workers : 0;      // tiles of this workgroup
     if (n_my == 0) return;
 
-    // LDS-DMA rounds of step (tile index ti of this workgroup, K-step ks); ti >= n_my: empty descriptors (zeros into a stage nobody multiplies)
-    auto issue_a = [&](const int ti, const int ks, const int stage) {
+    // LDS-DMA rounds of step (tile index ti of this workgroup, K-step ks); ti >= n_my: empty descriptors (zeros into a stage nobody multiplies).
+    // The four waves of a group issue a whole round: 8 pieces each.
+    const int gw = wave & 3;
+    // (the descriptor of a round depends on its tile only: rebuilt when the tile index moves on, the K-step rides in the scalar offset)
+    auto desc_a = [&](const int ti) {
         const int tile = worker + ti * p.n_workers;
         const bool live = ti < n_my;
         const int mt = live ? tile / p.n_co : 0;
         const long long m0 = (long long)mt * G1_BM;
         long long rows = p.M - m0;
         rows = !live || rows < 0 ? 0 : (rows > G1_BM ? G1_BM : rows);
-        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.src + ((G1_EXP(p) & 1) ? (m0 & 511) : m0) * rowA_b), 0, (int)(rows * rowA_b), 0x00020000);
-        char* base = lds + stage * G1_A_STAGE;
-#pragma unroll
-        for (int i = 0; i < G1_PA; ++i) {
-            const int q = wave * G1_PA + i;                         // wave-uniform
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + q * 1024), 16, dma_lane + (unsigned)(q * 8 * rowA_b), ks * 128, 0, 0);
-        }
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(p.src + ((G1_EXP(p) & 1) ? (m0 & 511) : m0) * rowA_b), 0, (int)(rows * rowA_b), 0x00020000);
     };
-    auto issue_b = [&](const int ti, const int ks, const int stage) {
+    auto desc_b = [&](const int ti) {
         const int tile = worker + ti * p.n_workers;
         const bool live = ti < n_my;
         const int co = live ? tile % p.n_co : 0;
-        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.wgt + (long long)co * G1_BN * rowA_b), 0, live ? G1_BN * rowA_b : 0, 0x00020000);
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(p.wgt + (long long)co * G1_BN * rowA_b), 0, live ? G1_BN * rowA_b : 0, 0x00020000);
+    };
+    auto issue_a = [&](const __amdgpu_buffer_rsrc_t rsA, const int ks, const int stage) {
+        char* base = lds + stage * G1_A_STAGE;
+#pragma unroll
+        for (int i = 0; i < G1_PA; ++i) {
+            const int q = gw * G1_PA + i;                           // wave-uniform
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + q * 1024), 16, dma_lane + (unsigned)(q * 8 * rowA_b), ks * 128, 0, 0);
+        }
+    };
+    auto issue_b = [&](const __amdgpu_buffer_rsrc_t rsB, const int ks, const int stage) {
         char* base = lds + G1_NA * G1_A_STAGE + stage * G1_B_STAGE;
 #pragma unroll
         for (int i = 0; i < G1_PB; ++i) {
-            const int q = wave * G1_PB + i;
+            const int q = gw * G1_PB + i;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(base + q * 1024), 16, dma_lane + (unsigned)(q * 8 * rowA_b), ks * 128, 0, 0);
         }
     };
 
     f32x4_t acc[FI][FJ];
-    // Queue order (per wave, all counts follow from it): step t issues [filter round t + 1] [pixel round t + 2]; the top of step t needs pixel round t (issued
-    // in step t - 2) and filter round t (step t - 1) and leaves pixel round t + 1 (step t - 1, BEHIND filter round t) in flight: vmcnt(G1_PA).
-    // Prologue: [pixels 0] [filter 0] [pixels 1]  (KS >= 8: all of the first tile)
-    issue_a(0, 0, 0);
-    issue_b(0, 0, 0);
-    issue_a(0, 1, 1);
-    int b_ti = 0, b_ks = 1, a_ti = 0, a_ks = 2;          // the next rounds to issue
-    int sa = 0, sb = 0;                                  // ring stages of the step that is multiplied
-    int after_epilogue = 0;                              // the first step of a tile: the previous tile's stores sit behind pixel round 1 in the queue (one step: the
-                                                         // second step's filter round was issued behind them, so its wait retires them anyway)
-    for (int ti = 0; ti < n_my; ++ti) {
-        for (int ks = 0; ks < KS; ++ks) {
-            if (after_epilogue > 0) { g1_wait_vmcnt<G1_PA + NST>(); --after_epilogue; } else g1_wait_vmcnt<G1_PA>();
-            __builtin_amdgcn_s_barrier();                // ... everybody's share has landed; everybody has left the stages the next rounds go into
-            // An LDS-DMA instruction holds its wave at issue while the CU's load path works the queue off (64 of them per step: ~2000 cycles with all eight
-            // waves issuing together and the matrix pipe idle -- as long as the step's MFMAs).  So the two waves of a SIMD take turns: waves 0-3 (one per
-            // SIMD) issue their pieces here, waves 4-7 between the two halves of their MFMAs -- while one is held, the other one multiplies.
-            const bool early = !G1_STAGGER || wave < 4;
-            if (early) {
-                issue_b((G1_EXP(p) & 16) ? n_my : b_ti, b_ks, sb ^ 1);
-                issue_a((G1_EXP(p) & 16) ? n_my : a_ti, a_ks, sa == 0 ? 2 : sa - 1);
+    uint4 wb[2][FI], px[2][FJ];
+    // A step's work of a wave: all fragment reads (24), then 64 MFMAs in two PARTS of 8 G1_IQ / 64 - 8 G1_IQ around the middle barrier: the group that is busy
+    // with the memory side (reads, LDS-DMA issue) multiplies little, the other one much -- both parts of an interval end together.
+    auto frag_reads = [&](const int sa, const int sb) {
+        const unsigned soa = sa * G1_A_STAGE, sob = sb * G1_B_STAGE;
+        g1_static_for<0, 2>([&](auto hc) {
+            constexpr int h = decltype(hc)::value;
+            g1_static_for<0, FI>([&](auto ic) { constexpr int i = decltype(ic)::value; wb[h][i] = g1_lds_read16<i * 2048>(pb[h] + sob); });
+            g1_static_for<0, FJ>([&](auto jc) { constexpr int j = decltype(jc)::value; px[h][j] = g1_lds_read16<j * 2048>(pa[h] + soa); });
+        });
+    };
+    auto mma_rows = [&](auto hc, auto i0c, auto i1c, auto firstc) {
+        constexpr int h = decltype(hc)::value, i0 = decltype(i0c)::value, i1 = decltype(i1c)::value;
+#pragma unroll
+        for (int i = i0; i < i1; ++i)
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) {
+                const f32x4_t c = decltype(firstc)::value ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : acc[i][j];
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wb[h][i]), __builtin_bit_cast(bf16x8_t, px[h][j]), c, 0, 0, 0);
             }
-#ifdef FB_C1G_EXPERIMENTS
-            if (G1_EXP(p) & 8) { if (ks == 0) for (int i = 0; i < FI; ++i) for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; sa = sa == 2 ? 0 : sa + 1; sb ^= 1; if (!early) { issue_b(b_ti, b_ks, sb); issue_a(a_ti, a_ks, sa == 2 ? 0 : sa + 1); } if (++b_ks == KS) { b_ks = 0; ++b_ti; } if (++a_ks == KS) { a_ks = 0; ++a_ti; } continue; }
-#endif
-            const unsigned soa = sa * G1_A_STAGE, sob = sb * G1_B_STAGE;
-            uint4 wb[2][FI], px[2][FJ];
-            g1_static_for<0, 2>([&](auto hc) {
-                constexpr int h = decltype(hc)::value;
-                g1_static_for<0, FI>([&](auto ic) { constexpr int i = decltype(ic)::value; wb[h][i] = g1_lds_read16<i * 2048>(pb[h] + sob); });
-                g1_static_for<0, FJ>([&](auto jc) { constexpr int j = decltype(jc)::value; px[h][j] = g1_lds_read16<j * 2048>(pa[h] + soa); });
-            });
-            g1_wait_lgkmcnt<FI + FJ>();
-#ifdef FB_C1G_EXPERIMENTS
-            if (G1_EXP(p) & 4) {
-                g1_wait_lgkmcnt<0>();
-                if (ks == 0) for (int i = 0; i < FI; ++i) for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                unsigned x = 0;
-                for (int h = 0; h < 2; ++h) { for (int i = 0; i < FI; ++i) x ^= wb[h][i].x ^ wb[h][i].w; for (int j = 0; j < FJ; ++j) x ^= px[h][j].y ^ px[h][j].z; }
-                acc[0][0][0] += __uint_as_float(x);
-                if (!early) { issue_b(b_ti, b_ks, sb ^ 1); issue_a(a_ti, a_ks, sa == 0 ? 2 : sa - 1); }
-                if (++b_ks == KS) { b_ks = 0; ++b_ti; }
-                if (++a_ks == KS) { a_ks = 0; ++a_ti; }
-                sa = sa == 2 ? 0 : sa + 1; sb ^= 1;
-                continue;
-            }
-#endif
-            if (ks == 0) {
-#pragma unroll
-                for (int i = 0; i < FI; ++i)
-#pragma unroll
-                    for (int j = 0; j < FJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wb[0][i]), __builtin_bit_cast(bf16x8_t, px[0][j]), (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int i = 0; i < FI; ++i)
-#pragma unroll
-                    for (int j = 0; j < FJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wb[0][i]), __builtin_bit_cast(bf16x8_t, px[0][j]), acc[i][j], 0, 0, 0);
-            }
-            if (!early) {
-                __builtin_amdgcn_sched_barrier(0);
-                issue_b((G1_EXP(p) & 16) ? n_my : b_ti, b_ks, sb ^ 1);
-                issue_a((G1_EXP(p) & 16) ? n_my : a_ti, a_ks, sa == 0 ? 2 : sa - 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (++b_ks == KS) { b_ks = 0; ++b_ti; }
-            if (++a_ks == KS) { a_ks = 0; ++a_ti; }
-            g1_wait_lgkmcnt<0>();
-#pragma unroll
-            for (int i = 0; i < FI; ++i)
-#pragma unroll
-                for (int j = 0; j < FJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wb[1][i]), __builtin_bit_cast(bf16x8_t, px[1][j]), acc[i][j], 0, 0, 0);
-            sa = sa == 2 ? 0 : sa + 1;
-            sb ^= 1;
-        }
-        // ---- epilogue of the tile: bf16 outputs (whole 128-byte lines per store instruction), BatchNorm partial sums of the wave's 128-pixel block ----
+    };
+    using c0 = std::integral_constant<int, 0>; using c1 = std::integral_constant<int, 1>; using cq = std::integral_constant<int, G1_IQ>; using cf = std::integral_constant<int, FI>;
+    auto part1 = [&](const bool first) {
+        g1_wait_lgkmcnt<FI + FJ>();                      // the fragments of the first 32 channels
+        if (first) mma_rows(c0{}, c0{}, cq{}, std::true_type{}); else mma_rows(c0{}, c0{}, cq{}, std::false_type{});
+        g1_wait_lgkmcnt<0>();                            // (every fragment of the step is in registers: the stages may be overwritten behind the next barrier)
+    };
+    auto part2 = [&](const bool first) {
+        if (first) mma_rows(c0{}, cq{}, cf{}, std::true_type{}); else mma_rows(c0{}, cq{}, cf{}, std::false_type{});
+        mma_rows(c1{}, c0{}, cf{}, std::false_type{});
+    };
+    // epilogue of a tile: bf16 outputs (whole 128-byte lines per store instruction), BatchNorm partial sums of the wave's 128-pixel block
+    auto epilogue = [&](const int ti) {
         const int tile = worker + ti * p.n_workers;
         const int mt = tile / p.n_co, co = tile - mt * p.n_co;
         const long long m0 = (long long)mt * G1_BM;
@@ -262,18 +245,101 @@ __global__ __launch_bounds__(512) void conv1x1_gemm_kernel(const G1Params p) {
                 { const g1_u32x4 sv = __builtin_bit_cast(g1_u32x4, (g1_f32x4){ssq[i][0], ssq[i][1], ssq[i][2], ssq[i][3]}); __builtin_amdgcn_raw_buffer_store_b128(sv, rsT, voffT + i * 64, plane, 0); store_b128_guard(sv); }
             }
         }
-        after_epilogue = 1;
+    };
+
+    // PING-PONG.  What the timing experiments said about the lock-step form (all eight waves: barrier, 64 LDS-DMA instructions, 192 fragment reads,
+    // 512 MFMAs): the phases add up -- an LDS-DMA instruction holds its wave at issue while the CU's load path works the queue off (~2000 cycles per
+    // step with nothing else running), the fragment reads of eight waves arrive together, and the matrix pipe waits for both.  Here the two waves of
+    // every SIMD run HALF A STEP APART: waves 0-3 (group E, one per SIMD) and waves 4-7 (group L) alternate between [LDS-DMA issue, fragment reads,
+    // first 32 MFMAs] and [second 32 MFMAs] -- in every barrier interval one group feeds the matrix pipe from registers while the other one is busy
+    // with the memory side.  Barriers b = 0, 1, 2 ...: E's step t runs from barrier 2t (middle: 2t + 1), L's from 2t + 1 (middle: 2t + 2).
+    //   E loads the FILTER rounds (two stages): round t + 1 behind barrier 2t, awaited before barrier 2t + 2 (its own next top)
+    //   L loads the PIXEL rounds (three stages): round t + 2 behind barrier 2t + 1, round t + 1 awaited before barrier 2t + 2 (E reads it next)
+    // Stage reuse: a stage's last fragment read is complete (lgkmcnt(0)) before the reader's middle barrier, and the next round into it is issued at least one
+    // barrier later.  L passes one extra barrier at the start (that is the offset), E one at the end.
+    const int n_steps = n_my * KS;
+    int tstep = 0;
+    (void)tstep;
+    if (wave < 4) {
+        __amdgpu_buffer_rsrc_t rsB = desc_b(0);
+        issue_b(rsB, 0, 0);
+        int b_ti = 0, b_ks = 1, sa = 0, sb = 0;
+        bool after_epilogue = false;
+        for (int ti = 0; ti < n_my; ++ti) {
+            for (int ks = 0; ks < KS; ++ks) {
+                G1_STAMP(0, 0);
+                if (after_epilogue) { g1_wait_vmcnt<NST>(); after_epilogue = false; } else g1_wait_vmcnt<0>();     // filter round t (the newest loads of this wave)
+                G1_STAMP(0, 1);
+                __builtin_amdgcn_s_barrier();            // 2t
+                G1_STAMP(0, 2);
+                if (G1_DMA_FIRST) issue_b(rsB, b_ks, sb ^ 1);
+                frag_reads(sa, sb);
+                if (!G1_DMA_FIRST) issue_b(rsB, b_ks, sb ^ 1);      // (behind the reads: while the wave is held at issue its fragments arrive)
+                if (++b_ks == KS) { b_ks = 0; ++b_ti; rsB = desc_b(b_ti); }
+                G1_STAMP(0, 3);
+                part1(ks == 0);
+                G1_STAMP(0, 4);
+                __builtin_amdgcn_s_barrier();            // 2t + 1
+                G1_STAMP(0, 5);
+                part2(ks == 0);
+                G1_STAMP(0, 6);
+                ++tstep;
+                sa = sa == 2 ? 0 : sa + 1;
+                sb ^= 1;
+            }
+            epilogue(ti);
+            after_epilogue = true;
+        }
+        __builtin_amdgcn_s_barrier();                    // 2 n_steps: L's last middle barrier
+    } else {
+        __amdgpu_buffer_rsrc_t rsA = desc_a(0);
+        issue_a(rsA, 0, 0);
+        issue_a(rsA, 1, 1);
+        int a_ti = 0, a_ks = 2, sa = 0, sb = 0;
+        bool after_epilogue = false;
+        g1_wait_vmcnt<G1_PA>();                          // pixel round 0
+        __builtin_amdgcn_s_barrier();                    // 0
+        for (int ti = 0; ti < n_my; ++ti) {
+            for (int ks = 0; ks < KS; ++ks) {
+                G1_STAMP(1, 0);
+                __builtin_amdgcn_s_barrier();            // 2t + 1
+                G1_STAMP(1, 2);
+                if (G1_DMA_FIRST) issue_a(rsA, a_ks, sa == 0 ? 2 : sa - 1);
+                frag_reads(sa, sb);
+                if (!G1_DMA_FIRST) issue_a(rsA, a_ks, sa == 0 ? 2 : sa - 1);
+                if (++a_ks == KS) { a_ks = 0; ++a_ti; rsA = desc_a(a_ti); }
+                G1_STAMP(1, 3);
+                part1(ks == 0);
+                G1_STAMP(1, 4);
+                // pixel round t + 1 (issued a step ago; behind it in the queue: round t + 2, and once per tile the previous tile's stores between them)
+                if (after_epilogue) { g1_wait_vmcnt<G1_PA + NST>(); after_epilogue = false; } else g1_wait_vmcnt<G1_PA>();
+                G1_STAMP(1, 1);
+                __builtin_amdgcn_s_barrier();            // 2t + 2
+                G1_STAMP(1, 5);
+                part2(ks == 0);
+                G1_STAMP(1, 6);
+                ++tstep;
+                sa = sa == 2 ? 0 : sa + 1;
+                sb ^= 1;
+            }
+            epilogue(ti);
+            after_epilogue = true;
+        }
     }
+    (void)n_steps;
     g1_wait_vmcnt<0>();                                  // (the rounds past the end: nothing may land in LDS after the workgroup has left)
 #endif
 }
 
 // returns 1 if the kernel handled the call: bf16 1x1 convolution (forward or input gradient), K a multiple of 64 and >= 512, output channels a multiple of
-// 128, one shared weight set, no addend, optional BatchNorm partial sums (forward).  FB_C1G=0: the implicit GEMM takes these calls.
+// 256, one shared weight set, no addend, optional BatchNorm partial sums (forward).
+// OPT-IN (FB_C1G=1: forward calls, FB_C1G=2: input gradients too; read per call: the tests compare the two kernels inside one process; same bits -- both
+// add the K-steps up in the same order).  Alone on the device it beats the implicit GEMM by 15-25 % (1024 / 2048 images, same box, us: forward 1024 -> 256
+// @14x14 136 / 159 and 242-253 / 326-334, its input-gradient twin 141 / 173 and 256-262 / 304-307, 2048 -> 512 @7x7 122 / 146, 107 / 121), and rocprofv3 sees
+// those 4.4 ms of kernel time go (ResNet-152 @224, one stream: 356.7 -> 351.8 ms of kernels per step) -- but the STEP does not get shorter: 5848-5890
+// images/s with it against 5878-5912 without on one stream, 5801-5813 / 5851-5862 beside the weight-gradient stream (a workgroup takes its CU's whole LDS,
+// so nothing overlaps its start or its tail, and its neighbours in the sequence run 6-7 % longer).  Hence not the default.
 int fb_try_conv1x1_gemm(const fb_conv_args* a, hipStream_t st) {
-    // OPT-IN (FB_C1G=1: forward calls, FB_C1G=2: input gradients too; read per call: the tests compare the two kernels inside one process).  Built, bit-identical to
-    // the implicit GEMM, and measured WITHOUT effect where it counts: ResNet-152 @224, 2048 images per step, same box: 5775 / 5809 images/s with it,
-    // 5789 / 5780 without, 5790 with the input gradients too.
     const char* sw = getenv("FB_C1G");
     if (sw == nullptr || atoi(sw) == 0) return 0;
     if (a->R != 1 || a->S != 1 || a->stride != 1 || a->pad != 0 || a->dtype != FB_BF16) return 0;
@@ -282,11 +348,7 @@ int fb_try_conv1x1_gemm(const fb_conv_args* a, hipStream_t st) {
     if (a->wset_stride != 0 && a->imgs_per_wset > 0 && a->imgs_per_wset < a->n_img) return 0;
     if (a->addend || a->addend_mask || a->bst_x) return 0;
     if (a->mode == 1 && a->stat_partial) return 0;
-    // Measured against the implicit GEMM (1024 images, same box, us): forward 1024 -> 256 @14x14 147 / 158, 512 -> 2048 @7x7 149 / 177, 512 -> 128 @28x28
-    // 210 / 219, 2048 -> 512 @7x7 140 / 138; input gradients 154 / 154, 137 / 132, 211 / 215, 129 / 133: the ring removes the waits but the 48 LDS-DMA
-    // instructions a K-step needs cost a wave ~100 cycles each to ISSUE -- as much as its 32 MFMAs -- so the matrix pipe is no busier than before.
-    // (alone on the device; inside the step the difference disappears, see above)
-    if (a->mode == 1 && !(sw != nullptr && atoi(sw) == 2)) return 0;
+    if (a->mode == 1 && atoi(sw) != 2) return 0;
     const long long M = (long long)a->n_img * a->Hd * a->Wd;
     if ((M + G1_BM - 1) / G1_BM * (a->Cd / G1_BN) >= (1LL << 31) || (M / 128 + 2) * a->Cd * 8 >= (1LL << 31)) return 0;
     G1Params p;
@@ -296,6 +358,9 @@ int fb_try_conv1x1_gemm(const fb_conv_args* a, hipStream_t st) {
     p.n_tiles = (int)((M + G1_BM - 1) / G1_BM) * p.n_co;
     p.n_mblocks = (int)((M + 127) / 128);
     p.exp = 0;
+#ifdef FB_C1G_TRACE
+    p.trace = ::g_g1_trace;
+#endif
 #ifdef FB_C1G_EXPERIMENTS
     p.exp = getenv("FB_C1G_EXP") ? atoi(getenv("FB_C1G_EXP")) : 0;
 #endif

@@ -13,6 +13,7 @@ with conv weights in KRSC order ``[Cout][R*S][Cin]``; NHWC activations in the co
 """
 import math
 import os
+import time
 import warnings
 
 import torch
@@ -341,7 +342,15 @@ class Engine:
         self.bnf_sync = torch.zeros(int(lib.load().fb_ws_bn_bwd_fused_ints(self.G)), device=self.device, dtype=torch.int32)
         # weight gradients depend on nothing downstream in the backward chain: they run on their own stream, overlapping the
         # HBM-bound BN backward kernels and the dgrad convolutions of the main stream (FB_WGRAD_STREAM=0: same stream)
-        self.wstream = torch.cuda.Stream(device=self.device) if os.environ.get("FB_WGRAD_STREAM", "1") != "0" else None
+        sw = os.environ.get("FB_WGRAD_STREAM")
+        self.wstream = torch.cuda.Stream(device=self.device) if sw != "0" else None
+        # Whether the second stream pays depends on what it would run beside: the 3 x 3 layers of a BasicBlock net leave room on a CU (ResNet-18 @32: -1..4 % step
+        # time, ResNet-50 @32: -5 %), the big-tile 1 x 1 kernels of a wide Bottleneck net take a CU's whole LDS / register file and the two streams only get
+        # in each other's way (ResNet-152 @224 bf16: ONE stream is 1.5 % faster; with the fp32 regulariser two are 1.3 % faster again; round 5, same box).
+        # Both schedules give the same bits (test_two_stream_schedule_is_bit_identical_to_one_stream), so for such nets the first full_gradient call times one
+        # chunk group both ways and keeps the faster one.  FB_WGRAD_STREAM=0 / 1 pins the choice.
+        self.stream_autotune = sw not in ("0", "1") and any(L.R == 1 and L.cin_pad >= 512 for L in self.plan.layers)
+        self.stream_times = None
         self._wgrad_event = None
         self.label_smoothing, self.only_incorrect = 0.0, False      # loss function of the head kernel (reference get_loss_fn)
         self.load_from_model(model)
@@ -1034,6 +1043,22 @@ class Engine:
         self._replayable(("group", patches.data_ptr(), labels.data_ptr(), G, gout.data_ptr(), wsets, theta.data_ptr(), pidx, self.chunk, self.valid,
                           float(self.label_smoothing), bool(self.only_incorrect), self.fuse_bwd_stat, self.chain_on), body)
 
+    def _autotune_streams(self, xb, yb, g_n):
+        """Times one chunk group (forward + backward into ``self.g``, which the caller's first group overwrites) with the weight gradients on their own
+        stream and with everything on one stream, and keeps the faster schedule (two streams unless one is at least 0.5 % faster).  The group pass has no
+        side effects beyond its own buffers: running statistics and the mean gradient are updated by full_gradient, not here."""
+        two, times = self.wstream, {}
+        for label, ws in (("two", two), ("one", None)):
+            self.wstream = ws
+            self.group_gradient(xb, yb, g_n, self.g, 1, self.theta, 0)          # (records the launch sequence / warms the caches)
+            torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            self.group_gradient(xb, yb, g_n, self.g, 1, self.theta, 0)
+            torch.cuda.synchronize(self.device)
+            times[label] = time.perf_counter() - t0
+        self.stream_times = times
+        self.wstream = None if times["one"] < 0.995 * times["two"] else two
+
     def _fold(self, gbuf, g_n, lo, hi, counter, sq_out, ws, seg_row=0):
         """The running mean over [lo, hi) of the arena advanced by the ``g_n`` chunks in ``gbuf`` (+ their squared norms over that range into
         ``sq_out[:g_n]``): fb_mt_accumulate; with chained weight gradients the chained layers from their group sum (fb_mt_accumulate_sum), the
@@ -1139,6 +1164,10 @@ class Engine:
         # With several groups per step the running-mean pass of group k (HBM-bound, 2 x G x 45 MB) runs on the weight-gradient stream
         # beside the forward convolutions of group k+1; the per-chunk gradients then alternate between two arenas (the main stream
         # writes dgamma / dbeta / fc gradients of group k+1 while group k is still being folded in).
+        if self.stream_autotune:
+            self.stream_autotune = False
+            g_n = min(G, n_chunks)
+            self._autotune_streams(patches[k_first * chunk:(k_first + g_n) * chunk], labels[k_first * chunk:(k_first + g_n) * chunk], g_n)
         overlap = (not fd) and batch_clip is None and self.wstream is not None and n_chunks > G and os.environ.get("FB_ACC_OVERLAP", "1") != "0"
         if overlap and getattr(self, "g_alt", None) is None:
             self.g_alt, self.acc_ws = torch.zeros_like(self.g), torch.zeros_like(self.mt_ws)

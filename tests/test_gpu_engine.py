@@ -487,7 +487,7 @@ def test_two_stream_schedule_is_bit_identical_to_one_stream(case, monkeypatch):
     monkeypatch.setenv("FB_ACC_OVERLAP", "0")
     eng, ref = run()
     assert eng.wstream is None and all(bool(torch.isfinite(t).all()) for t in ref)
-    monkeypatch.delenv("FB_WGRAD_STREAM")
+    monkeypatch.setenv("FB_WGRAD_STREAM", "1")       # (unset, a wide Bottleneck net would time both schedules and keep the faster one: engine._autotune_streams)
     monkeypatch.delenv("FB_ACC_OVERLAP")
     for rep in range(reps):
         eng, got = run()
