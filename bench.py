@@ -104,6 +104,56 @@ def cpu_baseline(budget_s=24.0):
             "reference_in_build_container": "SURVEY.md section 6: the real reference, 8 threads: ~122 images/s (off), ~50 images/s (on)"}
 
 
+class PowerSampler:
+    """Board power and shader clock of this process's GPU over the timed region, read by a HOST thread from the amdgpu hwmon files (power1_input in
+    microwatts, freq1_input in Hz, power1_cap) every 0.2 s -- no device call, nothing queued.  Why it is in the line: the headline step runs AT the
+    board's power cap (round 5: 1364-1384 W of 1400 W, shader clock 2.12-2.20 GHz instead of 2.4), which is why kernels that are faster alone on the
+    device do not shorten the step.  Unreadable files (another driver layout, no permission): ``result()`` is None."""
+
+    def __init__(self, device_index):
+        import glob
+        import threading
+        self.dir, self.samples, self._stop, self._thread = None, [], threading.Event(), None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            found = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+            if found and os.path.exists(os.path.join(found[0], "power1_input")):
+                self.dir = found[0]
+        except Exception:
+            self.dir = None
+        self._threading = threading
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as handle:
+                return float(handle.read().strip())
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop.wait(0.2):
+            self.samples.append((self._read("power1_input"), self._read("freq1_input")))
+
+    def start(self):
+        if self.dir is not None:
+            self._thread = self._threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+
+    def result(self):
+        if self._thread is None:
+            return None
+        self._stop.set()
+        self._thread.join()
+        watts = [p / 1e6 for p, _ in self.samples if p]
+        mhz = [f / 1e6 for _, f in self.samples if f]
+        cap = self._read("power1_cap")
+        if not watts:
+            return None
+        return {"avg_w": round(sum(watts) / len(watts)), "max_w": round(max(watts)), "cap_w": round(cap / 1e6) if cap else None,
+                "sclk_mhz": round(sum(mhz) / len(mhz)) if mhz else None, "sclk_nominal_mhz": 2400, "samples": len(watts), "source": "amdgpu hwmon, host thread"}
+
+
 def _timed_steps(trainer, n_steps, warm):
     for _ in range(warm):
         trainer.step()
@@ -601,13 +651,17 @@ def main():
     for _ in range(args.warmup):
         trainer.step()
     # ---- the timed region: EXACTLY --steps steps of the production schedule, no instrumentation ----
+    power = PowerSampler(device.index if device.index is not None else 0) if rank == 0 else None
     sync()
+    if power is not None:
+        power.start()                # (a host thread reading hwmon files: nothing is queued on the device)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         trainer.step()
     trainer.flush_stats()            # the statistics of every timed step are read back and recorded inside the timed region
     sync()
     elapsed = time.perf_counter() - t0
+    power = power.result() if power is not None else None
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     rank_ms = None
     if world > 1:
@@ -684,6 +738,7 @@ def main():
         }
         if rank_ms is not None:
             out["rank_ms_per_step"] = {"min": min(rank_ms), "max": max(rank_ms)}
+        out["power"] = power
         extra = {"config": dict(out["config"], launches="native command lists (one host call per chunk group)" if eng.use_replay else "one ctypes call per launch (FB_REPLAY=0)"),
                  "outside_the_step": "the dataset is resident in HBM and the stem's im2col patches (fb_stem_patches, 3.3 GB bf16, ~3 ms) are gathered once before the "
                                      "timed region (static, un-augmented dataset); inside: weight prep, all chunk forward/backward passes, running mean, clip + SGD "
