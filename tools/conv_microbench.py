@@ -20,9 +20,19 @@ CASES = {  # name: (cin, cout, k, stride, hw, n_img)
 
 
 def bench(fn, iters=10):
+    # SUSTAIN=<seconds>: loop that long before timing -- a 10-launch loop runs at boost clock; the step does not (the board sits at its power cap:
+    # profiles/r5_kernel_power.md), and a kernel's sustained time is what it costs there
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
+    sustain = float(os.environ.get("SUSTAIN", "0"))
+    if sustain > 0:
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < sustain:
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
+        iters = 200
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(iters):

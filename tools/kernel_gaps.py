@@ -32,5 +32,20 @@ def main():
         print(f"| `{n}` | {cnt[n]} | {dur[n] / 1e6:.1f} | {before[n] / 1e6:.2f} | {after[n] / 1e6:.2f} | {(before[n] + after[n]) / 1e3 / max(cnt[n], 1):.1f} |")
 
 
+def by_predecessor(path, focus):
+    """Average duration of the launches of kernels whose name contains ``focus``, split by the kernel that ran before them."""
+    rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Grid_Size", "")) for r in csv.DictReader(open(path))), key=lambda r: r[0])
+    acc = collections.defaultdict(list)
+    for (s0, e0, n0, g0), (s1, e1, n1, g1) in zip(rows, rows[1:]):
+        if focus in n1:
+            acc[(n1, g1, n0)].append((e1 - s1) / 1e3)
+    print(f"| kernel (grid) | after | launches | avg us |\n|---|---|---|---|")
+    for (n1, g1, n0), v in sorted(acc.items(), key=lambda kv: -len(kv[1]))[:16]:
+        print(f"| `{n1}` ({g1}) | `{n0}` | {len(v)} | {sum(v) / len(v):.1f} |")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 3:
+        by_predecessor(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0], sys.argv[3])
+        sys.exit(0)
     main()
