@@ -400,3 +400,25 @@ def test_bench_line_stays_below_4k_on_a_canned_run():
     # and a line that would not fit is refused by the assembler itself
     with pytest.raises(RuntimeError, match="bench line is"):
         bench.assemble_line(dict(base, padding="x" * 4096), {}, (line_part, detail_part), side, cpu)
+
+
+def test_power_sampler_without_a_gpu_reports_nothing(tmp_path):
+    """bench.PowerSampler reads the amdgpu hwmon files of the process's GPU from a host thread; where there is no such device (this container) or the
+    files are unreadable it must stay out of the way: start() is a no-op and result() is None (the line then carries ``"power": null``).  With a
+    directory that looks like hwmon it samples, averages and converts the units (microwatts -> W, Hz -> MHz)."""
+    import time
+
+    import bench
+
+    ps = bench.PowerSampler(0)
+    assert ps.dir is None
+    ps.start()
+    assert ps.result() is None
+    for name, value in (("power1_input", "1364000000"), ("freq1_input", "2130000000"), ("power1_cap", "1400000000")):
+        (tmp_path / name).write_text(value + "\n")
+    ps = bench.PowerSampler(0)
+    ps.dir = str(tmp_path)
+    ps.start()
+    time.sleep(0.7)
+    got = ps.result()
+    assert got["avg_w"] == 1364 and got["max_w"] == 1364 and got["cap_w"] == 1400 and got["sclk_mhz"] == 2130 and got["samples"] >= 2

@@ -496,6 +496,38 @@ def test_two_stream_schedule_is_bit_identical_to_one_stream(case, monkeypatch):
             assert torch.equal(a, b), (case, rep, k, float((a - b).abs().max()))
 
 
+def test_stream_schedule_is_timed_once_for_wide_bottleneck_nets(monkeypatch):
+    """engine._autotune_streams: with FB_WGRAD_STREAM unset, an engine whose plan has 1x1 layers with K >= 512 (ResNet-50) times one chunk group with and
+    without the weight-gradient stream at its first full_gradient call and keeps the faster schedule (two streams unless one is 0.5 % faster); the timing
+    passes leave nothing behind -- losses, squared norms, mean gradient and running statistics equal those of an engine pinned to either schedule bit for
+    bit; a BasicBlock net (ResNet-18) never times anything; FB_WGRAD_STREAM=0 / 1 pins."""
+    monkeypatch.delenv("FB_WGRAD_STREAM", raising=False)
+    x, y = make_data(32 * 5, 64)
+
+    def run(depth):
+        cfg, model, eng, stem_patches = _build(depth, 64, 32, 2, torch.bfloat16, stem="standard")
+        patches, yd = stem_patches(x.cuda(), eng.plan.stem, torch.bfloat16), y.cuda()
+        auto = eng.stream_autotune
+        loss, correct, sq = eng.full_gradient(patches, yd, 0.1)
+        loss2, _, sq2 = eng.full_gradient(patches, yd, 0.1)              # (the second call does not time again)
+        torch.cuda.synchronize()
+        return eng, auto, [loss.clone(), correct.clone(), sq.clone(), eng.avg.clone(), eng.running_mean.clone(), eng.running_var.clone(), loss2.clone(), sq2.clone()]
+
+    eng, auto, got = run(50)
+    assert auto and not eng.stream_autotune and set(eng.stream_times) == {"one", "two"} and all(t > 0 for t in eng.stream_times.values())
+    assert (eng.wstream is None) == (eng.stream_times["one"] < 0.995 * eng.stream_times["two"])
+    assert int(eng.num_batches_tracked) == 10                             # two calls x five chunks: the timing passes are not counted
+    for pin in ("0", "1"):
+        monkeypatch.setenv("FB_WGRAD_STREAM", pin)
+        eng_p, auto_p, ref = run(50)
+        assert not auto_p and eng_p.stream_times is None and (eng_p.wstream is None) == (pin == "0")
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b)
+    monkeypatch.delenv("FB_WGRAD_STREAM")
+    eng18, auto18, _ = run(18)
+    assert not auto18 and eng18.stream_times is None and eng18.wstream is not None
+
+
 def test_chunk_group_beyond_2g_byte_tensors_equals_smaller_groups():
     """bf16 chunk groups whose activation tensors exceed 2^31 bytes (more than 127 chunks of 128 images at 32 x 32 x 64 channels): every kernel bases
     its buffer descriptors at its own tile / K slice, so the 32-bit offsets inside stay small.  130 chunks in ONE group (the 64-channel tensors are

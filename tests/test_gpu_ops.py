@@ -225,6 +225,38 @@ def test_conv1x1_kernels_agree_at_full_size(cin, cout, hw, n, monkeypatch):
     assert rel(new[0].reshape(-1, cout).float(), ref) < tol(dt)
 
 
+@pytest.mark.parametrize("cin,cout,hw,n", [(1024, 256, 14, 1024), (2048, 512, 7, 1000), (512, 2048, 7, 300)])
+def test_conv1x1_gemm_kernel_agrees_with_the_implicit_gemm_at_full_size(cin, cout, hw, n, monkeypatch):
+    """The opt-in ping-pong GEMM kernel (csrc/conv1x1_gemm.hip, FB_C1G=2) at a ResNet-152 chunk group's size: persistent workgroups walk three or four
+    256 x 256 tiles each (784 tiles @14x14; 192 pixel tiles x 2 or 58 x 8 channel tiles @7x7 with a ragged last pixel tile), the two wave groups half a
+    step apart, rings running across tile boundaries.  Same K-steps in the same order as the implicit GEMM: the SAME BITS for forward outputs and input
+    gradients; the statistics' fp32 sums associate differently (one wave per 128-pixel block here) and agree to 1e-5; both against torch's matmul."""
+    lib = _lib()
+    torch.manual_seed(11)
+    dt = torch.bfloat16
+    x = torch.randn(n, hw, hw, cin, device="cuda").to(dt)
+    w = (torch.randn(cout, 1, cin, device="cuda") * 0.03).to(dt)
+    wt = (torch.randn(cout, 1, cin, device="cuda") * 0.03).to(dt)       # as a transposed set: input gradient of a cout <- cin ... convolution with K = cin
+    nblk = (n * hw * hw + 127) // 128
+
+    def run():
+        out, stat, dx = torch.empty(n, hw, hw, cout, device="cuda", dtype=dt), torch.zeros(2, nblk, cout, device="cuda"), torch.empty(n, hw, hw, cout, device="cuda", dtype=dt)
+        lib.conv2d(x, w, out, 1, 1, 1, 0, 0, stat_partial=stat)
+        lib.conv2d(x, wt, dx, 1, 1, 1, 0, 1)
+        torch.cuda.synchronize()
+        return out, stat, dx
+
+    base = run()
+    monkeypatch.setenv("FB_C1G", "2")
+    for _ in range(2):                                       # (twice: the rings and barriers leave no state behind)
+        got = run()
+        assert torch.equal(base[0], got[0]) and torch.equal(base[2], got[2])
+        assert rel(base[1], got[1]) < 1e-5
+    ref = x.reshape(-1, cin).float() @ w.reshape(cout, cin).float().t()
+    assert rel(got[0].reshape(-1, cout).float(), ref) < tol(dt)
+    assert rel(got[1][0].sum(0), ref.sum(0)) < 2e-3 and rel(got[1][1].sum(0), (ref * ref).sum(0)) < 1e-4
+
+
 @pytest.mark.parametrize("magnitude", [1.0, 3e-6, 4e4])
 @pytest.mark.parametrize("cin,cout,k,stride,hw,n", [(64, 64, 3, 1, 8, 8), (64, 128, 3, 2, 8, 8), (128, 256, 1, 1, 4, 16), (64, 64, 3, 1, 32, 2),
                                                    (128, 128, 3, 1, 16, 3), (256, 128, 3, 1, 8, 4), (512, 512, 3, 1, 4, 32), (96, 64, 3, 1, 6, 3)])
