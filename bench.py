@@ -758,6 +758,10 @@ def main():
         if launches is not None:
             out["ms_per_step_with_kernel_events"] = round(1000 * elapsed_ev / args.steps, 2)
             roof = roofline_objects(args, trainer, launches, launches_iso, elapsed / args.steps, world, headline, passes)
+            if power is not None and power.get("sclk_mhz") and "roofline" in roof[0] and roof[0]["roofline"].get("frac"):
+                # `peak` is the dense peak at the nominal 2.4 GHz (MI355X_MICROARCH.md); the board's power cap holds the step at `power.sclk_mhz` on
+                # average (the 3x3 kernels lower still: profiles/r5_kernel_power.md) -- the same fraction against the peak at THAT clock
+                roof[0]["roofline"]["frac_at_step_clock"] = round(roof[0]["roofline"]["frac"] * power["sclk_nominal_mhz"] / power["sclk_mhz"], 4)
         if world == 1 and headline and args.grad_reg == 0 and trainer.dtype == torch.bfloat16 and not args.no_side_configs and not force_dist:
             side = side_configs(args, device, X, Y, trainer)
         if world == 1 and not args.no_cpu_baseline:

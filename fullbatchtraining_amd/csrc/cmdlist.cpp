@@ -49,6 +49,7 @@ const Entry kEntries[] = {
     FB_ENTRY(fb_mt_accumulate), FB_ENTRY(fb_mt_fd_perturb), FB_ENTRY(fb_mt_fd_combine_accumulate), FB_ENTRY(fb_mt_fd_combine),
     FB_ENTRY(fb_mt_chunk_clip), FB_ENTRY(fb_bn_eval_coeffs), FB_ENTRY(fb_mt_norms2), FB_ENTRY(fb_mt_clip_sgd), FB_ENTRY(fb_mt_scale), FB_ENTRY(fb_bn_bwd_fused), FB_ENTRY(fb_bn_bwd_reduce2), FB_ENTRY(fb_bn_bwd_apply2),
     FB_ENTRY(fb_conv2d_wgrad_chain), FB_ENTRY(fb_mt_accumulate_sum), FB_ENTRY(fb_mt_accumulate_skip),
+    FB_ENTRY(fb_maxpool3s2_fwd_idx), FB_ENTRY(fb_maxpool3s2_bwd_idx),
 };
 constexpr int kNumEntries = sizeof(kEntries) / sizeof(kEntries[0]);
 

@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     constexpr int PROW_A = TM * 2 + WG<bf16_tag>::PAD, PROW_B = TN * 2 + WG<bf16_tag>::PAD;      // plane rows (bf16 / fp16)
     constexpr int PLANE_A = KPX * PROW_A, PLANE_B = KPX * PROW_B;
     constexpr int TILE_BYTES = SPLIT ? NPL * (PLANE_A + PLANE_B) : KPX * (ROW_A + ROW_B);
-    constexpr int RED_BYTES = (WK > 1) ? WK * 64 * 16 * NJ * 4 : 0;
+    static_assert(WK == 1 || WM == 1, "the cross-wave K reduction covers one 64-row block tile");
+    constexpr int RED_BYTES = (WK > 1) ? WK * 64 * TN * 4 : 0;
     constexpr int LDS_BYTES = TILE_BYTES > RED_BYTES ? TILE_BYTES : RED_BYTES;
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     char* tileA = lds;
@@ -238,21 +239,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     const int taps = p.R * p.S;
     float* out = p.out + group * p.group_stride + ((long long)split * p.Cd) * taps * p.Cs;
     if constexpr (WK > 1) {
-        constexpr int WN_ = 16 * NJ;
-        float* red = (float*)lds;   // [WK][64][16*NJ]
+        float* red = (float*)lds;   // [WK][64][TN]
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) red[(wk * 64 + i * 16 + (lane >> 4) * 4 + q) * WN_ + j * 16 + (lane & 15)] = acc[i][j][q];
+                for (int q = 0; q < 4; ++q) red[(wk * 64 + i * 16 + (lane >> 4) * 4 + q) * TN + wn * 16 * NJ + j * 16 + (lane & 15)] = acc[i][j][q];
         __syncthreads();
-        for (int e = tid; e < 64 * WN_; e += 256) {
+        for (int e = tid; e < 64 * TN; e += 256) {
             float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < WK; ++w) v += red[w * 64 * WN_ + e];
-            const int co = tile_m * TM + e / WN_, ci = tile_n * TN + e % WN_;
+            for (int w = 0; w < WK; ++w) v += red[w * 64 * TN + e];
+            const int co = tile_m * TM + e / TN, ci = tile_n * TN + e % TN;
             out[((long long)co * taps + tap) * p.Cs + ci] = v;
         }
     } else {
@@ -309,7 +309,15 @@ extern "C" int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream) {
     const bool split = fb_f32_split_enabled();
     const int32_t info[FB_PROF_INFO] = {a->n_img, a->Hs, a->Ws, a->Cs, a->Hd, a->Wd, a->Cd, a->R, a->stride, a->split_k | (a->dtype << 16), FB_K_WGRAD_GENERIC};
     const int prof = fb_prof_begin(FB_PROF_WGRAD, st, info);
-    if (a->bn_x) {
+    // the ImageNet stem's 7 x 7 x 3 patches (147 -> 160 "channels"), bf16: ONE 64 x 160 tile per workgroup instead of five 64 x 32 tiles that each read dy (and, with
+    // the BatchNorm apply in the loader, x and the mask) again -- the launch is a streaming reduction over 12 544 pixels per image (round 5: 1.83 ms
+    // per 512 images at 1.6 TB/s of algorithmic bytes before)
+    static const bool wide160 = getenv("FB_DISABLE_WGRAD_WIDE160") == nullptr;
+    if (wide160 && a->dtype == FB_BF16 && a->R == 1 && a->S == 1 && a->Cs % 160 == 0 && a->Cs % 64 != 0 && a->Cd % 64 == 0) {
+        dim3 grid((a->Cd / 64) * (a->Cs / 160), taps, n_groups * a->split_k);
+        if (a->bn_x) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_tag, 1, 2, 2, 2, 5, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_tag, 1, 2, 2, 2, 5, false>), grid, dim3(256), 0, st, p);
+    } else if (a->bn_x) {
         dim3 grid((a->Cd / 64) * (a->Cs / 32), taps, n_groups * a->split_k);
         if (a->dtype == FB_F32 && split) hipLaunchKernelGGL((conv_wgrad_kernel<f32s_tag, 1, 1, 4, 1, 2, true>), grid, dim3(256), 0, st, p);
         else if (a->dtype == FB_F32) hipLaunchKernelGGL((conv_wgrad_kernel<float, 1, 1, 4, 1, 2, true>), grid, dim3(256), 0, st, p);

@@ -130,6 +130,112 @@ __global__ void maxpool3s2_bwd_kernel(const uint4* __restrict__ x, const uint4* 
     }
 }
 
+// ---- the same pooling with the argmax REMEMBERED: the forward pass writes, per output element, the window position (0..8, row-major, first maximum) it
+// took its value from -- one byte per element, 1/16 (bf16) of the pooled tensor -- and the backward pass reads that byte instead of finding the maximum of
+// every window again.  The recomputing backward reads the whole pre-pool tensor (1.6 GB per 1024 images of the ImageNet stem) and spends ~300 compare /
+// select instructions per item: 1.9-2.0 ms at 1.85 TB/s, three times its bytes' worth; this one reads dy + indices and writes dx.  Same bits: the position is
+// chosen by the same comparison in the same order.
+template <typename T>
+__global__ void maxpool3s2_fwd_idx_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, unsigned char* __restrict__ idx, int n_img, int H, int W, int cvec) {
+    constexpr int V = ET<T>::VEC;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long long total = (long long)n_img * Ho * Wo * cvec;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % cvec); long long r = i / cvec;
+        const int ox = (int)(r % Wo); r /= Wo; const int oy = (int)(r % Ho); const long long n = r / Ho;
+        float best[V]; int pos[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) { best[k] = -INFINITY; pos[k] = -1; }
+#pragma unroll
+        for (int dyy = 0; dyy < 3; ++dyy)
+#pragma unroll
+            for (int dxx = 0; dxx < 3; ++dxx) {
+                const int sy = 2 * oy + dyy - 1, sx = 2 * ox + dxx - 1;
+                if ((unsigned)sy >= (unsigned)H || (unsigned)sx >= (unsigned)W) continue;
+                float v[V];
+                ET<T>::unpack(x[((n * H + sy) * W + sx) * cvec + cv], v);
+#pragma unroll
+                for (int k = 0; k < V; ++k) if (v[k] > best[k] || pos[k] < 0) { best[k] = v[k]; pos[k] = dyy * 3 + dxx; }
+            }
+        y[i] = ET<T>::pack(best);
+        unsigned w[V / 4];
+#pragma unroll
+        for (int q = 0; q < V / 4; ++q) w[q] = (unsigned)pos[4 * q] | ((unsigned)pos[4 * q + 1] << 8) | ((unsigned)pos[4 * q + 2] << 16) | ((unsigned)pos[4 * q + 3] << 24);
+        if constexpr (V == 8) *(uint2*)(idx + i * 8) = make_uint2(w[0], w[1]); else *(unsigned*)(idx + i * 4) = w[0];
+    }
+}
+template <typename T, typename IDX>
+__global__ void maxpool3s2_bwd_idx_kernel(const unsigned char* __restrict__ idx, const uint4* __restrict__ dy, uint4* __restrict__ dx, int n_img, int H, int W, int cvec) {
+    constexpr int V = ET<T>::VEC;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const IDX total = (IDX)n_img * Ho * Wo * cvec;
+    for (IDX i = (IDX)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (IDX)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % (IDX)cvec); IDX r = i / (IDX)cvec;
+        const int b = (int)(r % (IDX)Wo); r /= (IDX)Wo; const int a = (int)(r % (IDX)Ho); const long long n = (long long)(r / (IDX)Ho);
+        float acc[4][V];                              // quad pixels (0,0), (0,1), (1,0), (1,1): see maxpool3s2_bwd_kernel
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < V; ++k) acc[q][k] = 0.f;
+#pragma unroll
+        for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+            for (int wx = 0; wx < 2; ++wx) {
+                const int oy = a + wy, ox = b + wx;
+                if (oy >= Ho || ox >= Wo) continue;
+                const long long o = ((n * Ho + oy) * Wo + ox) * cvec + cv;
+                unsigned w[2];
+                if constexpr (V == 8) { const uint2 t = *(const uint2*)(idx + o * 8); w[0] = t.x; w[1] = t.y; } else { w[0] = *(const unsigned*)(idx + o * 4); w[1] = 0; }
+                float g[V];
+                ET<T>::unpack(dy[o], g);
+#pragma unroll
+                for (int qy = 0; qy < 2; ++qy)
+#pragma unroll
+                    for (int qx = 0; qx < 2; ++qx) {
+                        const int ry = qy + 1 - 2 * wy, rx = qx + 1 - 2 * wx;
+                        if (ry < 0 || rx < 0) continue;
+                        const unsigned want = (unsigned)(ry * 3 + rx);
+#pragma unroll
+                        for (int k = 0; k < V; ++k) if (((w[k >> 2] >> (8 * (k & 3))) & 0xffu) == want) acc[qy * 2 + qx][k] += g[k];
+                    }
+            }
+#pragma unroll
+        for (int qy = 0; qy < 2; ++qy)
+#pragma unroll
+            for (int qx = 0; qx < 2; ++qx) {
+                const int py = 2 * a + qy, px = 2 * b + qx;
+                if (py < H && px < W) dx[((n * H + py) * W + px) * cvec + cv] = ET<T>::pack(acc[qy * 2 + qx]);
+            }
+    }
+}
+
+extern "C" int fb_maxpool3s2_fwd_idx(const void* x, void* y, void* idx, int32_t n_img, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
+    if (!x || !y || !idx) FB_FAIL(FB_ERR_ARG, "fb_maxpool3s2_fwd_idx: null pointer");
+    const int V = dtype == FB_F32 ? 4 : 8, cvec = C / V;
+    const long long total = (long long)n_img * ((H + 1) / 2) * ((W + 1) / 2) * cvec;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (dtype == FB_F32) hipLaunchKernelGGL((maxpool3s2_fwd_idx_kernel<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (uint4*)y, (unsigned char*)idx, n_img, H, W, cvec);
+    else hipLaunchKernelGGL((maxpool3s2_fwd_idx_kernel<bf16_tag>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (uint4*)y, (unsigned char*)idx, n_img, H, W, cvec);
+    FB_CHECK_LAUNCH("fb_maxpool3s2_fwd_idx");
+    return FB_OK;
+}
+extern "C" int fb_maxpool3s2_bwd_idx(const void* idx, const void* dy, void* dx, int32_t n_img, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
+    if (!idx || !dy || !dx) FB_FAIL(FB_ERR_ARG, "fb_maxpool3s2_bwd_idx: null pointer");
+    const int V = dtype == FB_F32 ? 4 : 8, cvec = C / V;
+    const long long total = (long long)n_img * ((H + 1) / 2) * ((W + 1) / 2) * cvec;        // one thread per 2x2 input quad and channel vector
+    const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    const bool small = total + 65536LL * 256 < (1LL << 32) && !(getenv("FB_MAXPOOL_IDX64") != nullptr);
+    if (dtype == FB_F32) {
+        if (small) hipLaunchKernelGGL((maxpool3s2_bwd_idx_kernel<float, unsigned>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)idx, (const uint4*)dy, (uint4*)dx, n_img, H, W, cvec);
+        else hipLaunchKernelGGL((maxpool3s2_bwd_idx_kernel<float, long long>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)idx, (const uint4*)dy, (uint4*)dx, n_img, H, W, cvec);
+    } else {
+        if (small) hipLaunchKernelGGL((maxpool3s2_bwd_idx_kernel<bf16_tag, unsigned>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)idx, (const uint4*)dy, (uint4*)dx, n_img, H, W, cvec);
+        else hipLaunchKernelGGL((maxpool3s2_bwd_idx_kernel<bf16_tag, long long>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)idx, (const uint4*)dy, (uint4*)dx, n_img, H, W, cvec);
+    }
+    FB_CHECK_LAUNCH("fb_maxpool3s2_bwd_idx");
+    return FB_OK;
+}
+
 extern "C" int fb_maxpool3s2_fwd(const void* x, void* y, int32_t n_img, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
     if (!x || !y) FB_FAIL(FB_ERR_ARG, "fb_maxpool3s2_fwd: null pointer");
     const int V = dtype == FB_F32 ? 4 : 8, cvec = C / V;

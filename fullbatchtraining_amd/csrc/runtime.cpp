@@ -8,7 +8,7 @@
 
 thread_local char fb_err_buf[512] = "";
 extern "C" const char* fb_last_error_string(void) { return fb_err_buf; }
-extern "C" int fb_abi_version(void) { return 12; }
+extern "C" int fb_abi_version(void) { return 13; }
 
 // ---- workspace sizes (floats) ------------------------------------------------------------------------------------------
 extern "C" int64_t fb_ws_conv_stat_floats(const fb_conv_args* a) {

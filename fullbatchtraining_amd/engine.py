@@ -424,6 +424,9 @@ class Engine:
         if self.plan.stem_pool:
             hp = (self.plan.stem.hout + 1) // 2
             self.stem_pooled = torch.empty(n, hp, hp, 64, device=dev, dtype=dt)
+            # the argmax of every pooling window (one byte per pooled element): the backward pass reads it instead of recomputing 4 windows x 9 values per input
+            # quad from the pre-pool tensor (fb_maxpool3s2_bwd_idx: 2.0 -> ~0.5 ms per 1024 images of the ImageNet stem, same bits); FB_MAXPOOL_IDX=0: recompute
+            self.stem_pool_idx = torch.empty(n, hp, hp, 64, device=dev, dtype=torch.uint8) if os.environ.get("FB_MAXPOOL_IDX", "1") != "0" else None
         for b in self.plan.blocks:
             b.mids = [torch.empty_like(c.x) for c in b.convs[:-1]]              # post BN-ReLU activations inside the block
             b.out = torch.empty_like(b.convs[-1].x)                              # block output (post add + ReLU)
@@ -690,7 +693,10 @@ class Engine:
         a = self.stem_out
         if plan.stem_pool:
             s = plan.stem
-            call("fb_maxpool3s2_fwd", a.data_ptr(), self.stem_pooled.data_ptr(), G * self.chunk, s.hout, s.wout, 64, self.dtc)
+            if self.stem_pool_idx is not None and not getattr(self, "_eval", False):
+                call("fb_maxpool3s2_fwd_idx", a.data_ptr(), self.stem_pooled.data_ptr(), self.stem_pool_idx.data_ptr(), G * self.chunk, s.hout, s.wout, 64, self.dtc)
+            else:
+                call("fb_maxpool3s2_fwd", a.data_ptr(), self.stem_pooled.data_ptr(), G * self.chunk, s.hout, s.wout, 64, self.dtc)
             a = self.stem_pooled
         pooled_ready = False                         # the previous block's output pass already wrote this block's pooled input
         for bi, b in enumerate(plan.blocks):
@@ -968,7 +974,10 @@ class Engine:
         S = plan.stem
         if plan.stem_pool:
             d_r = pool.get((n, S.hout, S.wout, 64))
-            call("fb_maxpool3s2_bwd", self.stem_out.data_ptr(), d.data_ptr(), d_r.data_ptr(), n, S.hout, S.wout, 64, self.dtc)
+            if self.stem_pool_idx is not None:
+                call("fb_maxpool3s2_bwd_idx", self.stem_pool_idx.data_ptr(), d.data_ptr(), d_r.data_ptr(), n, S.hout, S.wout, 64, self.dtc)
+            else:
+                call("fb_maxpool3s2_bwd", self.stem_out.data_ptr(), d.data_ptr(), d_r.data_ptr(), n, S.hout, S.wout, 64, self.dtc)
             pool.put(d)
             d = d_r
         if self._wgrad_bn_ok(S, self.stem_out) and not (d_reduced and not plan.stem_pool):

@@ -10,7 +10,7 @@ import struct
 import torch
 
 FB_F32, FB_BF16 = 0, 1
-EXPECTED_ABI = 12         # fb_abi_version() the ctypes structs / signatures below were written for
+EXPECTED_ABI = 13         # fb_abi_version() the ctypes structs / signatures below were written for
 MT_BLOCKS = 1024
 _LIB_PATH = os.environ.get("FB_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libfbengine.so")     # (FB_LIB_PATH: A/B builds, tools/build_variant.py)
 
@@ -58,6 +58,8 @@ _SIGS = {
     "fb_avgpool2_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "fb_maxpool3s2_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "fb_maxpool3s2_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "fb_maxpool3s2_fwd_idx": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "fb_maxpool3s2_bwd_idx": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "fb_head_pool": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "fb_head_loss": [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                      c_float, c_int, c_void_p],

@@ -258,6 +258,12 @@ int fb_avgpool2_fwd(const void* x, void* y, int32_t n_img, int32_t H, int32_t W,
 int fb_maxpool3s2_fwd(const void* x, void* y, int32_t n_img, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
 int fb_maxpool3s2_bwd(const void* x, const void* dy, void* dx, int32_t n_img, int32_t H, int32_t W, int32_t C, int32_t dtype,
                       void* stream);
+/* the same pooling with the argmax remembered (what autograd's max_pool2d_with_indices keeps, resnets.py:78): idx [n][Ho][Wo][C] bytes, the window
+ * position 0..8 (row-major, first maximum) every output element came from; the backward pass reads it instead of the pre-pool tensor.  Same bits
+ * as fb_maxpool3s2_fwd / fb_maxpool3s2_bwd (ABI v13). */
+int fb_maxpool3s2_fwd_idx(const void* x, void* y, void* idx, int32_t n_img, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
+int fb_maxpool3s2_bwd_idx(const void* idx, const void* dy, void* dx, int32_t n_img, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                          void* stream);
 /* AdaptiveAvgPool2d(1) + flatten (resnets.py:185-186): feat[n][C] fp32 */
 int fb_head_pool(const void* a, float* feat, int32_t n_img, int32_t HW, int32_t C, int32_t dtype, void* stream);
 /* fc + log_softmax + nll (mean over the chunk) + argmax-correct (training.py:78-80): logits, dlogits [n][classes],

@@ -587,6 +587,22 @@ def test_maxpool_backward_with_ties(dtype, hw, n, C):
     assert bool(torch.isfinite(got).all())
     assert rel(got, xr.grad) < tol(dtype, 0.5)
     assert float((got - q(xr.grad, dtype)).abs().max()) <= (0 if dtype == torch.float32 else 2 ** -7 * float(xr.grad.abs().max()))
+    # the form the engine runs (ABI v13): the forward pass remembers every window's argmax as one byte, the backward pass reads it instead of the pre-pool
+    # tensor -- the same outputs and the same input gradient BIT FOR BIT, and the remembered positions are torch's own max_pool2d_with_indices
+    ho = (hw + 1) // 2
+    y0, y1 = (torch.empty(n, ho, ho, C, dtype=dtype, device="cuda") for _ in range(2))
+    idx = torch.full((n, ho, ho, C), 255, dtype=torch.uint8, device="cuda")
+    lib.call("fb_maxpool3s2_fwd", xd.data_ptr(), y0.data_ptr(), n, hw, hw, C, lib.dtype_code(dtype))
+    lib.call("fb_maxpool3s2_fwd_idx", xd.data_ptr(), y1.data_ptr(), idx.data_ptr(), n, hw, hw, C, lib.dtype_code(dtype))
+    dxi = torch.full_like(xd, float("nan"))
+    lib.call("fb_maxpool3s2_bwd_idx", idx.data_ptr(), nhwc(dmp).to(dtype).cuda().data_ptr(), dxi.data_ptr(), n, hw, hw, C, lib.dtype_code(dtype))
+    assert torch.equal(y0, y1) and torch.equal(dxi, dxm)
+    _, tidx = F.max_pool2d(x, 3, 2, 1, return_indices=True)                 # flat index into the hw x hw plane
+    pos = nchw(idx.cpu()).long()
+    oy = torch.arange(ho).view(1, 1, ho, 1)
+    ox = torch.arange(ho).view(1, 1, 1, ho)
+    flat = (2 * oy - 1 + pos // 3) * hw + (2 * ox - 1 + pos % 3)
+    assert int(pos.max()) <= 8 and torch.equal(flat, tidx)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

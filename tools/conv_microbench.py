@@ -15,6 +15,7 @@ CASES = {  # name: (cin, cout, k, stride, hw, n_img)
     "b1a": (64, 256, 1, 1, 56, 512), "b1b": (256, 64, 1, 1, 56, 512), "b2a": (128, 512, 1, 1, 28, 512), "b2b": (512, 128, 1, 1, 28, 512),
     "b3a": (256, 1024, 1, 1, 14, 512), "b3b": (1024, 256, 1, 1, 14, 512), "b4a": (512, 2048, 1, 1, 7, 512), "b4b": (2048, 512, 1, 1, 7, 512),
     "c1": (64, 64, 3, 1, 56, 512), "c2": (128, 128, 3, 1, 28, 512), "c3": (256, 256, 3, 1, 14, 512), "c4": (512, 512, 3, 1, 7, 512),
+    "stemI": (160, 64, 1, 1, 112, 512),              # the ImageNet stem on its pre-gathered 7x7x3 patches (147 -> 160 channels), half a ResNet-152 chunk group
     "l1big": (64, 64, 3, 1, 32, 3840), "l2big": (128, 128, 3, 1, 16, 3840), "l3big": (256, 256, 3, 1, 8, 3840), "l4big": (512, 512, 3, 1, 4, 3840),
 }
 
