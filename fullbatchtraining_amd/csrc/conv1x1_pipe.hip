@@ -54,6 +54,19 @@ __device__ __forceinline__ int p1_xcd_remap(int b, int n) {
 __device__ __forceinline__ void p1_load16(p1_u32x4& dst, unsigned voff, p1_u32x4 rs) {
     asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rs) : "memory");
 }
+// one mask byte per lane (the ReLU bitmask of the lane's 16-byte addend vector: bit j <-> channel j), through inline asm like p1_load16
+__device__ __forceinline__ void p1_load_byte(unsigned& dst, unsigned voff, p1_u32x4 rs) {
+    asm volatile("buffer_load_ubyte %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rs) : "memory");
+}
+// the addend where its bit is set, zero elsewhere (v_bfe_i32 turns a bit into an all-ones word)
+__device__ __forceinline__ p1_u32x4 p1_masked(p1_u32x4 a, unsigned bits) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_sbfe((int)bits, 2 * d, 1), hi = (unsigned)__builtin_amdgcn_sbfe((int)bits, 2 * d + 1, 1);
+        a[d] &= (lo & 0x0000ffffu) | (hi & 0xffff0000u);
+    }
+    return a;
+}
 // counted wait that names the four destinations it releases (no consumer of them can be scheduled above it)
 template <int N> __device__ __forceinline__ void p1_wait_loads4(p1_u32x4& a, p1_u32x4& b, p1_u32x4& c, p1_u32x4& d) {
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
@@ -73,6 +86,7 @@ constexpr unsigned P1_OOB = 0x80000000u;
 
 struct P1Params {
     const char* src; const char* wgt; char* dst; const char* addend; float* stat;
+    const unsigned char* addend_mask;    // MASK: ReLU bitmask of the addend as fb_bn_apply wrote it (1 byte per 16-byte vector): the addend counts only where its bit is set
     long long M; int Cd; int n_co; int n_workers; int n_mblocks;
     int exp;                             // timing experiments, only in builds with -DFB_C1P_EXPERIMENTS (WRONG results): FB_C1P_EXP & 1 = every store into the first 256 rows, & 2 = every LDS-DMA round from the first 256 rows, & 4 = full 128-byte lines per store instruction (pixel pairs)
 };
@@ -84,8 +98,9 @@ struct P1Params {
 }  // namespace
 
 // K input channels; NWC waves share the channels of the workgroup (32 each), NW / NWC the pixels of a sub-tile; STAT: BatchNorm partial sums
-// per 128-pixel block (forward); ADD: same-shape addend (input gradient of the convolution behind a residual branch)
-template <int K, int NWC, int NW, bool STAT, bool ADD>
+// per 128-pixel block (forward); ADD: same-shape addend (input gradient of the convolution behind a residual branch); MASK: ... taken through its ReLU
+// bitmask (the masked gradient d * (out > 0) of reference resnets.py:312-316 without a materialised copy: fb_conv_args.addend_mask)
+template <int K, int NWC, int NW, bool STAT, bool ADD, bool MASK = false>
 __global__ __launch_bounds__(NW * 64) void conv1x1_pipe_kernel(const P1Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NS = K / 64;                       // 128-byte channel slices per pixel row
@@ -98,7 +113,8 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_pipe_kernel(const P1Params p)
     static_assert(NSUB * NG == 2 && FJ * NWP * 16 == PXT, "a wave owns 128 pixels of a unit: two groups");
     constexpr int TILE = 32768, NDMA = 32 / NW;      // LDS-DMA instructions per wave and sub-tile
     // memory operations of one group section, in issue order: [addend loads of the group] ... [statistics stores of the previous group's block] [stores of the previous group]
-    constexpr int AD = ADD ? JG : 0, SS = STAT ? 4 : 0, ST = JG;
+    static_assert(ADD || !MASK, "a mask needs an addend");
+    constexpr int AD = ADD ? (MASK ? 2 * JG : JG) : 0, SS = STAT ? 4 : 0, ST = JG;
     __shared__ __attribute__((aligned(16))) char lds[2 * TILE];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -146,6 +162,7 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_pipe_kernel(const P1Params p)
 
     f32x4_t accA[FI][JG], accB[FI][JG];              // group n / group n - 1 (roles alternate)
     p1_u32x4 adA[ADD ? JG : 1], adB[ADD ? JG : 1];
+    unsigned mkA[MASK ? JG : 1], mkB[MASK ? JG : 1];         // MASK: the mask byte of every addend vector
     float ssum[FI][4], ssq[FI][4];
 
     // Forward (STAT): outputs whose epilogue has run wait for the NEXT barrier before they are stored (P1_LATE) -- right behind a barrier all waves of
@@ -177,6 +194,7 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_pipe_kernel(const P1Params p)
     //   [TOP, LATE: stores of the pending groups] [TOP, !SPREAD: LDS-DMA round] [addend loads] [TOP, SPREAD: LDS-DMA pieces, in the slices]
     //   [block end: statistics stores] [!LATE: stores of the previous group]
     auto section = [&](auto posc, f32x4_t (&acc)[FI][JG], f32x4_t (&accp)[FI][JG], p1_u32x4 (&ad)[ADD ? JG : 1], p1_u32x4 (&adp)[ADD ? JG : 1],
+                       unsigned (&mk)[MASK ? JG : 1], unsigned (&mkp)[MASK ? JG : 1],
                        const long long m0u, const long long m0p, const long long m0_next_dma, const int stage) {
         constexpr int POS = decltype(posc)::value;   // 0 / 1: first / second 64 pixels of the wave's block
         constexpr bool TOP = NSUB == 2 || POS == 0;
@@ -210,6 +228,13 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_pipe_kernel(const P1Params p)
             asm volatile("s_nop 4" ::: "memory");    // (the descriptor's words may come straight from v_readfirstlane: 5 wait states)
 #pragma unroll
             for (int jj = 0; jj < JG; ++jj) p1_load16(ad[jj], voffS[jj], rs);
+            if constexpr (MASK) {                    // (a row's mask bytes sit at its byte offsets / 16; rows past the end read 0: nothing is added, nothing stored)
+                const long long rows = p.M - m0g;
+                const p1_u32x4 rsm = p1_desc((const char*)p.addend_mask + ((m0g * row_b) >> 4), 1, 1, (int)(((rows < 0 ? 0 : (rows > 64 ? 64 : rows)) * row_b) >> 4));
+                asm volatile("s_nop 4" ::: "memory");
+#pragma unroll
+                for (int jj = 0; jj < JG; ++jj) p1_load_byte(mk[jj], voffS[jj] >> 4, rsm);
+            }
         }
         const unsigned r0 = rd0 + stage * TILE, r1 = rd1 + stage * TILE;
         unsigned pk0[JG][2];                          // packed outputs of the previous group's first channel fragment
@@ -242,6 +267,11 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_pipe_kernel(const P1Params p)
                 constexpr int younger = ((TOPQ && SPREAD) ? NDMA : 0) + ((STAT && PPOS == 0) ? SS : 0) + ST_EARLY
                                         + (TOP ? ST_LATE : 0) + ((TOP && !SPREAD) ? NDMA : 0) + AD;
                 p1_wait_loads4<younger>(adp[0], adp[ADD ? 1 : 0], adp[ADD ? 2 : 0], adp[ADD ? 3 : 0]);
+                if constexpr (MASK) {                // (the mask bytes were requested right behind the addend: the same wait covers them)
+                    asm volatile("" : "+v"(mkp[0]), "+v"(mkp[MASK ? 1 : 0]), "+v"(mkp[MASK ? 2 : 0]), "+v"(mkp[MASK ? 3 : 0]));
+#pragma unroll
+                    for (int jj = 0; jj < JG; ++jj) adp[jj] = p1_masked(adp[jj], mkp[MASK ? jj : 0]);
+                }
             }
 #pragma unroll
             for (int t = kk * TPS; t < (kk + 1) * TPS; ++t) {
@@ -328,6 +358,8 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_pipe_kernel(const P1Params p)
 #pragma unroll
     for (int j = 0; j < (ADD ? JG : 1); ++j) adB[j] = (p1_u32x4){0u, 0u, 0u, 0u};
 #pragma unroll
+    for (int j = 0; j < (MASK ? JG : 1); ++j) mkB[j] = 0u;
+#pragma unroll
     for (int f = 0; f < FI; ++f)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ssum[f][r] = 0.f; ssq[f][r] = 0.f; }
@@ -342,14 +374,14 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_pipe_kernel(const P1Params p)
     for (; unit < n_units; unit += p.n_workers) {
         const long long m0u = unit * UNIT, m0n = (unit + p.n_workers) * UNIT;       // (a unit past the end: its LDS-DMA reads zeros, nobody multiplies them)
         if constexpr (NSUB == 2) {
-            section(std::integral_constant<int, 0>{}, accA, accB, adA, adB, m0u, m0p, m0u + PXT, stage);
+            section(std::integral_constant<int, 0>{}, accA, accB, adA, adB, mkA, mkB, m0u, m0p, m0u + PXT, stage);
             stage ^= 1;
-            section(std::integral_constant<int, 1>{}, accB, accA, adB, adA, m0u, m0u + px0, m0n, stage);
+            section(std::integral_constant<int, 1>{}, accB, accA, adB, adA, mkB, mkA, m0u, m0u + px0, m0n, stage);
             stage ^= 1;
             m0p = m0u + PXT + px0;
         } else {
-            section(std::integral_constant<int, 0>{}, accA, accB, adA, adB, m0u, m0p, m0n, stage);
-            section(std::integral_constant<int, 1>{}, accB, accA, adB, adA, m0u, m0u + px0, m0n, stage);
+            section(std::integral_constant<int, 0>{}, accA, accB, adA, adB, mkA, mkB, m0u, m0p, m0n, stage);
+            section(std::integral_constant<int, 1>{}, accB, accA, adB, adA, mkB, mkA, m0u, m0u + px0, m0n, stage);
             stage ^= 1;
             m0p = m0u + px0 + 64;
         }
@@ -364,6 +396,12 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_pipe_kernel(const P1Params p)
         f32x4_t (&accp)[FI][JG] = accB;
         p1_u32x4 (&adp)[ADD ? JG : 1] = adB;
         if constexpr (ADD) p1_wait_loads4<0>(adp[0], adp[ADD ? 1 : 0], adp[ADD ? 2 : 0], adp[ADD ? 3 : 0]);
+        if constexpr (MASK) {
+            unsigned (&mkp)[MASK ? JG : 1] = mkB;
+            asm volatile("" : "+v"(mkp[0]), "+v"(mkp[MASK ? 1 : 0]), "+v"(mkp[MASK ? 2 : 0]), "+v"(mkp[MASK ? 3 : 0]));
+#pragma unroll
+            for (int jj = 0; jj < JG; ++jj) adp[jj] = p1_masked(adp[jj], mkp[MASK ? jj : 0]);
+        }
         const __amdgpu_buffer_rsrc_t rsD = p1_rsrc(p.dst + m0p * row_b, p.M - m0p, 64, row_b);
 #pragma unroll
         for (int jj = 0; jj < JG; ++jj) {
@@ -410,11 +448,12 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_pipe_kernel(const P1Params p)
 #endif
 }
 
-template <int K, int NWC, int NW, bool STAT, bool ADD> static void p1_launch(const P1Params& p, int grid, hipStream_t st) {
-    hipLaunchKernelGGL((conv1x1_pipe_kernel<K, NWC, NW, STAT, ADD>), dim3(grid), dim3(NW * 64), 0, st, p);
+template <int K, int NWC, int NW, bool STAT, bool ADD, bool MASK = false> static void p1_launch(const P1Params& p, int grid, hipStream_t st) {
+    hipLaunchKernelGGL((conv1x1_pipe_kernel<K, NWC, NW, STAT, ADD, MASK>), dim3(grid), dim3(NW * 64), 0, st, p);
 }
 template <int K, int NWC, int NW> static void p1_pick(const P1Params& p, int grid, bool stat, bool add, hipStream_t st) {
     if (stat) p1_launch<K, NWC, NW, true, false>(p, grid, st);
+    else if (add && p.addend_mask) p1_launch<K, NWC, NW, false, true, true>(p, grid, st);
     else if (add) p1_launch<K, NWC, NW, false, true>(p, grid, st);
     else p1_launch<K, NWC, NW, false, false>(p, grid, st);
 }
@@ -422,7 +461,8 @@ template <int K, int NWC, int NW> static void p1_pick(const P1Params& p, int gri
 // returns 1 if the kernel handled the call: bf16 1x1 convolution (forward or input gradient), 64 / 128 / 256 input channels, output channels a
 // multiple of 128, one shared weight set, optional same-shape addend (mode 1), optional BatchNorm partial sums (mode 0).  FB_C1S_PIPE=0: the
 // round-3 form (conv1x1_stream.hip) takes these calls (same results up to the order of the statistics' fp32 additions)
-int fb_try_conv1x1_pipe(const fb_conv_args* a, hipStream_t st) {
+// the shapes this kernel takes (fb_conv_masked_addend_supported asks for the masked-addend form: conv_igemm.hip)
+int fb_conv1x1_pipe_takes(const fb_conv_args* a) {
     const char* sw = getenv("FB_C1S_PIPE");           // (read per call: the tests compare the two forms inside one process)
     if (sw != nullptr && atoi(sw) == 0) return 0;
     if (a->R != 1 || a->S != 1 || a->stride != 1 || a->pad != 0 || a->dtype != FB_BF16) return 0;
@@ -434,11 +474,18 @@ int fb_try_conv1x1_pipe(const fb_conv_args* a, hipStream_t st) {
     if (a->Cs == 128 && !a->addend && !(sw != nullptr && atoi(sw) == 2)) return 0;
     if (a->Cd % 128 != 0) return 0;
     if (a->wset_stride != 0 && a->imgs_per_wset > 0 && a->imgs_per_wset < a->n_img) return 0;
-    if (a->addend_mask || a->bst_x) return 0;
+    if (a->bst_x) return 0;
+    if (a->addend_mask && (!a->addend || a->mode != 1 || a->addend_mode != 1 || getenv("FB_C1P_NO_MASK") != nullptr)) return 0;
     if (a->mode == 0 && a->addend) return 0;
     if (a->mode == 1 && (a->stat_partial || (a->addend && a->addend_mode != 1))) return 0;
     const long long M = (long long)a->n_img * a->Hd * a->Wd;
     if (M * a->Cs * 2 >= (1LL << 40) || M * a->Cd * 2 >= (1LL << 40) || (M / 128 + 2) * a->Cd * 8 >= (1LL << 31)) return 0;
+    return 1;
+}
+
+int fb_try_conv1x1_pipe(const fb_conv_args* a, hipStream_t st) {
+    if (!fb_conv1x1_pipe_takes(a)) return 0;
+    const long long M = (long long)a->n_img * a->Hd * a->Wd;
     // 8-wave workgroups (one per CU, 256 channels) where the layer has them, else 4-wave ones (two per CU, 128 channels); FB_C1P_NW overrides
     static const int nw_env = getenv("FB_C1P_NW") ? atoi(getenv("FB_C1P_NW")) : 0;
     int nw = nw_env ? nw_env : 8;
@@ -448,6 +495,7 @@ int fb_try_conv1x1_pipe(const fb_conv_args* a, hipStream_t st) {
     const int pxt = 16384 / a->Cs, unit = pxt > 128 ? pxt : 128;
     P1Params p;
     p.src = (const char*)a->src; p.wgt = (const char*)a->wgt; p.dst = (char*)a->dst; p.addend = (const char*)a->addend; p.stat = a->stat_partial;
+    p.addend_mask = (const unsigned char*)a->addend_mask;
     p.M = M; p.Cd = a->Cd;
     p.n_co = a->Cd / (NWC * 32);
     p.n_mblocks = (int)((M + 127) / 128);

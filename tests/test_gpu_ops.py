@@ -854,6 +854,37 @@ def test_conv_masked_addend_equals_materialised_mask():
         lib.conv2d(dy2, w2, torch.empty_like(d2), 3, 3, 1, 1, 1, addend=d2, addend_mode=1, addend_mask=bits)
 
 
+@pytest.mark.parametrize("k,cd,hw,n", [(256, 1024, 14, 64), (256, 1024, 14, 3), (128, 512, 28, 5), (64, 256, 56, 2), (256, 512, 7, 9), (256, 128, 8, 4)])
+def test_conv1x1_masked_addend_equals_materialised_mask(k, cd, hw, n, monkeypatch):
+    """fb_conv_args.addend_mask in the streaming 1x1 input gradients (round 5: the identity Bottleneck blocks, reference resnets.py:312-316 -- the gradient
+    entering the residual branch is d * (out > 0)): taking `d` through the ReLU bitmask of the block output gives bit for bit what adding the materialised
+    d * (out > 0) gives, at every K the pipelined kernel serves, with ragged last groups (pixel counts that are no multiple of 64) and 4-wave
+    workgroups (128 output channels); with the kernel switched off the layer says "not supported" and the engine materialises the mask."""
+    lib = _lib()
+    torch.manual_seed(k + hw)
+    dy = (torch.randn(n, hw, hw, k, device="cuda") * 0.1).bfloat16()
+    wt = (torch.randn(cd, 1, k, device="cuda") * 0.05).bfloat16()
+    d = torch.randn(n, hw, hw, cd, device="cuda").bfloat16()
+    out_act = torch.randn(n, hw, hw, cd, device="cuda")
+    bits = ((out_act.reshape(-1, 8) > 0).to(torch.int32) << torch.arange(8, device="cuda")).sum(1).to(torch.uint8)
+    masked = torch.where(out_act > 0, d, torch.zeros_like(d))
+    a, b = torch.empty_like(d), torch.full_like(d, float("nan"))
+    args = lib.ConvArgs(dy.data_ptr(), wt.data_ptr(), b.data_ptr(), d.data_ptr(), None, n, hw, hw, k, hw, hw, cd, 1, 1, 1, 0, 1, 0, 0, 1, lib.dtype_code(torch.bfloat16),
+                        bits.data_ptr(), None, None, None, None, 0)
+    assert lib.load().fb_conv_masked_addend_supported(lib.C.byref(args))
+    lib.conv2d(dy, wt, a, 1, 1, 1, 0, 1, addend=masked, addend_mode=1)
+    lib.conv2d(dy, wt, b, 1, 1, 1, 0, 1, addend=d, addend_mode=1, addend_mask=bits)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    plain = torch.empty_like(d)
+    lib.conv2d(dy, wt, plain, 1, 1, 1, 0, 1)
+    assert not torch.equal(a, plain)
+    monkeypatch.setenv("FB_C1S_PIPE", "0")
+    assert not lib.load().fb_conv_masked_addend_supported(lib.C.byref(args))
+    with pytest.raises(lib.EngineError):
+        lib.conv2d(dy, wt, b, 1, 1, 1, 0, 1, addend=d, addend_mode=1, addend_mask=bits)
+
+
 @pytest.mark.parametrize("C,hw,amode", [(64, 32, 0), (64, 32, 1), (64, 32, 3), (128, 16, 0), (128, 16, 1), (256, 8, 0), (256, 8, 1), (512, 4, 0),
                                          (512, 4, 1)])
 def test_conv_dgrad_fused_bn_backward_reduction(C, hw, amode):
