@@ -23,6 +23,7 @@
 struct Halo4Params {
     const char* src; const char* wgt; char* dst; const char* addend; float* stat;
     const char* bst_x; const unsigned char* bst_mask;       // BST: input and ReLU bitmask of the BatchNorm whose backward consumes dst
+    const unsigned char* addend_mask;                        // addend_mode 1, bf16: the addend counts only where its ReLU bit is set (fb_conv_args.addend_mask)
     const float* amax_src; const float* amax_wgt;           // f32h (fp16x2 split): largest magnitudes per chunk of src / per weight set
     int amax_imgs;
     int n_img, H, Cs, Cd, mode;
@@ -596,6 +597,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
                 });
             }
         };
+        // masked addend (the residual-branch gradient d * (out > 0) of an identity block without a materialised copy): CO_T / 8 mask bytes per pixel, the
+        // whole tile's requested up front like the BST mask
+        unsigned am[4][FI / 2];
+        const bool masked = EB == 2 && p.addend_mode == 1 && p.addend_mask != nullptr;
+        if (masked) {
+            const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.addend_mask + (long long)cur.pt * 32 * p.Cd), 0, 32 * p.Cd, 0x00020000);
+            const int voffA = (wave * 64 + (lane & 15)) * (p.Cd >> 3);
+            h4_static_for<0, 4>([&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                const int soffA = (J * 16 * p.Cd + cur.ct * CO_T) >> 3;
+                if constexpr (FI == 4) {
+                    const h4_u32x2 m = __builtin_amdgcn_raw_buffer_load_b64(rsrcA, voffA, soffA, 0);
+                    am[J][0] = m[0]; am[J][1] = m[1];
+                } else {
+                    const h4_u32x4 m = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, voffA, soffA, 0);
+                    am[J][0] = m[0]; am[J][1] = m[1]; am[J][2] = m[2]; am[J][3] = m[3];
+                }
+            });
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < FI / 2; ++i) am[j][i] = 0xffffffffu;
+        }
         if constexpr (BST) {
             const __amdgpu_buffer_rsrc_t rsrcN = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bst_mask + (long long)cur.pt * 32 * p.Cd), 0, 32 * p.Cd, 0x00020000);
             const int voffN = (wave * 64 + (lane & 15)) * (p.Cd >> 3);
@@ -631,7 +656,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
                         const h4_u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrcE, voffD + I * 16 * EB, soff, 0);
                         v[0] += __uint_as_float(a[0]); v[1] += __uint_as_float(a[1]); v[2] += __uint_as_float(a[2]); v[3] += __uint_as_float(a[3]);
                     } else {
-                        const h4_u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(rsrcE, voffD + I * 16 * EB, soff, 0);
+                        h4_u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(rsrcE, voffD + I * 16 * EB, soff, 0);
+                        if (masked) {        // mask byte 2 (I & 1) + (g4 >> 1) of the word covers this lane's channels in its low (g4 even) or high nibble
+                            const unsigned bits = am[J][I >> 1] >> (((2 * (I & 1) + (g4 >> 1)) * 8) + (g4 & 1) * 4);
+                            const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 0, 1), m1 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 1, 1);
+                            const unsigned m2 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 2, 1), m3 = (unsigned)__builtin_amdgcn_sbfe((int)bits, 3, 1);
+                            a[0] &= (m0 & 0x0000ffffu) | (m1 & 0xffff0000u);
+                            a[1] &= (m2 & 0x0000ffffu) | (m3 & 0xffff0000u);
+                        }
                         v[0] += __uint_as_float(a[0] << 16); v[1] += __uint_as_float(a[0] & 0xffff0000u);
                         v[2] += __uint_as_float(a[1] << 16); v[3] += __uint_as_float(a[1] & 0xffff0000u);
                     }
@@ -750,6 +782,8 @@ static int h4_variant(const fb_conv_args* a) {
     if ((long long)(imgs_per_tile * a->Hs * W + 2 * W + 2) * a->Cs * EB >= (1LL << 31)) return 0;
     const int n_pt = a->n_img * a->Hs * W / 256, n_ct = a->Cd / (wide ? 128 : 64);
     if ((long long)n_pt * n_ct * n_ct >= (1LL << 32) || (long long)a->n_img * imgs_per_wset >= (1LL << 32)) return 0;
+    // masked addend: bf16 input gradients with a same-shape addend (FB_H4_NO_MASK: A/B switch -- the engine then materialises d * (out > 0))
+    if (a->addend_mask && (a->dtype != FB_BF16 || a->mode != 1 || !a->addend || a->addend_mode != 1 || getenv("FB_H4_NO_MASK") != nullptr)) return 0;
     // fused BatchNorm-backward reduction: bf16 input gradients on 16x16 / 8x8 / 4x4 maps
     if (a->bst_x && (a->mode != 1 || !a->bst_mask || !a->stat_partial || a->dtype != FB_BF16 || W == 32)) return 0;
     return compact ? 3 : (wide ? 2 : 1);
@@ -769,6 +803,7 @@ int fb_try_conv3x3_halo4(const fb_conv_args* a, hipStream_t st) {
     p.src = (const char*)a->src; p.wgt = (const char*)a->wgt; p.dst = (char*)a->dst; p.addend = (const char*)a->addend;
     p.stat = a->stat_partial;
     p.bst_x = (const char*)a->bst_x; p.bst_mask = (const unsigned char*)a->bst_mask;
+    p.addend_mask = (const unsigned char*)a->addend_mask;
     p.amax_src = a->amax_src; p.amax_wgt = a->amax_wgt; p.amax_imgs = a->amax_imgs > 0 ? a->amax_imgs : a->n_img;
     p.n_img = a->n_img; p.H = a->Hs; p.Cs = a->Cs; p.Cd = a->Cd; p.mode = a->mode;
     p.imgs_per_wset = imgs_per_wset;

@@ -203,13 +203,13 @@ int fb_try_conv1x1_pipe(const fb_conv_args* a, hipStream_t st);    // conv1x1_pi
 
 // 1 if fb_conv2d accepts `addend_mask` for these arguments (only the resident-filter 64-channel kernel applies the mask so far)
 int fb_conv1x1_pipe_takes(const fb_conv_args* a);     // conv1x1_pipe.hip
+int fb_conv3x3_halo4_takes(const fb_conv_args* a);    // conv3x3_halo4.hip
 extern "C" int32_t fb_conv_masked_addend_supported(const fb_conv_args* a) {
     if (!a || !a->addend || !a->addend_mask || a->addend_mode != 1) return 0;
-    return fb_conv3x3_halo5_takes(a) || fb_conv1x1_pipe_takes(a);
+    return fb_conv3x3_halo5_takes(a) || fb_conv1x1_pipe_takes(a) || fb_conv3x3_halo4_takes(a);
 }
 
 // 1 if fb_conv2d implements the fused BatchNorm-backward reduction for these arguments: the resident-filter and the persistent halo kernels
-int fb_conv3x3_halo4_takes(const fb_conv_args* a);   // conv3x3_halo4.hip
 extern "C" int32_t fb_conv_bwd_stat_supported(const fb_conv_args* a) {
     static const bool disabled = getenv("FB_DISABLE_FUSED_BWD_STAT") != nullptr;
     if (disabled || !a || !a->bst_x || !a->bst_mask || !a->stat_partial || a->mode != 1 || a->dtype != FB_BF16) return 0;

@@ -831,7 +831,7 @@ def test_absmax_norm_bias_and_ema_kernels():
 
 
 def test_conv_masked_addend_equals_materialised_mask():
-    """fb_conv_args.addend_mask (input gradient of the 64-channel 32x32 layers): adding `addend` through the ReLU bitmask gives bit
+    """fb_conv_args.addend_mask (input gradients of the 3x3 layers of identity blocks): adding `addend` through the ReLU bitmask gives bit
     for bit what adding the materialised d * (out > 0) gives; unsupported shapes say so instead of ignoring the mask."""
     lib = _lib()
     torch.manual_seed(11)
@@ -848,10 +848,27 @@ def test_conv_masked_addend_equals_materialised_mask():
     torch.cuda.synchronize()
     assert torch.equal(a, b)
     assert not torch.equal(a, d)                                               # (the convolution did something)
-    dy2, w2 = dy[:, :16, :16].contiguous().repeat(1, 1, 1, 2), torch.randn(128, 9, 128, device="cuda").bfloat16()
-    d2 = torch.randn(n, 16, 16, 128, device="cuda").bfloat16()
-    with pytest.raises(lib.EngineError):                                       # 128 channels: not implemented, and loudly so
-        lib.conv2d(dy2, w2, torch.empty_like(d2), 3, 3, 1, 1, 1, addend=d2, addend_mode=1, addend_mask=bits)
+    # the persistent halo kernel (128 / 256 / 512 channels on 16x16 / 8x8 / 4x4 maps, round 5): the same identity
+    for C, hw2 in ((128, 16), (256, 8), (512, 4)):
+        dy2 = (torch.randn(n, hw2, hw2, C, device="cuda") * 0.1).bfloat16()
+        w2 = (torch.randn(C, 9, C, device="cuda") * 0.03).bfloat16()
+        d2 = torch.randn(n, hw2, hw2, C, device="cuda").bfloat16()
+        act2 = torch.randn(n, hw2, hw2, C, device="cuda")
+        bits2 = ((act2.reshape(-1, 8) > 0).to(torch.int32) << torch.arange(8, device="cuda")).sum(1).to(torch.uint8)
+        a2, b2 = torch.empty_like(d2), torch.full_like(d2, float("nan"))
+        lib.conv2d(dy2, w2, a2, 3, 3, 1, 1, 1, addend=torch.where(act2 > 0, d2, torch.zeros_like(d2)), addend_mode=1)
+        lib.conv2d(dy2, w2, b2, 3, 3, 1, 1, 1, addend=d2, addend_mode=1, addend_mask=bits2)
+        torch.cuda.synchronize()
+        assert torch.equal(a2, b2), (C, hw2)
+    # a layer no kernel takes the mask for says so instead of ignoring it: fp32 storage, a 1x1 layer with K >= 512
+    d3 = torch.randn(n, 16, 16, 128, device="cuda")
+    with pytest.raises(lib.EngineError):
+        lib.conv2d(torch.randn(n, 16, 16, 128, device="cuda"), torch.randn(128, 9, 128, device="cuda"), torch.empty_like(d3), 3, 3, 1, 1, 1, addend=d3, addend_mode=1,
+                   addend_mask=bits)
+    d4 = torch.randn(n, 8, 8, 256, device="cuda").bfloat16()
+    with pytest.raises(lib.EngineError):
+        lib.conv2d(torch.randn(n, 8, 8, 1024, device="cuda").bfloat16(), torch.randn(256, 1, 1024, device="cuda").bfloat16(), torch.empty_like(d4), 1, 1, 1, 0, 1,
+                   addend=d4, addend_mode=1, addend_mask=bits)
 
 
 @pytest.mark.parametrize("k,cd,hw,n", [(256, 1024, 14, 64), (256, 1024, 14, 3), (128, 512, 28, 5), (64, 256, 56, 2), (256, 512, 7, 9), (256, 128, 8, 4)])
