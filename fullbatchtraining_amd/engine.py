@@ -60,11 +60,12 @@ class Block:
         self.convs, self.shortcut, self.stride, self.cin, self.hin, self.win = convs, shortcut, stride, cin, hin, win
 
 
-def max_group(plan, chunk, dtype, device=None):
+def max_group(plan, chunk, dtype, device=None, reserve_bytes=0):
     """Largest chunk group the fast kernels take.  fp32 storage: the biggest activation tensor (NHWC) stays below 2^31 bytes -- the fp32 LDS-DMA
     kernels address whole tensors with 32-bit buffer offsets and hand larger ones to the slower pointer-based kernels.  bf16: every kernel
     bases its descriptors at its own tile / K slice (round 3), so only a sanity limit of 2^35 bytes per tensor remains (the persistent
-    kernels' tile counts are 32-bit)."""
+    kernels' tile counts are 32-bit) -- and the device's memory: ``reserve_bytes`` = what the caller will allocate beside the engine (the stem's
+    pre-gathered patches of the rank's whole shard, resident images)."""
     # (the stem's pre-gathered patches -- 7x7x3 -> 160 values per pixel for the ImageNet stem, the largest tensor by far -- do not count: the two
     # launches that read them are cut into chunk ranges below 2^31 bytes, Engine._stem_ranges; ResNet-152 @224: groups of 10 chunks instead of 4)
     per_image = max(max(L.hout * L.wout * L.cout, L.hin * L.win * (L.cin_pad if L is not plan.stem else 0)) for L in plan.layers)
@@ -72,14 +73,22 @@ def max_group(plan, chunk, dtype, device=None):
     cap31 = max(1, ((1 << 31) - 1) // (chunk * per_image * es))
     if dtype != torch.bfloat16 or os.environ.get("FB_BIG_GROUPS", "1") == "0":
         return cap31
-    # beyond the old limit only as far as the resident activations of a group fit: conv outputs + post-BN activations + block outputs
-    # (+ ReLU masks) per image and ~8 gradient buffers of the largest tensor, against a third of the device (the rest: per-chunk
-    # gradients, patches, other engines)
-    acts = sum(2 * L.hout * L.wout * L.cout for L in plan.layers) + sum(b.convs[-1].hout * b.convs[-1].wout * b.convs[-1].cout for b in plan.blocks)
+    # beyond the old limit as far as the resident activations of a group fit: every layer's conv output and post-BN activation (a block's last
+    # BatchNorm writes the block output: counted once) with their ReLU masks, ~8 gradient buffers of the largest tensor -- against 90 % of the device
+    # or what is free of it, less the caller's own tensors.  Round 5 measured ResNet-152 @224: 108.8 GB at 8 chunks of 128 images, 207.9 GB at 16
+    # (12.4 GB per chunk + 9.5 GB; this estimate: 13.9 GB per chunk) -- and 16 chunks in ONE group are 2.5 % faster than two groups of 8 (half as many launches
+    # for the same work; the old rule, a third of the device, stopped at 10).  FB_GROUP_MEM_FRAC overrides the 0.9.
+    acts = sum(2 * L.hout * L.wout * L.cout for L in plan.layers)
     per_image_bytes = (acts * 17 // 16 + 8 * per_image) * es
-    # (the engine's OWN device: ranks other than local rank 0, heterogeneous boxes)
-    total = torch.cuda.get_device_properties(torch.device(device if device is not None else "cuda")).total_memory if torch.cuda.is_available() else 288 << 30
-    return max(cap31, min((1 << 35) // (chunk * per_image * es), (total // 3) // (chunk * per_image_bytes)))
+    dev = torch.device(device if device is not None else "cuda")
+    if torch.cuda.is_available():
+        total = torch.cuda.get_device_properties(dev).total_memory          # (the engine's OWN device: ranks other than local rank 0, heterogeneous boxes)
+        free = torch.cuda.mem_get_info(dev)[0]
+    else:
+        total = free = 288 << 30
+    frac = float(os.environ.get("FB_GROUP_MEM_FRAC", "0.9"))
+    budget = max(0, min(int(total * frac), free) - int(reserve_bytes))
+    return max(cap31, min((1 << 35) // (chunk * per_image * es), budget // (chunk * per_image_bytes)))
 
 
 def padded_chunk(plan, chunk):

@@ -447,7 +447,10 @@ class FullBatchTrainer:
         # chunk sizes that do not fill whole 128-pixel statistics blocks (data.batch_size=125: all 50 000 images in 400 chunks,
         # reference data_preparation.py:64-72) are stored padded with zero images (label -1)
         self.chunk_pad = padded_chunk(plan, self.chunk)
-        want, cap = int(cfg.impl.get("engine", {}).get("chunk_group", 98)), max_group(plan, self.chunk_pad, self.dtype, self.device)
+        # what this trainer keeps on the device beside the engine: the stem's patches of the rank's whole shard (and the base images where they are re-augmented)
+        es = torch.empty((), dtype=self.dtype).element_size()
+        own = self.shard.count * self.chunk_pad * plan.stem.hout * plan.stem.wout * plan.stem.cin_pad * es + self.shard.count * self.chunk * X[0].numel() * 4
+        want, cap = int(cfg.impl.get("engine", {}).get("chunk_group", 98)), max_group(plan, self.chunk_pad, self.dtype, self.device, reserve_bytes=own)
         G = group_size(self.shard.count, want, cap=cap)
         # K-slice counts of the weight gradients are sized for the group of the WHOLE problem on one GPU -- the same number on every rank, so
         # that a chunk's summation order (hence its gradient, bit for bit) does not depend on the number of GPUs
