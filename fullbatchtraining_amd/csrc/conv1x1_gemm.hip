@@ -333,22 +333,22 @@ __global__ __launch_bounds__(512) void conv1x1_gemm_kernel(const G1Params p) {
 
 // returns 1 if the kernel handled the call: bf16 1x1 convolution (forward or input gradient), K a multiple of 64 and >= 512, output channels a multiple of
 // 256, one shared weight set, no addend, optional BatchNorm partial sums (forward).
-// OPT-IN (FB_C1G=1: forward calls, FB_C1G=2: input gradients too; read per call: the tests compare the two kernels inside one process; same bits -- both
+// FB_C1G=0: never, 1: every forward call it can take, 2: input gradients too (read per call: the tests compare the two kernels inside one process; same bits -- both
 // add the K-steps up in the same order).  Alone on the device it beats the implicit GEMM by 15-25 % (1024 / 2048 images, same box, us: forward 1024 -> 256
 // @14x14 136 / 159 and 242-253 / 326-334, its input-gradient twin 141 / 173 and 256-262 / 304-307, 2048 -> 512 @7x7 122 / 146, 107 / 121), and rocprofv3 sees
-// those 4.4 ms of kernel time go (ResNet-152 @224, one stream: 356.7 -> 351.8 ms of kernels per step) -- but the STEP does not get shorter: 5848-5890
-// images/s with it against 5878-5912 without on one stream, 5801-5813 / 5851-5862 beside the weight-gradient stream (a workgroup takes its CU's whole LDS,
-// so nothing overlaps its start or its tail, and its neighbours in the sequence run 6-7 % longer).  Hence not the default.
+// those 4.4 ms of kernel time go (ResNet-152 @224, one stream: 356.7 -> 351.8 ms of kernels per step) -- but with groups of 1024 images the STEP did not get
+// shorter (5848-5890 images/s with it against 5878-5912 without; a workgroup takes its CU's whole LDS, so nothing overlaps its start or its tail).  With the
+// 2048-image groups of the end of round 5 the forward calls pay (6255-6266 against 6214-6228), the input gradients do not (6210-6233): the default.
 int fb_try_conv1x1_gemm(const fb_conv_args* a, hipStream_t st) {
     const char* sw = getenv("FB_C1G");
-    if (sw == nullptr || atoi(sw) == 0) return 0;
+    if (sw != nullptr && atoi(sw) == 0) return 0;
     if (a->R != 1 || a->S != 1 || a->stride != 1 || a->pad != 0 || a->dtype != FB_BF16) return 0;
     if (a->Hs != a->Hd || a->Ws != a->Wd) return 0;
     if (a->Cs < 512 || a->Cs % 64 != 0 || a->Cs > 4096 || a->Cd % G1_BN != 0) return 0;
     if (a->wset_stride != 0 && a->imgs_per_wset > 0 && a->imgs_per_wset < a->n_img) return 0;
     if (a->addend || a->addend_mask || a->bst_x) return 0;
     if (a->mode == 1 && a->stat_partial) return 0;
-    if (a->mode == 1 && atoi(sw) != 2) return 0;
+    if (a->mode == 1 && !(sw != nullptr && atoi(sw) == 2)) return 0;
     const long long M = (long long)a->n_img * a->Hd * a->Wd;
     if ((M + G1_BM - 1) / G1_BM * (a->Cd / G1_BN) >= (1LL << 31) || (M / 128 + 2) * a->Cd * 8 >= (1LL << 31)) return 0;
     G1Params p;
@@ -356,6 +356,9 @@ int fb_try_conv1x1_gemm(const fb_conv_args* a, hipStream_t st) {
     p.M = M; p.K = a->Cs; p.Cd = a->Cd;
     p.n_co = a->Cd / G1_BN;
     p.n_tiles = (int)((M + G1_BM - 1) / G1_BM) * p.n_co;
+    // DEFAULT: forward calls whose workgroups walk five tiles or more (a 2048-image ResNet-152 group: 1568 tiles; a 1024-image group's 3.06 tiles per workgroup
+    // round up to 4 -- a quarter of the kernel's span is a tail on 16 CUs, and the step gains nothing there)
+    if (sw == nullptr && p.n_tiles < 5 * fb_persistent_cus()) return 0;
     p.n_mblocks = (int)((M + 127) / 128);
     p.exp = 0;
 #ifdef FB_C1G_TRACE
