@@ -471,6 +471,12 @@ class Engine:
         px = self.chunk * L.hout * L.wout
         kstep = (32 if self.dt == torch.float32 else 64) if big else 128
         want = max(1, 1024 // max(tiles * G, 1))
+        if L is self.plan.stem and L.cin_pad % 64 != 0 and len(self._stem_ranges(G)) > 1:
+            # the stem on its pre-gathered patches is launched range by range (_stem_ranges: 4 chunks of the ImageNet stem), and bf16 patches of 160 values are ONE
+            # 64 x 160 tile per slice (conv_wgrad.hip): sized by the group, a 16-chunk ResNet-152 group left it 128 workgroups (1.6 ms per launch at 1.8 TB/s)
+            per_range = self._stem_ranges(G)[0][1]
+            tiles = (L.cout // 64) * (1 if (bf16 and L.cin_pad % 160 == 0) else L.cin_pad // 32)
+            want = max(1, 512 // max(tiles * per_range, 1))
         split = max(1, min(want, px // (kstep * 4)))
         while split > 1 and (split - 1) * (_round_up(-(-px // split), kstep)) >= px:
             split -= 1
