@@ -299,10 +299,11 @@ extern "C" int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream) {
     const bool hsplit = p.amax_x != nullptr;
     const int n_groups = a->n_img / a->imgs_per_group;
     hipStream_t st = (hipStream_t)stream;
-    // 128 x 128 tiles (four waves of 64 x 64) where both channel counts allow it and there are enough tiles; fp32 3x3 layers of 128 channels too (round 5: on
-    // 64 x 64 tiles every operand is streamed 18 times through L2 -- 62 fp32-TFLOP/s on the 28 x 28 maps of ResNet-152 against 152 for the 256-channel layers).
+    // 128 x 128 tiles (four waves of 64 x 64) where both channel counts allow it and there are enough tiles; 3x3 layers of 128 channels too (round 5: on
+    // 64 x 64 tiles every operand is streamed 18 times through L2 -- 62 fp32-TFLOP/s on the 28 x 28 maps of ResNet-152 against 152 for the 256-channel layers;
+    // bf16: the one stride-2 layer on 56 x 56 maps that the all-taps kernels do not cover, 178 TFLOP/s).
     // fullbatchtraining_amd/engine.py::_choose_split mirrors this choice (K-slice counts).
-    const bool big = (a->Cs % 128 == 0) && (a->Cd % 128 == 0) && (a->Cs >= 256 || a->Cd >= 256 || (a->dtype == FB_F32 && a->R == 3));
+    const bool big = (a->Cs % 128 == 0) && (a->Cd % 128 == 0) && (a->Cs >= 256 || a->Cd >= 256 || a->R == 3);
     const int kstep = big ? (a->dtype == FB_F32 ? 32 : 64) : 128;
     p.px_per_split = (int)(ceil_div64(ceil_div64(p.px_per_group, a->split_k), kstep) * kstep);
     const int taps = a->R * a->S;

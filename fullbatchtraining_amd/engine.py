@@ -465,7 +465,7 @@ class Engine:
             slots = 256 if (L.stride == 2 and L.wout == 4) else 512
             unit = 2 if L.wout == 4 else 1
             return max(1, min(slots // (tiles * G), self.chunk // (2 * unit)))
-        big = L.cin_pad % 128 == 0 and L.cout % 128 == 0 and (L.cin_pad >= 256 or L.cout >= 256 or (self.dt == torch.float32 and L.R == 3))   # = conv_wgrad.hip
+        big = L.cin_pad % 128 == 0 and L.cout % 128 == 0 and (L.cin_pad >= 256 or L.cout >= 256 or L.R == 3)   # = conv_wgrad.hip
         tile = 128 if big else 64
         tiles = (L.cout // tile) * max(L.cin_pad // tile, 1) * L.taps
         px = self.chunk * L.hout * L.wout
