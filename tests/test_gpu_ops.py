@@ -209,6 +209,7 @@ def test_conv1x1_kernels_agree_at_full_size(cin, cout, hw, n, monkeypatch):
         torch.cuda.synchronize()
         return out, stat, dx0, dx1, dxz
 
+    monkeypatch.setenv("FB_C1G", "0")                        # (this test is about the two streaming kernels: a forward call of this size with K = 256 goes to the GEMM kernel by default)
     new = run()
     monkeypatch.setenv("FB_C1S_PIPE", "0")
     old = run()
@@ -225,9 +226,9 @@ def test_conv1x1_kernels_agree_at_full_size(cin, cout, hw, n, monkeypatch):
     assert rel(new[0].reshape(-1, cout).float(), ref) < tol(dt)
 
 
-@pytest.mark.parametrize("cin,cout,hw,n", [(1024, 256, 14, 1024), (2048, 512, 7, 1000), (512, 2048, 7, 300)])
+@pytest.mark.parametrize("cin,cout,hw,n", [(1024, 256, 14, 1024), (2048, 512, 7, 1000), (512, 2048, 7, 300), (256, 1024, 14, 700)])
 def test_conv1x1_gemm_kernel_agrees_with_the_implicit_gemm_at_full_size(cin, cout, hw, n, monkeypatch):
-    """The opt-in ping-pong GEMM kernel (csrc/conv1x1_gemm.hip, FB_C1G=2) at a ResNet-152 chunk group's size: persistent workgroups walk three or four
+    """The ping-pong GEMM kernel (csrc/conv1x1_gemm.hip; FB_C1G=2: every call it can take) at a ResNet-152 chunk group's size: persistent workgroups walk three or four
     256 x 256 tiles each (784 tiles @14x14; 192 pixel tiles x 2 or 58 x 8 channel tiles @7x7 with a ragged last pixel tile), the two wave groups half a
     step apart, rings running across tile boundaries.  Same K-steps in the same order as the implicit GEMM: the SAME BITS for forward outputs and input
     gradients; the statistics' fp32 sums associate differently (one wave per 128-pixel block here) and agree to 1e-5; both against torch's matmul."""
