@@ -344,9 +344,12 @@ int fb_try_conv1x1_gemm(const fb_conv_args* a, hipStream_t st) {
     if (sw != nullptr && atoi(sw) == 0) return 0;
     if (a->R != 1 || a->S != 1 || a->stride != 1 || a->pad != 0 || a->dtype != FB_BF16) return 0;
     if (a->Hs != a->Hd || a->Ws != a->Wd) return 0;
-    // K = 256 (the Bottleneck blocks' conv3: 256 -> 1024): forward calls only -- alone on the device the streaming kernel is faster (244 against 320 us, 2048 images), inside
+    // K = 128 / 256 (the Bottleneck blocks' conv3: 128 -> 512, 256 -> 1024; K = 128: +0.45 % more): forward calls only -- alone on the device the streaming kernel is faster (244 against 320 us, 2048 images), inside
     // the ResNet-152 step this one is (6383-6385 against 6344-6347 images/s: whole-line stores, 822 MB written instead of 1028)
-    if (a->Cs < (a->mode == 0 ? 256 : 512) || a->Cs % 64 != 0 || a->Cs > 4096 || a->Cd % G1_BN != 0) return 0;
+    // (K < 512 only where the output is four times the input -- the expanding conv3 of a Bottleneck block, whose bytes are its stores; the 2x shortcuts of a BasicBlock net
+    // run beside a weight-gradient stream that this kernel's 160 KiB of LDS shut out: ResNet-18 headline 233.5-233.9 ms with it against 232.9-233.6)
+    if (sw == nullptr && a->Cs < 512 && a->Cd < 4 * a->Cs) return 0;
+    if (a->Cs < (a->mode == 0 ? 128 : 512) || a->Cs % 64 != 0 || a->Cs > 4096 || a->Cd % G1_BN != 0) return 0;
     if (a->wset_stride != 0 && a->imgs_per_wset > 0 && a->imgs_per_wset < a->n_img) return 0;
     if (a->addend || a->addend_mask || a->bst_x) return 0;
     if (a->mode == 1 && a->stat_partial) return 0;

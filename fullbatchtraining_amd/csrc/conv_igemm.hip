@@ -285,7 +285,7 @@ extern "C" int fb_conv2d(const fb_conv_args* a, void* stream) {
     static const bool v1 = getenv("FB_IGEMM_V1") != nullptr;
     int kernel = 0;
     if (fb_try_conv1x1_k32(a, st)) kernel = FB_K_CONV1X1_K32;
-    else if (a->mode == 0 && a->Cs == 256 && fb_try_conv1x1_gemm(a, st)) kernel = FB_K_CONV1X1_GEMM;      // (large forward calls with K = 256: conv1x1_gemm.hip)
+    else if (a->mode == 0 && (a->Cs == 256 || a->Cs == 128) && fb_try_conv1x1_gemm(a, st)) kernel = FB_K_CONV1X1_GEMM;      // (large forward calls with K = 128 / 256: conv1x1_gemm.hip)
     else if (fb_try_conv1x1_pipe(a, st)) kernel = FB_K_CONV1X1_PIPE;
     else if (fb_try_conv1x1_stream(a, st)) kernel = FB_K_CONV1X1_STREAM;
     else if (fb_try_conv1x1_gemm(a, st)) kernel = FB_K_CONV1X1_GEMM;
