@@ -59,6 +59,7 @@ constexpr int G1_PA = G1_BM / 8 / 4, G1_PB = G1_BN / 8 / 4;         // LDS-DMA p
 
 struct G1Params {
     const char* src; const char* wgt; char* dst; float* stat;
+    const char* addend; const unsigned char* addend_mask;     // ADDM 1 / 2: same-shape addend of an input gradient; ... through its ReLU bitmask (1 byte per 8 channels)
     long long M; int K; int Cd; int n_co; int n_tiles; int n_workers; int n_mblocks;
 #ifdef FB_C1G_TRACE
     long long* trace;
@@ -80,7 +81,8 @@ struct G1Params {
 #endif
 }  // namespace
 
-template <bool STAT>
+// ADDM: 0 no addend, 1 same-shape addend, 2 the addend where its ReLU bit is set (fb_conv_args.addend_mask) -- input gradients of the convolution behind a residual branch
+template <bool STAT, int ADDM = 0>
 __global__ __launch_bounds__(512) void conv1x1_gemm_kernel(const G1Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int FI = 4, FJ = 8;                                   // a wave: 64 channels x 128 pixels (32 accumulator fragments)
@@ -191,12 +193,33 @@ __global__ __launch_bounds__(512) void conv1x1_gemm_kernel(const G1Params p) {
         const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dst + ((G1_EXP(p) & 2) ? (m0 & 255) : m0) * row_b + co * G1_BN * 2), 0, (int)(rows * row_b), 0x00020000);
         float ssum[FI][4], ssq[FI][4];
         const bool upper = col >= 8;
+        // ADDM: the addend in the ACCUMULATORS' layout (a lane: channels 16 i + 4 g .. + 3 of pixel 16 j + col: 8 bytes per fragment), ordinary loads -- hipcc
+        // waits for them with vmcnt(0), which also lands this wave's ring rounds: the ones its next step's wait would have waited for anyway (E: filter round
+        // t + 1, L: pixel round t + 2), so the counted waits behind the epilogue only become conservative.  The mask: 8 bytes per pixel (this wave's 64 channels).
+        const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc((void*)(ADDM ? p.addend + m0 * row_b + co * G1_BN * 2 : p.dst), 0, ADDM ? (int)(rows * row_b) : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void*)(ADDM == 2 ? (const char*)p.addend_mask + ((m0 * row_b + co * G1_BN * 2) >> 4) : p.dst), 0,
+                                                                              ADDM == 2 ? (int)((rows * row_b) >> 4) : 0, 0x00020000);
+        const unsigned voffE = (unsigned)((wp * 128 + col) * row_b + (wc * 64 + g * 4) * 2), voffM = (unsigned)(((wp * 128 + col) * row_b + wc * 64 * 2) >> 4);
 #pragma unroll
         for (int j = 0; j < FJ; ++j) {
             unsigned q[FI][2];
+            g1_u32x2 am = {0xffffffffu, 0xffffffffu};
+            if constexpr (ADDM == 2) am = __builtin_amdgcn_raw_buffer_load_b64(rsM, voffM + (unsigned)((j * 16 * row_b) >> 4), 0, 0);
 #pragma unroll
             for (int i = 0; i < FI; ++i) {
-                const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if constexpr (ADDM != 0) {
+                    g1_u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(rsE, voffE + (unsigned)(j * 16 * row_b) + i * 32, 0, 0);
+                    if constexpr (ADDM == 2) {       // mask byte 2 i + (g >> 1) of the pixel's eight: this lane's channels are its low (g even) or high nibble
+                        const unsigned bits = am[i >> 1] >> ((((2 * i + (g >> 1)) & 3) * 8) + (g & 1) * 4);
+                        const unsigned m0_ = (unsigned)__builtin_amdgcn_sbfe((int)bits, 0, 1), m1_ = (unsigned)__builtin_amdgcn_sbfe((int)bits, 1, 1);
+                        const unsigned m2_ = (unsigned)__builtin_amdgcn_sbfe((int)bits, 2, 1), m3_ = (unsigned)__builtin_amdgcn_sbfe((int)bits, 3, 1);
+                        a[0] &= (m0_ & 0x0000ffffu) | (m1_ & 0xffff0000u);
+                        a[1] &= (m2_ & 0x0000ffffu) | (m3_ & 0xffff0000u);
+                    }
+                    v[0] += __uint_as_float(a[0] << 16); v[1] += __uint_as_float(a[0] & 0xffff0000u);
+                    v[2] += __uint_as_float(a[1] << 16); v[3] += __uint_as_float(a[1] & 0xffff0000u);
+                }
                 q[i][0] = pack_bf16x2(v[0], v[1]); q[i][1] = pack_bf16x2(v[2], v[3]);
                 if constexpr (STAT) {
                     if (j == 0) {
@@ -339,7 +362,7 @@ __global__ __launch_bounds__(512) void conv1x1_gemm_kernel(const G1Params p) {
 // those 4.4 ms of kernel time go (ResNet-152 @224, one stream: 356.7 -> 351.8 ms of kernels per step) -- but with groups of 1024 images the STEP did not get
 // shorter (5848-5890 images/s with it against 5878-5912 without; a workgroup takes its CU's whole LDS, so nothing overlaps its start or its tail).  With the
 // 2048-image groups of the end of round 5 the forward calls pay (6255-6266 against 6214-6228), the input gradients do not (6210-6233): the default.
-int fb_try_conv1x1_gemm(const fb_conv_args* a, hipStream_t st) {
+int fb_conv1x1_gemm_takes(const fb_conv_args* a) {
     const char* sw = getenv("FB_C1G");
     if (sw != nullptr && atoi(sw) == 0) return 0;
     if (a->R != 1 || a->S != 1 || a->stride != 1 || a->pad != 0 || a->dtype != FB_BF16) return 0;
@@ -349,21 +372,34 @@ int fb_try_conv1x1_gemm(const fb_conv_args* a, hipStream_t st) {
     // (K < 512 only where the output is four times the input -- the expanding conv3 of a Bottleneck block, whose bytes are its stores; the 2x shortcuts of a BasicBlock net
     // run beside a weight-gradient stream that this kernel's 160 KiB of LDS shut out: ResNet-18 headline 233.5-233.9 ms with it against 232.9-233.6)
     if (sw == nullptr && a->Cs < 512 && a->Cd < 4 * a->Cs) return 0;
-    if (a->Cs < (a->mode == 0 ? 128 : 512) || a->Cs % 64 != 0 || a->Cs > 4096 || a->Cd % G1_BN != 0) return 0;
+    if (a->Cs < ((a->mode == 0 || a->addend) ? 128 : 512) || a->Cs % 64 != 0 || a->Cs > 4096 || a->Cd % G1_BN != 0) return 0;
     if (a->wset_stride != 0 && a->imgs_per_wset > 0 && a->imgs_per_wset < a->n_img) return 0;
-    if (a->addend || a->addend_mask || a->bst_x) return 0;
+    if (a->bst_x) return 0;
+    if (a->addend && (a->mode != 1 || a->addend_mode != 1)) return 0;
+    if (a->addend_mask && !a->addend) return 0;
     if (a->mode == 1 && a->stat_partial) return 0;
+    // input gradients only with FB_C1G=2: without an addend (K >= 512) no step-level gain; with the same-shape addend of an identity block (plain or through its ReLU
+    // bitmask, K >= 128) the epilogue's 8-byte loads in the accumulators' layout are waited for with vmcnt(0) and the kernel spills: ResNet-152 @224 6082-6092
+    // images/s with it against 6421-6442 on the streaming kernel (round 5) -- built, bit-identical, off
     if (a->mode == 1 && !(sw != nullptr && atoi(sw) == 2)) return 0;
     const long long M = (long long)a->n_img * a->Hd * a->Wd;
     if ((M + G1_BM - 1) / G1_BM * (a->Cd / G1_BN) >= (1LL << 31) || (M / 128 + 2) * a->Cd * 8 >= (1LL << 31)) return 0;
+    const long long n_tiles = (M + G1_BM - 1) / G1_BM * (a->Cd / G1_BN);
+    // DEFAULT: calls whose workgroups walk five tiles or more (a 2048-image ResNet-152 group: 1568 tiles; a 1024-image group's 3.06 tiles per workgroup
+    // round up to 4 -- a quarter of the kernel's span is a tail on 16 CUs, and the step gains nothing there)
+    if (sw == nullptr && n_tiles < 5 * fb_persistent_cus()) return 0;
+    return 1;
+}
+
+int fb_try_conv1x1_gemm(const fb_conv_args* a, hipStream_t st) {
+    if (!fb_conv1x1_gemm_takes(a)) return 0;
+    const long long M = (long long)a->n_img * a->Hd * a->Wd;
     G1Params p;
     p.src = (const char*)a->src; p.wgt = (const char*)a->wgt; p.dst = (char*)a->dst; p.stat = a->stat_partial;
+    p.addend = (const char*)a->addend; p.addend_mask = (const unsigned char*)a->addend_mask;
     p.M = M; p.K = a->Cs; p.Cd = a->Cd;
     p.n_co = a->Cd / G1_BN;
     p.n_tiles = (int)((M + G1_BM - 1) / G1_BM) * p.n_co;
-    // DEFAULT: forward calls whose workgroups walk five tiles or more (a 2048-image ResNet-152 group: 1568 tiles; a 1024-image group's 3.06 tiles per workgroup
-    // round up to 4 -- a quarter of the kernel's span is a tail on 16 CUs, and the step gains nothing there)
-    if (sw == nullptr && p.n_tiles < 5 * fb_persistent_cus()) return 0;
     p.n_mblocks = (int)((M + 127) / 128);
     p.exp = 0;
 #ifdef FB_C1G_TRACE
@@ -375,6 +411,8 @@ int fb_try_conv1x1_gemm(const fb_conv_args* a, hipStream_t st) {
     const int n_cu = fb_persistent_cus();
     p.n_workers = p.n_tiles < n_cu ? p.n_tiles : n_cu;
     if (a->stat_partial) hipLaunchKernelGGL((conv1x1_gemm_kernel<true>), dim3(p.n_workers), dim3(512), 0, st, p);
+    else if (a->addend && a->addend_mask) hipLaunchKernelGGL((conv1x1_gemm_kernel<false, 2>), dim3(p.n_workers), dim3(512), 0, st, p);
+    else if (a->addend) hipLaunchKernelGGL((conv1x1_gemm_kernel<false, 1>), dim3(p.n_workers), dim3(512), 0, st, p);
     else hipLaunchKernelGGL((conv1x1_gemm_kernel<false>), dim3(p.n_workers), dim3(512), 0, st, p);
     return 1;
 }

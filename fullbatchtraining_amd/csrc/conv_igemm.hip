@@ -204,9 +204,10 @@ int fb_try_conv1x1_pipe(const fb_conv_args* a, hipStream_t st);    // conv1x1_pi
 // 1 if fb_conv2d accepts `addend_mask` for these arguments (only the resident-filter 64-channel kernel applies the mask so far)
 int fb_conv1x1_pipe_takes(const fb_conv_args* a);     // conv1x1_pipe.hip
 int fb_conv3x3_halo4_takes(const fb_conv_args* a);    // conv3x3_halo4.hip
+int fb_conv1x1_gemm_takes(const fb_conv_args* a);     // conv1x1_gemm.hip
 extern "C" int32_t fb_conv_masked_addend_supported(const fb_conv_args* a) {
     if (!a || !a->addend || !a->addend_mask || a->addend_mode != 1) return 0;
-    return fb_conv3x3_halo5_takes(a) || fb_conv1x1_pipe_takes(a) || fb_conv3x3_halo4_takes(a);
+    return fb_conv3x3_halo5_takes(a) || fb_conv1x1_pipe_takes(a) || fb_conv3x3_halo4_takes(a) || fb_conv1x1_gemm_takes(a);
 }
 
 // 1 if fb_conv2d implements the fused BatchNorm-backward reduction for these arguments: the resident-filter and the persistent halo kernels
@@ -285,7 +286,7 @@ extern "C" int fb_conv2d(const fb_conv_args* a, void* stream) {
     static const bool v1 = getenv("FB_IGEMM_V1") != nullptr;
     int kernel = 0;
     if (fb_try_conv1x1_k32(a, st)) kernel = FB_K_CONV1X1_K32;
-    else if (a->mode == 0 && (a->Cs == 256 || a->Cs == 128) && fb_try_conv1x1_gemm(a, st)) kernel = FB_K_CONV1X1_GEMM;      // (large forward calls with K = 128 / 256: conv1x1_gemm.hip)
+    else if ((a->mode == 0 || a->addend) && (a->Cs == 256 || a->Cs == 128) && fb_try_conv1x1_gemm(a, st)) kernel = FB_K_CONV1X1_GEMM;      // (mode 1: only with FB_C1G=2)      // (large forward calls with K = 128 / 256: conv1x1_gemm.hip)
     else if (fb_try_conv1x1_pipe(a, st)) kernel = FB_K_CONV1X1_PIPE;
     else if (fb_try_conv1x1_stream(a, st)) kernel = FB_K_CONV1X1_STREAM;
     else if (fb_try_conv1x1_gemm(a, st)) kernel = FB_K_CONV1X1_GEMM;

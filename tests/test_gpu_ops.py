@@ -898,6 +898,16 @@ def test_conv1x1_masked_addend_equals_materialised_mask(k, cd, hw, n, monkeypatc
     plain = torch.empty_like(d)
     lib.conv2d(dy, wt, plain, 1, 1, 1, 0, 1)
     assert not torch.equal(a, plain)
+    # the 256 x 256 GEMM kernel (large calls of the expanding layers by default; FB_C1G=2: every call it can take) adds the same values in its epilogue: same bits,
+    # with the mask, with a plain addend, without
+    monkeypatch.setenv("FB_C1G", "2")
+    c, e, f = torch.full_like(d, float("nan")), torch.full_like(d, float("nan")), torch.full_like(d, float("nan"))
+    lib.conv2d(dy, wt, c, 1, 1, 1, 0, 1, addend=d, addend_mode=1, addend_mask=bits)
+    lib.conv2d(dy, wt, e, 1, 1, 1, 0, 1, addend=masked, addend_mode=1)
+    lib.conv2d(dy, wt, f, 1, 1, 1, 0, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(a, c) and torch.equal(a, e) and torch.equal(plain, f)
+    monkeypatch.setenv("FB_C1G", "0")
     monkeypatch.setenv("FB_C1S_PIPE", "0")
     assert not lib.load().fb_conv_masked_addend_supported(lib.C.byref(args))
     with pytest.raises(lib.EngineError):
