@@ -64,7 +64,7 @@ struct G1Params {
 #ifdef FB_C1G_TRACE
     long long* trace;
 #endif
-    int exp;   // timing experiments, only in builds with -DFB_C1G_EXPERIMENTS (WRONG results): FB_C1G_EXP & 1 = pixel rows from the first 512 rows (L2), & 2 = stores into the first 256 rows, & 4 = no MFMAs, & 8 = no fragment reads either, & 16 = no LDS-DMA (stale stages are multiplied)
+    int exp;   // timing experiments, only in builds with -DFB_C1G_EXPERIMENTS (WRONG results): FB_C1G_EXP & 1 = pixel rows from the first 512 rows (L2), & 2 = stores into the first 256 rows
 };
 #ifdef FB_C1G_TRACE
 // tools/g1_trace.hip: waves 0 and 4 of workgroup 0 stamp the shader clock (s_memtime) at 8 points of steps G1_T0 .. G1_T0 + 15
@@ -280,8 +280,7 @@ __global__ __launch_bounds__(512) void conv1x1_gemm_kernel(const G1Params p) {
     //   L loads the PIXEL rounds (three stages): round t + 2 behind barrier 2t + 1, round t + 1 awaited before barrier 2t + 2 (E reads it next)
     // Stage reuse: a stage's last fragment read is complete (lgkmcnt(0)) before the reader's middle barrier, and the next round into it is issued at least one
     // barrier later.  L passes one extra barrier at the start (that is the offset), E one at the end.
-    const int n_steps = n_my * KS;
-    int tstep = 0;
+    int tstep = 0;                                       // (tools/g1_trace.hip stamps steps by this count)
     (void)tstep;
     if (wave < 4) {
         __amdgpu_buffer_rsrc_t rsB = desc_b(0);
@@ -349,7 +348,6 @@ __global__ __launch_bounds__(512) void conv1x1_gemm_kernel(const G1Params p) {
             after_epilogue = true;
         }
     }
-    (void)n_steps;
     g1_wait_vmcnt<0>();                                  // (the rounds past the end: nothing may land in LDS after the workgroup has left)
 #endif
 }
