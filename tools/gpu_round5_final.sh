@@ -9,7 +9,7 @@ bash tools/pmc_bench.sh r5final > $out/pmc.log 2>&1; tail -6 $out/pmc.log | cut 
 bash tools/pmc_mfma.sh r5final > $out/pmc_mfma.log 2>&1; tail -3 $out/pmc_mfma.log | cut -c1-300; cp gpurun_out/pmcmfma_r5final/summary.md $out/mfma_util.md; cp gpurun_out/pmcmfma_r5final/mfma_util.json $out/mfma_util.json
 python tools/roofline_table.py gpurun_out/prof_r5final gpurun_out/pmcbench_r5final 3 > $out/roofline_per_kernel.md 2>&1; head -14 $out/roofline_per_kernel.md | cut -c1-200
 FB_WGRAD_STREAM=0 python tools/step_breakdown.py bf16 98 > $out/breakdown_bf16.md 2>&1; tail -14 $out/breakdown_bf16.md
-FB_WGRAD_STREAM=0 python tools/step_breakdown.py bf16 8 resnet152 standard 224 128 > $out/breakdown_r152.md 2>&1; tail -16 $out/breakdown_r152.md
+FB_WGRAD_STREAM=0 python tools/step_breakdown.py bf16 16 resnet152 standard 224 128 > $out/breakdown_r152.md 2>&1; tail -16 $out/breakdown_r152.md
 mkdir -p gpurun_out/prof_r5final_gradreg
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r5final_gradreg -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --grad-reg 0.5 --steps 1 --warmup 1 --serialize --no-cpu-baseline --no-kernel-timing > $GRAFT_REPO_ROOT/gpurun_out/prof_r5final_gradreg/bench.log 2>&1
