@@ -355,6 +355,14 @@ def test_conv_wgrad(dtype, cin, cout, k, stride, hw, ipg, groups, split, monkeyp
         monkeypatch.delenv("FB_WGRAD3_COMPACT")
         if ((ipg + split - 1) // split) % 4 == 0:          # same K slices in both layouts
             assert torch.equal(slab, slab2)
+    if k == 1 and dtype == torch.bfloat16 and (cin % 256 == 0 or cout % 256 == 0):
+        # 1x1 weight gradients: 128-channel tiles per side by default (two workgroups per CU), 256-channel tiles with FB_W1_CAP_M / _N = 8 -- every output element adds the
+        # same pixels up in the same order: same bits
+        monkeypatch.setenv("FB_W1_CAP_M", "8"), monkeypatch.setenv("FB_W1_CAP_N", "8")
+        slab2 = torch.full_like(slab, float("nan"))
+        lib.conv2d_wgrad(xd, dyd, slab2, k, k, stride, pad, ipg, split)
+        monkeypatch.delenv("FB_W1_CAP_M"), monkeypatch.delenv("FB_W1_CAP_N")
+        assert torch.equal(slab, slab2)
     if split == 1:      # group_stride: per-chunk gradients written straight into arena rows, no reduce pass
         arena = torch.full((groups, cout * k * k * cin + 40), float("nan"), device="cuda")
         lib.conv2d_wgrad(xd, dyd, arena[:, 8:], k, k, stride, pad, ipg, 1, group_stride=arena.shape[1])
