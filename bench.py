@@ -650,6 +650,8 @@ def main():
 
     for _ in range(args.warmup):
         trainer.step()
+    if trainer.patches is not None:
+        eng.choose_schedule(trainer.patches, trainer.labels, trainer.shard.count)      # (a no-op unless --warmup 0 left a wide Bottleneck net's stream choice pending)
     # ---- the timed region: EXACTLY --steps steps of the production schedule, no instrumentation ----
     power = PowerSampler(device.index if device.index is not None else 0) if rank == 0 else None
     sync()

@@ -1067,6 +1067,14 @@ class Engine:
         self._replayable(("group", patches.data_ptr(), labels.data_ptr(), G, gout.data_ptr(), wsets, theta.data_ptr(), pidx, self.chunk, self.valid,
                           float(self.label_smoothing), bool(self.only_incorrect), self.fuse_bwd_stat, self.chain_on), body)
 
+    def choose_schedule(self, patches, labels, n_chunks):
+        """The stream choice of a wide Bottleneck net NOW, if it is still pending (otherwise the first full_gradient call makes it): a caller that times its first
+        step (bench.py with --warmup 0) keeps the four extra group passes out of it.  ``patches`` / ``labels``: the rank's chunks as full_gradient takes them."""
+        if self.stream_autotune and n_chunks > 0:
+            self.stream_autotune = False
+            g_n = min(self.G, n_chunks)
+            self._autotune_streams(patches[:g_n * self.chunk], labels[:g_n * self.chunk], g_n)
+
     def _autotune_streams(self, xb, yb, g_n):
         """Times one chunk group (forward + backward into ``self.g``, which the caller's first group overwrites) with the weight gradients on their own
         stream and with everything on one stream, and keeps the faster schedule (two streams unless one is at least 0.5 % faster).  The group pass has no

@@ -526,6 +526,15 @@ def test_stream_schedule_is_timed_once_for_wide_bottleneck_nets(monkeypatch):
     monkeypatch.delenv("FB_WGRAD_STREAM")
     eng18, auto18, _ = run(18)
     assert not auto18 and eng18.stream_times is None and eng18.wstream is not None
+    # choose_schedule: the same choice made by the caller ahead of its first (timed) step -- full_gradient then has nothing left to time and gives the same bits
+    cfg, model, eng_c, stem_patches = _build(50, 64, 32, 2, torch.bfloat16, stem="standard")
+    patches, yd = stem_patches(x.cuda(), eng_c.plan.stem, torch.bfloat16), y.cuda()
+    eng_c.choose_schedule(patches, yd, 5)
+    assert not eng_c.stream_autotune and set(eng_c.stream_times) == {"one", "two"}
+    chosen = dict(eng_c.stream_times)
+    loss, correct, sq = eng_c.full_gradient(patches, yd, 0.1)
+    torch.cuda.synchronize()
+    assert eng_c.stream_times == chosen and torch.equal(loss, got[0]) and torch.equal(sq, got[2]) and torch.equal(eng_c.avg, got[3])
 
 
 def test_chunk_group_beyond_2g_byte_tensors_equals_smaller_groups():
