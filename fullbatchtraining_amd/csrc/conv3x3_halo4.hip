@@ -599,18 +599,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
         };
         // masked addend (the residual-branch gradient d * (out > 0) of an identity block without a materialised copy): CO_T / 8 mask bytes per pixel, the
         // whole tile's requested up front like the BST mask
-        unsigned am[4][FI / 2];
-        const bool masked = EB == 2 && p.addend_mode == 1 && p.addend_mask != nullptr;
+        // (bf16: a mask byte covers the 8 channels of a 16-byte vector -- CO_T / 8 bytes per pixel; fp32: the 4 channels of one -- CO_T / 4 bytes, bits 0-3)
+        constexpr int AMW = EB == 4 ? FI : FI / 2;
+        unsigned am[4][AMW];
+        const bool masked = p.addend_mode == 1 && p.addend_mask != nullptr;
         if (masked) {
-            const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.addend_mask + (long long)cur.pt * 32 * p.Cd), 0, 32 * p.Cd, 0x00020000);
-            const int voffA = (wave * 64 + (lane & 15)) * (p.Cd >> 3);
+            constexpr int SH = EB == 4 ? 2 : 3;                  // log2(channels per mask byte)
+            const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.addend_mask + (((long long)cur.pt * 256 * p.Cd) >> SH)), 0, (256 * p.Cd) >> SH, 0x00020000);
+            const int voffA = (wave * 64 + (lane & 15)) * (p.Cd >> SH);
             h4_static_for<0, 4>([&](auto jc) {
                 constexpr int J = decltype(jc)::value;
-                const int soffA = (J * 16 * p.Cd + cur.ct * CO_T) >> 3;
-                if constexpr (FI == 4) {
+                const int soffA = (J * 16 * p.Cd + cur.ct * CO_T) >> SH;
+                if constexpr (AMW == 2) {
                     const h4_u32x2 m = __builtin_amdgcn_raw_buffer_load_b64(rsrcA, voffA, soffA, 0);
                     am[J][0] = m[0]; am[J][1] = m[1];
                 } else {
+                    static_assert(AMW == 4, "masked addend: 64-channel tiles (bf16: also 128)");
                     const h4_u32x4 m = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, voffA, soffA, 0);
                     am[J][0] = m[0]; am[J][1] = m[1]; am[J][2] = m[2]; am[J][3] = m[3];
                 }
@@ -619,7 +623,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = 0; i < FI / 2; ++i) am[j][i] = 0xffffffffu;
+                for (int i = 0; i < AMW; ++i) am[j][i] = 0xffffffffu;
         }
         if constexpr (BST) {
             const __amdgpu_buffer_rsrc_t rsrcN = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bst_mask + (long long)cur.pt * 32 * p.Cd), 0, 32 * p.Cd, 0x00020000);
@@ -653,7 +657,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FI == 8 ? 1
                 float v[4] = {acc[I][J][0], acc[I][J][1], acc[I][J][2], acc[I][J][3]};
                 if (p.addend_mode == 1) {
                     if constexpr (EB == 4) {
-                        const h4_u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrcE, voffD + I * 16 * EB, soff, 0);
+                        h4_u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrcE, voffD + I * 16 * EB, soff, 0);
+                        if (masked) {        // (fp32 storage: mask byte 4 I + g4 of the pixel's CO_T / 4 holds this lane's four channels in bits 0-3)
+                            const unsigned bits = am[J][I] >> (g4 * 8);
+                            a[0] &= (unsigned)__builtin_amdgcn_sbfe((int)bits, 0, 1); a[1] &= (unsigned)__builtin_amdgcn_sbfe((int)bits, 1, 1);
+                            a[2] &= (unsigned)__builtin_amdgcn_sbfe((int)bits, 2, 1); a[3] &= (unsigned)__builtin_amdgcn_sbfe((int)bits, 3, 1);
+                        }
                         v[0] += __uint_as_float(a[0]); v[1] += __uint_as_float(a[1]); v[2] += __uint_as_float(a[2]); v[3] += __uint_as_float(a[3]);
                     } else {
                         h4_u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(rsrcE, voffD + I * 16 * EB, soff, 0);
@@ -782,8 +791,8 @@ static int h4_variant(const fb_conv_args* a) {
     if ((long long)(imgs_per_tile * a->Hs * W + 2 * W + 2) * a->Cs * EB >= (1LL << 31)) return 0;
     const int n_pt = a->n_img * a->Hs * W / 256, n_ct = a->Cd / (wide ? 128 : 64);
     if ((long long)n_pt * n_ct * n_ct >= (1LL << 32) || (long long)a->n_img * imgs_per_wset >= (1LL << 32)) return 0;
-    // masked addend: bf16 input gradients with a same-shape addend (FB_H4_NO_MASK: A/B switch -- the engine then materialises d * (out > 0))
-    if (a->addend_mask && (a->dtype != FB_BF16 || a->mode != 1 || !a->addend || a->addend_mode != 1 || getenv("FB_H4_NO_MASK") != nullptr)) return 0;
+    // masked addend: input gradients with a same-shape addend, bf16 and fp32 storage (FB_H4_NO_MASK: A/B switch -- the engine then materialises d * (out > 0))
+    if (a->addend_mask && (a->mode != 1 || !a->addend || a->addend_mode != 1 || getenv("FB_H4_NO_MASK") != nullptr)) return 0;
     // fused BatchNorm-backward reduction: bf16 input gradients on 16x16 / 8x8 / 4x4 maps
     if (a->bst_x && (a->mode != 1 || !a->bst_mask || !a->stat_partial || a->dtype != FB_BF16 || W == 32)) return 0;
     return compact ? 3 : (wide ? 2 : 1);

@@ -870,11 +870,19 @@ def test_conv_masked_addend_equals_materialised_mask():
         lib.conv2d(dy2, w2, b2, 3, 3, 1, 1, 1, addend=d2, addend_mode=1, addend_mask=bits2)
         torch.cuda.synchronize()
         assert torch.equal(a2, b2), (C, hw2)
-    # a layer no kernel takes the mask for says so instead of ignoring it: fp32 storage, a 1x1 layer with K >= 512
-    d3 = torch.randn(n, 16, 16, 128, device="cuda")
-    with pytest.raises(lib.EngineError):
-        lib.conv2d(torch.randn(n, 16, 16, 128, device="cuda"), torch.randn(128, 9, 128, device="cuda"), torch.empty_like(d3), 3, 3, 1, 1, 1, addend=d3, addend_mode=1,
-                   addend_mask=bits)
+    # ... and with fp32 storage (the regulariser's passes): there fb_bn_apply's mask byte covers the FOUR channels of a 16-byte vector
+    for C, hw2 in ((64, 32), (128, 16), (256, 8)):
+        dy3 = torch.randn(n, hw2, hw2, C, device="cuda") * 0.1
+        w3 = torch.randn(C, 9, C, device="cuda") * 0.03
+        d3 = torch.randn(n, hw2, hw2, C, device="cuda")
+        act3 = torch.randn(n, hw2, hw2, C, device="cuda")
+        bits3 = ((act3.reshape(-1, 4) > 0).to(torch.int32) << torch.arange(4, device="cuda")).sum(1).to(torch.uint8)
+        a3, b3 = torch.empty_like(d3), torch.full_like(d3, float("nan"))
+        lib.conv2d(dy3, w3, a3, 3, 3, 1, 1, 1, addend=torch.where(act3 > 0, d3, torch.zeros_like(d3)), addend_mode=1)
+        lib.conv2d(dy3, w3, b3, 3, 3, 1, 1, 1, addend=d3, addend_mode=1, addend_mask=bits3)
+        torch.cuda.synchronize()
+        assert torch.equal(a3, b3), (C, hw2)
+    # a layer no kernel takes the mask for says so instead of ignoring it: a 1x1 layer with K >= 512
     d4 = torch.randn(n, 8, 8, 256, device="cuda").bfloat16()
     with pytest.raises(lib.EngineError):
         lib.conv2d(torch.randn(n, 8, 8, 1024, device="cuda").bfloat16(), torch.randn(256, 1, 1024, device="cuda").bfloat16(), torch.empty_like(d4), 1, 1, 1, 0, 1,
