@@ -317,7 +317,10 @@ __global__ __launch_bounds__(512) void conv1x1_gemm_kernel(const G1Params p) {
         __amdgpu_buffer_rsrc_t rsA = desc_a(0);
         issue_a(rsA, 0, 0);
         issue_a(rsA, 1, 1);
-        int a_ti = 0, a_ks = 2, sa = 0, sb = 0;
+        // the next round to issue is round 2 = (tile 2 / KS, K-step 2 % KS): with K = 128 (KS = 2) that is already the SECOND tile's first K-step (round 5 started
+        // at (0, 2) for every K: a K-step past the row's end, and a tile index that never moved on -- wrong pixel rows for every tile behind a workgroup's first)
+        int a_ti = 2 / KS, a_ks = 2 % KS, sa = 0, sb = 0;
+        if (a_ti != 0) rsA = desc_a(a_ti);
         bool after_epilogue = false;
         g1_wait_vmcnt<G1_PA>();                          // pixel round 0
         __builtin_amdgcn_s_barrier();                    // 0

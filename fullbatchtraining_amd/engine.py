@@ -60,12 +60,14 @@ class Block:
         self.convs, self.shortcut, self.stride, self.cin, self.hin, self.win = convs, shortcut, stride, cin, hin, win
 
 
-def max_group(plan, chunk, dtype, device=None, reserve_bytes=0):
+def max_group(plan, chunk, dtype, device=None, reserve_bytes=0, use_free=True):
     """Largest chunk group the fast kernels take.  fp32 storage: the biggest activation tensor (NHWC) stays below 2^31 bytes -- the fp32 LDS-DMA
     kernels address whole tensors with 32-bit buffer offsets and hand larger ones to the slower pointer-based kernels.  bf16: every kernel
     bases its descriptors at its own tile / K slice (round 3), so only a sanity limit of 2^35 bytes per tensor remains (the persistent
     kernels' tile counts are 32-bit) -- and the device's memory: ``reserve_bytes`` = what the caller will allocate beside the engine (the stem's
-    pre-gathered patches of the rank's whole shard, resident images)."""
+    pre-gathered patches of the rank's whole shard, resident images).  ``use_free=False``: a DETERMINISTIC cap -- the device's total memory only, never what happens
+    to be free of it now (other processes, allocator state): the caller derives the NOMINAL group from it, the number the weight gradients' K-slice counts are sized
+    for, which has to be the same on every rank of a job and in every run (``FullBatchTrainer``: whole-problem reserve, MIN over the ranks)."""
     # (the stem's pre-gathered patches -- 7x7x3 -> 160 values per pixel for the ImageNet stem, the largest tensor by far -- do not count: the two
     # launches that read them are cut into chunk ranges below 2^31 bytes, Engine._stem_ranges; ResNet-152 @224: groups of 10 chunks instead of 4)
     per_image = max(max(L.hout * L.wout * L.cout, L.hin * L.win * (L.cin_pad if L is not plan.stem else 0)) for L in plan.layers)
@@ -87,7 +89,7 @@ def max_group(plan, chunk, dtype, device=None, reserve_bytes=0):
     else:
         total = free = 288 << 30
     frac = float(os.environ.get("FB_GROUP_MEM_FRAC", "0.9"))
-    budget = max(0, min(int(total * frac), free) - int(reserve_bytes))
+    budget = max(0, (min(int(total * frac), free) if use_free else int(total * frac)) - int(reserve_bytes))
     return max(cap31, min((1 << 35) // (chunk * per_image * es), budget // (chunk * per_image_bytes)))
 
 
@@ -1070,24 +1072,35 @@ class Engine:
     def choose_schedule(self, patches, labels, n_chunks):
         """The stream choice of a wide Bottleneck net NOW, if it is still pending (otherwise the first full_gradient call makes it): a caller that times its first
         step (bench.py with --warmup 0) keeps the four extra group passes out of it.  ``patches`` / ``labels``: the rank's chunks as full_gradient takes them."""
-        if self.stream_autotune and n_chunks > 0:
+        if self.stream_autotune and (n_chunks > 0 or (torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1)):
             self.stream_autotune = False
             g_n = min(self.G, n_chunks)
             self._autotune_streams(patches[:g_n * self.chunk], labels[:g_n * self.chunk], g_n)
 
     def _autotune_streams(self, xb, yb, g_n):
         """Times one chunk group (forward + backward into ``self.g``, which the caller's first group overwrites) with the weight gradients on their own
-        stream and with everything on one stream, and keeps the faster schedule (two streams unless one is at least 0.5 % faster).  The group pass has no
-        side effects beyond its own buffers: running statistics and the mean gradient are updated by full_gradient, not here."""
-        two, times = self.wstream, {}
-        for label, ws in (("two", two), ("one", None)):
-            self.wstream = ws
-            self.group_gradient(xb, yb, g_n, self.g, 1, self.theta, 0)          # (records the launch sequence / warms the caches)
-            torch.cuda.synchronize(self.device)
-            t0 = time.perf_counter()
-            self.group_gradient(xb, yb, g_n, self.g, 1, self.theta, 0)
-            torch.cuda.synchronize(self.device)
-            times[label] = time.perf_counter() - t0
+        stream and with everything on one stream -- the MEDIAN of three passes each, alternating (the measured effects are 1-1.5 %, one sample's noise is of that
+        size) -- and keeps the faster schedule (two streams unless one is at least 0.5 % faster).  In a job of several ranks rank 0's times decide for all (the two
+        schedules give the same bits, but per-rank choices would make step times and the reported ``streams`` depend on noise).  The group pass has no side
+        effects beyond its own buffers: running statistics and the mean gradient are updated by full_gradient, not here."""
+        two, samples = self.wstream, {"two": [0.0] * 3, "one": [0.0] * 3}
+        if g_n > 0:
+            samples = {"two": [], "one": []}
+        for rep in range(4 if g_n > 0 else 0):           # (pass 0 records the launch sequences / warms the caches; a rank without chunks only takes rank 0's answer)
+            for label, ws in (("two", two), ("one", None)):
+                self.wstream = ws
+                torch.cuda.synchronize(self.device)
+                t0 = time.perf_counter()
+                self.group_gradient(xb, yb, g_n, self.g, 1, self.theta, 0)
+                torch.cuda.synchronize(self.device)
+                if rep > 0:
+                    samples[label].append(time.perf_counter() - t0)
+        times = {k: sorted(v)[1] for k, v in samples.items()}
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            t = torch.tensor([times["two"], times["one"]], dtype=torch.float64,
+                             device=self.device if torch.distributed.get_backend() == "nccl" else "cpu")
+            torch.distributed.broadcast(t, 0)
+            times = {"two": float(t[0]), "one": float(t[1])}
         self.stream_times = times
         self.wstream = None if times["one"] < 0.995 * times["two"] else two
 
@@ -1196,7 +1209,7 @@ class Engine:
         # With several groups per step the running-mean pass of group k (HBM-bound, 2 x G x 45 MB) runs on the weight-gradient stream
         # beside the forward convolutions of group k+1; the per-chunk gradients then alternate between two arenas (the main stream
         # writes dgamma / dbeta / fc gradients of group k+1 while group k is still being folded in).
-        if self.stream_autotune:
+        if self.stream_autotune and (n_chunks > 0 or (torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1)):
             self.stream_autotune = False
             g_n = min(G, n_chunks)
             self._autotune_streams(patches[k_first * chunk:(k_first + g_n) * chunk], labels[k_first * chunk:(k_first + g_n) * chunk], g_n)

@@ -451,11 +451,25 @@ class FullBatchTrainer:
         es = torch.empty((), dtype=self.dtype).element_size()
         own = self.shard.count * self.chunk_pad * plan.stem.hout * plan.stem.wout * plan.stem.cin_pad * es + self.shard.count * self.chunk * X[0].numel() * 4
         want, cap = int(cfg.impl.get("engine", {}).get("chunk_group", 98)), max_group(plan, self.chunk_pad, self.dtype, self.device, reserve_bytes=own)
-        G = group_size(self.shard.count, want, cap=cap)
-        # K-slice counts of the weight gradients are sized for the group of the WHOLE problem on one GPU -- the same number on every rank, so
-        # that a chunk's summation order (hence its gradient, bit for bit) does not depend on the number of GPUs
+        # K-slice counts of the weight gradients are sized for the group of the WHOLE problem on one GPU -- the same number on every rank and in every run, so
+        # that a chunk's summation order (hence its gradient, bit for bit) does not depend on the number of GPUs, on what else runs on the device or on the
+        # allocator's state: the nominal cap comes from the device's TOTAL memory less what the 1-process run would keep resident (not from free memory, not from
+        # this rank's share), and a job of several ranks takes the smallest of its ranks' values
+        own_whole = self.n_chunks * self.chunk_pad * plan.stem.hout * plan.stem.wout * plan.stem.cin_pad * es + self.n_chunks * self.chunk * X[0].numel() * 4
+        cap_nominal = max_group(plan, self.chunk_pad, self.dtype, self.device, reserve_bytes=own_whole, use_free=False)
+        if self.world > 1:
+            t = torch.tensor([cap_nominal], dtype=torch.int64, device=self.device if torch.distributed.get_backend() == "nccl" else "cpu")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+            cap_nominal = int(t.item())
+        nominal = group_size(self.n_chunks, want, cap=cap_nominal)
+        # this rank's own group: what is free NOW is a safety clamp on top (a rank's share is never cut larger than the nominal cap allows a whole problem's)
+        if cap < min(cap_nominal, max(self.shard.count, 1)):
+            log.warning(f"chunk group capped at {cap} chunks by the device's free memory (the nominal cap from its total memory is {cap_nominal}); "
+                        "results are unchanged, launches are smaller")
+        G = group_size(self.shard.count, want, cap=min(cap, cap_nominal))
+        log.info(f"chunk groups: {G} chunks per launch on this rank ({self.shard.count} chunks), K-slice counts sized for a nominal group of {nominal}")
         self.engine = Engine(model, X.shape[-1], self.chunk_pad, G, compute_dtype=self.dtype, device=self.device, fd_sets=fd_sets,
-                             arena_align=64 * self.world, chunk_valid=self.chunk, nominal_group=group_size(self.n_chunks, want, cap=cap),
+                             arena_align=64 * self.world, chunk_valid=self.chunk, nominal_group=nominal,
                              f32_split=str(cfg.impl.get("engine", {}).get("fd_arithmetic", "bf16x6")) if fd else None)
         self.engine.label_smoothing = getattr(self.loss_fn, "smoothing", 0.0)
         self.engine.only_incorrect = getattr(self.loss_fn, "only_incorrect", False)

@@ -368,6 +368,90 @@ def test_sharded_step_matches_single_process(tmp_path, bucketed, K, world):
         assert torch.equal(outs[0]["theta"], o["theta"])
 
 
+def _chunk_vector(k, P):
+    return torch.randn(P, generator=torch.Generator().manual_seed(1000 + k))
+
+
+def _worker_arena(rank, world, port, K, depth, out_dir):
+    """A rank of the bucketed exchange on the arena of a real Bottleneck plan (ResNet-50, 'standard' stem): bounds from parallel.exchange_bounds."""
+    import sys
+    import types
+    sys.path.insert(0, REPO)
+    from fullbatchtraining_amd.cfg import compose
+    from fullbatchtraining_amd.engine import Plan
+    from fullbatchtraining_amd.models import construct_model
+    from fullbatchtraining_amd.parallel import BucketExchange, ShardOps, ShardPlan, exchange_bounds
+
+    from tests.helpers import pg_timeout
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, timeout=pg_timeout())
+    cfg = compose([f"model=resnet{depth}", "model.stem=standard"])
+    torch.manual_seed(0)
+    arena = Plan(construct_model(cfg.model, 3, 1000), 64, arena_align=64 * world)
+    P = arena.P
+    plan = ShardPlan(K, world, rank)
+    bounds = exchange_bounds(types.SimpleNamespace(engine=types.SimpleNamespace(plan=arena), shard=plan))
+    gen = torch.Generator().manual_seed(7)
+    theta, mom = torch.randn(P, generator=gen), torch.randn(P, generator=gen) * 0.1
+    avg = torch.zeros(P)
+    for j, k in enumerate(range(plan.first, plan.first + plan.count)):
+        avg += (_chunk_vector(k, P) - avg) / (j + 1)
+    lr, wd, mu, clip = 0.1, 5e-4, 0.9, 0.25
+
+    def update(lo, n, gnorm2):
+        norm = gnorm2.sqrt()
+        coef = clip / (norm + 1e-6) if norm > clip else torch.tensor(1.0)
+        gr = avg[lo:lo + n] * coef
+        avg[lo:lo + n] = gr
+        d = gr + wd * theta[lo:lo + n]
+        mom[lo:lo + n] = mu * mom[lo:lo + n] + d
+        theta[lo:lo + n] -= lr * (d + mu * mom[lo:lo + n])
+
+    ex = BucketExchange(avg, theta, plan, ShardOps(scale=lambda t, a: t.mul_(a), sqnorm=lambda t: t.pow(2).sum(), update=update), bounds)
+    if rank % 2 == 0:                      # half of the ranks start the late bucket early (the engine: from inside the last backward pass)
+        ex.start(1)
+    gnorm2 = ex.finish()
+    if rank in (0, world - 1):
+        torch.save(dict(theta=theta, gnorm2=gnorm2, bounds=bounds, owned=ex.ranges(), mom=mom.clone(), P=P,
+                        late_offset=arena.late_offset, conv1=arena.offsets[f"layers.{3}.0.conv1.weight"]), os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_bucketed_exchange_on_a_bottleneck_arena_world8(tmp_path):
+    """Config 5's 8-GPU exchange on the gloo stand-in: the arena of a real Bottleneck plan (ResNet-50, 'standard' stem, 1000 classes: 25.6 M parameters), K = 16 chunks on
+    8 ranks (two each), two buckets cut by ``parallel.exchange_bounds`` -- the late one starts at the first parameter of the last stage (``layers.3.0.conv1.weight``, rounded
+    up to the shard granule lcm(4, world): what the backward pass has completed when ``on_block_done(plan.late_block)`` fires) and both split evenly over the ranks -- against
+    the 1-process step on the exact mean (the oracle's SGD)."""
+    from oracle import fb_oracle as orc
+    from tests.helpers import spawn_bounded
+
+    K, world = 16, 8
+    spawn_bounded(_worker_arena, (world, _free_port(), K, 50, str(tmp_path)), world, timeout=240)
+    outs = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in (0, world - 1)]
+    P, bounds = outs[0]["P"], outs[0]["bounds"]
+    granule = 8
+    assert bounds[0] == 0 and bounds[2] == P and P % (64 * world) == 0
+    assert outs[0]["late_offset"] == outs[0]["conv1"] and 0 <= bounds[1] - outs[0]["conv1"] < granule        # a parameter boundary of the last stage's first layer
+    assert bounds[1] % granule == 0 and (P - bounds[1]) % world == 0 and 0.5 < (P - bounds[1]) / P < 0.7     # 15 M of ResNet-50's 25.6 M parameters leave early
+    mean = torch.zeros(P)
+    for k in range(K):
+        mean += _chunk_vector(k, P) / K
+    gen = torch.Generator().manual_seed(7)
+    theta, mom = torch.randn(P, generator=gen), torch.randn(P, generator=gen) * 0.1
+    norm = mean.double().norm().float()          # (torch's fp32 norm of 25.6 M elements on the host is 0.15 % off)
+    grad = mean * (0.25 / (norm + 1e-6)) if norm > 0.25 else mean
+    params, momentum = {"w": theta.clone()}, [mom.clone()]
+    orc.sgd_step(params, [grad], momentum, 0.1, dict(momentum=0.9, weight_decay=5e-4, dampening=0.0, nesterov=True))
+    for o in outs:
+        assert torch.allclose(o["theta"], params["w"], rtol=1e-5, atol=1e-7)
+        assert torch.allclose(o["gnorm2"], norm ** 2, rtol=1e-5)
+        for lo, n in o["owned"]:
+            assert torch.allclose(o["mom"][lo:lo + n], momentum[0][lo:lo + n], rtol=1e-5, atol=1e-6)
+    assert torch.equal(outs[0]["theta"], outs[1]["theta"])
+    # the two ranks own different ranges of BOTH buckets
+    assert outs[0]["owned"][0][0] == 0 and outs[1]["owned"][1][0] + outs[1]["owned"][1][1] == P
+
+
 def test_bench_line_stays_below_4k_on_a_canned_run():
     """The driver parses the LAST stdout line of bench.py out of a bounded tail (round 3's 23 KB line came back ``parsed: null``): the line is
     assembled by bench.assemble_line, which keeps numbers only and moves tables / notes / sources to gpurun_out/bench_detail.json.  Canned input:

@@ -31,13 +31,14 @@ def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
 
 
-def _nchw(t):
-    return t.float().cpu().double().permute(0, 3, 1, 2)
+def _nchw(t, device):
+    """device NHWC -> NCHW float64 on ``device`` (the oracle's: on a GPU box the comparison never leaves the device -- a ResNet-50 walk at 224 px compares ~6 G elements)"""
+    return t.to(device).double().permute(0, 3, 1, 2)
 
 
 def _close(got_nhwc, ref_nchw, what, report):
     ref = ref_nchw.double()
-    got = _nchw(got_nhwc).to(ref.device)
+    got = _nchw(got_nhwc, ref.device)
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     diff = (got - ref).abs()
     rms = float(ref.pow(2).mean().sqrt())
@@ -63,23 +64,25 @@ def _mask_bytes(positive_nchw):
     return (bits * weights).sum(1).to(torch.uint8).cuda()
 
 
-def test_resnet18_bf16_kernels_layer_by_layer_against_the_oracle():
+def _walk(depth, stem, pixels, chunk, classes=10):
+    """Forward and backward walk through ``resnet<depth>`` with the given stem: every production bf16 launch on the oracle's own tensors.  Returns the report
+    [(what, relative L2, fraction beyond 2 ulp)]."""
     from fullbatchtraining_amd.cfg import compose
     from fullbatchtraining_amd.engine import Engine, stem_patches
     from fullbatchtraining_amd.lib import call
     from fullbatchtraining_amd.models import construct_model
     from oracle import fb_oracle as orc
 
-    pixels, chunk, G = 32, 128, 1
-    cfg = compose([])
+    G = 1
+    cfg = compose([f"model=resnet{depth}", f"model.stem={stem}"])
     torch.manual_seed(0)
-    model = construct_model(cfg.model, 3, 10)
+    model = construct_model(cfg.model, 3, classes)
     eng = Engine(model, pixels, chunk, G, compute_dtype=torch.bfloat16)
     eng.use_replay = False                       # primitives are called one by one with injected tensors
     plan = eng.plan
-    x, y = make_data(chunk, pixels)
+    x, y = make_data(chunk, pixels, classes)
     q = lambda t: t.to(torch.bfloat16).to(t.dtype)          # noqa: E731  (orc.bf16_round returns float32; the walk runs in float64)
-    spec = orc.Spec(18)
+    spec = orc.Spec(depth, stem=stem, classes=classes)
     params, buffers = oracle_state(model)                  # the walk runs on the oracle's device (tests/helpers.oracle_device)
     xo, yo = to_oracle(x, y)
     logits_o, tape = orc.forward(spec, params, buffers, xo, q, update_bn=False, train=True)
@@ -90,7 +93,7 @@ def test_resnet18_bf16_kernels_layer_by_layer_against_the_oracle():
     eng.prep_weights(eng.theta, 1)
 
     def grad_of(name):
-        return eng._unflatten(gout[0].cpu(), name)
+        return eng._unflatten(gout[0], name)
 
     def put_mask(act, positive):
         eng._mask_of(act).copy_(_mask_bytes(positive))
@@ -112,22 +115,33 @@ def test_resnet18_bf16_kernels_layer_by_layer_against_the_oracle():
     patches = stem_patches(x.cuda(), plan.stem, torch.bfloat16)
     fwd_conv(plan.stem, patches, stem_e["rec"], "stem")
     eng._bn_apply(plan.stem, eng.stem_out, G)
-    _close(eng.stem_out, stem_e["out"], "stem BN+ReLU", report)
-    eng.stem_out.copy_(_nhwc(stem_e["out"]))
-    put_mask(eng.stem_out, stem_e["out"] > 0)
+    stem_act = stem_e["relu_out"] if plan.stem_pool else stem_e["out"]
+    _close(eng.stem_out, stem_act, "stem BN+ReLU", report)
+    eng.stem_out.copy_(_nhwc(stem_act))
+    put_mask(eng.stem_out, stem_act > 0)
     a_prev = eng.stem_out
+    if plan.stem_pool:                           # MaxPool2d(3, 2, 1) of the ImageNet stem, remembering its argmax (reference resnets.py:74-79)
+        s_ = plan.stem
+        assert eng.stem_pool_idx is not None
+        call("fb_maxpool3s2_fwd_idx", eng.stem_out.data_ptr(), eng.stem_pooled.data_ptr(), eng.stem_pool_idx.data_ptr(), G * chunk, s_.hout, s_.wout, 64, eng.dtc)
+        _close(eng.stem_pooled, stem_e["out"], "stem MaxPool2d(3,2,1)", report)
+        assert torch.equal(eng.stem_pooled, _nhwc(stem_e["out"]))          # (a selection: no rounding at all)
+        a_prev = eng.stem_pooled
     for bi, b in enumerate(plan.blocks):
         e = tape[1 + bi]
         tag = f"block {bi}"
-        c1, c2 = b.convs
-        r1, r2 = e["recs"]
+        recs = e["recs"]
         nxt = plan.blocks[bi + 1] if bi + 1 < len(plan.blocks) else None
-        fwd_conv(c1, a_prev, r1, f"{tag} conv1")
-        eng._bn_apply(c1, b.mids[0], G)
-        _close(b.mids[0], e["mids"][0], f"{tag} BN1+ReLU", report)
-        b.mids[0].copy_(_nhwc(e["mids"][0]))
-        put_mask(b.mids[0], e["mids"][0] > 0)
-        fwd_conv(c2, b.mids[0], r2, f"{tag} conv2")
+        cur = a_prev
+        for i, L in enumerate(b.convs[:-1]):
+            fwd_conv(L, cur, recs[i], f"{tag} conv{i + 1}")
+            eng._bn_apply(L, b.mids[i], G)
+            _close(b.mids[i], e["mids"][i], f"{tag} BN{i + 1}+ReLU", report)
+            b.mids[i].copy_(_nhwc(e["mids"][i]))
+            put_mask(b.mids[i], e["mids"][i] > 0)
+            cur = b.mids[i]
+        last = b.convs[-1]
+        fwd_conv(last, cur, recs[-1], f"{tag} conv{len(b.convs)}")
         next_pool = nxt.pooled if nxt is not None else None
         if b.shortcut is not None:
             src = a_prev
@@ -138,10 +152,10 @@ def test_resnet18_bf16_kernels_layer_by_layer_against_the_oracle():
                 b.pooled.copy_(_nhwc(e["rd"]["x"]))
                 src = b.pooled
             fwd_conv(b.shortcut, src, e["rd"], f"{tag} shortcut conv")
-            fused = eng._bn_apply(c2, b.out, G, res=b.shortcut.x, resL=b.shortcut, pool=next_pool)
+            fused = eng._bn_apply(last, b.out, G, res=b.shortcut.x, resL=b.shortcut, pool=next_pool)
         else:
-            fused = eng._bn_apply(c2, b.out, G, res=a_prev, pool=next_pool)
-        _close(b.out, e["out"], f"{tag} BN2 + residual + ReLU", report)
+            fused = eng._bn_apply(last, b.out, G, res=a_prev, pool=next_pool)
+        _close(b.out, e["out"], f"{tag} last BN + residual + ReLU", report)
         if fused:                                  # the pooled copy of this output for the next block's shortcut, written by the same pass
             _close(nxt.pooled, q(orc.avgpool2_fwd(e["out"])), f"{tag} fused pooled output", report)
         b.out.copy_(_nhwc(e["out"]))
@@ -191,26 +205,29 @@ def test_resnet18_bf16_kernels_layer_by_layer_against_the_oracle():
     def oracle_dx(rec, dxc_q):
         return torch.nn.grad.conv2d_input(rec["x"].shape, rec["w"], dxc_q, rec["stride"], rec["pad"])
 
+    stem_res = eng.stem_pooled if plan.stem_pool else eng.stem_out
     for bi in range(len(plan.blocks) - 1, -1, -1):
         b, e = plan.blocks[bi], tape[1 + bi]
         tag = f"block {bi}"
-        c1, c2 = b.convs
-        r1, r2 = e["recs"]
-        a0_dev = plan.blocks[bi - 1].out if bi > 0 else eng.stem_out
+        recs = e["recs"]
+        first = b.convs[0]
+        a0_dev = plan.blocks[bi - 1].out if bi > 0 else stem_res
+        srcs = [a0_dev] + b.mids
         d_dev = _nhwc(da)
         dy_o = q(da * (e["out"] > 0))
         out_bits = eng.masks.get(b.out.data_ptr())
-        lazy = b.shortcut is not None or eng._masked_addend_ok(c1, G, 1)
-        # conv2 / bn2 (the gradient enters through the block output's ReLU mask)
-        dxc2_q, dx2_dev = bwd_layer(c2, r2, d_dev, b.out, dy_o, b.mids[0], f"{tag} conv2", want_dy=not lazy)
-        d_mid = eng._dgrad(c2, dx2_dev, G, 1)
-        d_mid_o = q(oracle_dx(r2, dxc2_q))
-        _close(d_mid, d_mid_o, f"{tag} conv2 input gradient", report)
-        eng.pool.put(d_mid)
-        # conv1 / bn1
-        dy1_o = q(d_mid_o * (e["mids"][0] > 0))
-        dxc1_q, dx1_dev = bwd_layer(c1, r1, _nhwc(d_mid_o), b.mids[0], dy1_o, a0_dev, f"{tag} conv1")
-        dx0_o = oracle_dx(r1, dxc1_q)
+        lazy = b.shortcut is not None or eng._masked_addend_ok(first, G, 1)
+        # last conv / BatchNorm of the block (the gradient enters through the block output's ReLU mask), then down the chain
+        nc = len(b.convs)
+        dxc_q, dx_dev = bwd_layer(b.convs[-1], recs[-1], d_dev, b.out, dy_o, srcs[-1], f"{tag} conv{nc}", want_dy=not lazy)
+        for i in range(nc - 1, 0, -1):
+            d_mid = eng._dgrad(b.convs[i], dx_dev, G, 1)
+            d_mid_o = q(oracle_dx(recs[i], dxc_q))
+            _close(d_mid, d_mid_o, f"{tag} conv{i + 1} input gradient", report)
+            eng.pool.put(d_mid)
+            dy_mid_o = q(d_mid_o * (e["mids"][i - 1] > 0))
+            dxc_q, dx_dev = bwd_layer(b.convs[i - 1], recs[i - 1], _nhwc(d_mid_o), b.mids[i - 1], dy_mid_o, srcs[i - 1], f"{tag} conv{i}")
+        dx0_o = oracle_dx(recs[0], dxc_q)
         if b.shortcut is not None:
             S, rd = b.shortcut, e["rd"]
             src = b.pooled if b.pooled is not None else a0_dev
@@ -219,23 +236,64 @@ def test_resnet18_bf16_kernels_layer_by_layer_against_the_oracle():
             dp_o = q(oracle_dx(rd, dxcs_q))
             _close(d_p, dp_o, f"{tag} shortcut input gradient", report)
             eng.pool.put(d_p)
-            d_in = eng._dgrad(c1, dx1_dev, G, 1, addend=_nhwc(dp_o), addend_mode=2 if b.pooled is not None else 1)
+            d_in = eng._dgrad(first, dx_dev, G, 1, addend=_nhwc(dp_o), addend_mode=2 if b.pooled is not None else 1)
             d_o = dx0_o + (orc.avgpool2_bwd(dp_o) if b.stride == 2 else dp_o)
         elif lazy:
-            d_in = eng._dgrad(c1, dx1_dev, G, 1, addend=d_dev, addend_mode=1, addend_mask=out_bits)
+            d_in = eng._dgrad(first, dx_dev, G, 1, addend=d_dev, addend_mode=1, addend_mask=out_bits)
             d_o = dx0_o + dy_o
         else:
-            d_in = eng._dgrad(c1, dx1_dev, G, 1, addend=_nhwc(dy_o), addend_mode=1)
+            d_in = eng._dgrad(first, dx_dev, G, 1, addend=_nhwc(dy_o), addend_mode=1)
             d_o = dx0_o + dy_o
         da = q(d_o)
-        _close(d_in, da, f"{tag} input gradient (conv1 dgrad + residual branch)", report)
+        _close(d_in, da, f"{tag} input gradient (conv1 dgrad + residual branch{', masked addend' if (lazy and b.shortcut is None) else ''})", report)
         eng.pool.put(d_in)
-    dy_o = q(da * (stem_e["out"] > 0))
-    bwd_layer(plan.stem, stem_e["rec"], _nhwc(da), eng.stem_out, dy_o, patches, "stem")
+    S = plan.stem
+    if plan.stem_pool:
+        # MaxPool backward from the remembered argmax (the oracle scatters through torch's own indices of the same rounded tensor)
+        r = stem_e["relu_out"]
+        dr = torch.zeros_like(r).flatten(2)
+        dr.scatter_add_(2, stem_e["pool_idx"].flatten(2), da.flatten(2))
+        dr = q(dr.view_as(r))
+        d_r = eng.pool.get((n, S.hout, S.wout, 64))
+        call("fb_maxpool3s2_bwd_idx", eng.stem_pool_idx.data_ptr(), _nhwc(da).data_ptr(), d_r.data_ptr(), n, S.hout, S.wout, 64, eng.dtc)
+        _close(d_r, dr, "stem MaxPool backward", report)
+        eng.pool.put(d_r)
+        da = dr
+    dy_o = q(da * (stem_act > 0))
+    bwd_layer(S, stem_e["rec"], _nhwc(da), eng.stem_out, dy_o, patches, "stem")
+    if eng._wgrad_bn_ok(S, eng.stem_out):
+        # the production form of the stem's backward: no dx tensor -- the weight gradient applies the BatchNorm backward in its operand loader
+        gout[0, S.w_off:S.w_off + S.cout * S.taps * S.cin_real].zero_()
+        d_dev = _nhwc(da)
+        eng._bn_bwd(S, d_dev, eng.stem_out, G, gout, 0, want_dy=False, apply=False)
+        eng._wgrad(S, patches, None, G, gout, bn=(d_dev, eng.stem_out))
+        sync_wgrad()
+        rec = stem_e["rec"]
+        dxc, _, _ = orc.bn_train_bwd(dy_o, rec["gamma"], rec["bn"])
+        _, dw = orc.conv_bwd(rec["x"], rec["w"], q(dxc), rec["stride"], rec["pad"], need_dx=False)   # (dx becomes a bf16 MFMA operand in the loader: the same rounding point)
+        _close_f32(grad_of(f"{S.conv_name}.weight"), dw, "stem weight gradient (BatchNorm backward in the loader)", report, 1e-3)
     torch.cuda.synchronize()
 
     worst = sorted(report, key=lambda r: -r[1])[:8]
-    print(f"{len(report)} tensors compared; largest relative L2 distances:")
+    print(f"resnet{depth} / {stem} stem / {pixels} px / chunk {chunk}: {len(report)} tensors compared; largest relative L2 distances:")
     for what, rel, bad in worst:
         print(f"  {what}: {rel:.3e} ({bad:.1e} of the elements beyond 2 ulp)")
+    return report
+
+
+def test_resnet18_bf16_kernels_layer_by_layer_against_the_oracle():
+    report = _walk(18, "CIFAR", 32, 128)
     assert len(report) > 180
+
+
+@pytest.mark.parametrize("pixels,chunk", [(64, 32), (224, 128)])
+def test_resnet50_bottleneck_bf16_kernels_layer_by_layer_against_the_oracle(pixels, chunk):
+    """The Bottleneck path of bench.py's ResNet-152 lines (reference resnets.py:271-316, 'standard' stem :74-79), kernel by kernel: ResNet-50 has every layer shape
+    of ResNet-152 (the deeper net repeats the identity blocks of stages 2 and 3).  At 224 px with one chunk of 128 images these are the production launches of
+    BASELINE config 5's bf16 form: the 7x7 stem on 160-value patches and its 64 x 160 weight-gradient tile, MaxPool with a remembered argmax, streaming / pipelined
+    1x1 kernels on 56 / 28 / 14 / 7 maps incl. the masked residual addend of the identity blocks, the all-taps 3x3 weight gradients on ImageNet-shaped maps, the
+    1x1 weight-gradient GEMM, stride-2 3x3 layers, shortcuts with and without AvgPool; 64 px / chunks of 32: the shapes of the engine-level oracle tests."""
+    report = _walk(50, "standard", pixels, chunk)
+    names = [r[0] for r in report]
+    assert sum("masked addend" in w for w in names) >= 10 and any("MaxPool backward" in w for w in names)
+    assert len(report) > 500

@@ -217,6 +217,124 @@ def test_bottleneck_standard_stem_chunk_gradients_vs_oracle():
         assert rel_err(got[g][-2].numpy(), truth[g][0][-2].numpy()) < 1e-4
 
 
+@pytest.mark.parametrize("c1g,bn3_gamma", [(None, None), ("1", None), (None, 0.25), ("1", 0.25)])
+def test_bottleneck_standard_stem_bf16_chunk_gradients_vs_oracle(c1g, bn3_gamma, monkeypatch):
+    """The bf16 Bottleneck path -- the arithmetic of bench.py's ResNet-152 lines (reference resnets.py:296-316 under impl.mixed_precision, training.py:76-83) --
+    against the float64 oracle with the yardsticks of the ResNet-18 bf16 case: ResNet-50, 'standard' stem (7x7/s2 on pre-gathered patches, MaxPool with a
+    remembered argmax), 64 px, three chunks of 32 in ONE group so that the identity blocks take their residual gradient through the ReLU bitmask inside the
+    streaming 1x1 input gradients (asserted: the engine reports masked addends for them) -- with the shipped dispatch, and with FB_C1G=1 (every 1x1 forward
+    call the 256 x 256 GEMM kernel can take goes there: the dispatch of the large groups of the ResNet-152 bench).  Held to: per chunk, distance to the float64 truth <= 1.15 x torch's own
+    autocast(bf16) (and the rounding-emulating oracle's) and cosine >= torch's - 0.01, classifier gradient <= 1.15 x torch's; at the better-conditioned point (``bn3_gamma``)
+    also loss 2e-3 from the rounding-emulating oracle, classifier gradient 5e-2, cosine > 0.88; the stem's batch statistics and the MaxPool output against torch."""
+    from oracle import fb_oracle as orc
+    from tests.helpers import err_cos, flat64, torch_bf16_chunk_grads
+    if c1g is not None:
+        monkeypatch.setenv("FB_C1G", c1g)
+    pixels, chunk, G = 64, 32, 3
+    dt = torch.bfloat16
+    cfg, model, eng, stem_patches = _build(50, pixels, chunk, G, dt, stem="standard")
+    if bn3_gamma is not None:
+        # a better-conditioned point of the same net: the last BatchNorm of every block scaled down (towards the zero-init-residual start of reference
+        # resnets.py:120-126), so that the residual branches perturb the identity path instead of doubling its variance sixteen times -- ReLU-mask flips of rounded
+        # pre-activations then move the gradient by tens of per cent instead of replacing it, and an error of a few per cent in one kernel becomes visible end to end
+        with torch.no_grad():
+            for name, p_ in model.named_parameters():
+                if name.endswith("bn3.weight"):
+                    p_.fill_(bn3_gamma)
+        eng.load_from_model(model)
+    x, y = make_data(chunk * G, pixels)
+    truth, _, _ = _oracle_chunk_grads(model, x, y, chunk, depth=50, stem="standard")
+    ref, params, buffers = _oracle_chunk_grads(model, x, y, chunk, depth=50, stem="standard", emulate_bf16=True)
+    # which blocks hand their residual gradient to the 1x1 input gradient as (d, ReLU bitmask of the block output): every identity block whose conv1 has up to 256
+    # output channels (the streaming kernels' K; the two 512-channel identity blocks of the last stage materialise d * (out > 0) as before)
+    lazy = [b.shortcut is None and eng._masked_addend_ok(b.convs[0], G, 1) for b in eng.plan.blocks]
+    assert lazy == [b.shortcut is None and b.convs[0].cout <= 256 for b in eng.plan.blocks] and sum(lazy) == 10, lazy
+    patches = stem_patches(x.cuda(), eng.plan.stem, dt)
+    eng.prep_weights(eng.theta, 1)
+    eng.group_gradient(patches, y.cuda(), G, eng.g)
+    torch.cuda.synchronize()
+    got = _engine_grads_as_lists(eng, G)
+    yard = torch_bf16_chunk_grads(model, x, y, chunk)
+    rows = []
+    for g in range(G):
+        t = flat64(truth[g][0])
+        rows.append((err_cos(flat64(got[g]), t), err_cos(flat64(ref[g][0]), t), err_cos(flat64(yard[g][0]), t)))
+        (e_eng, c_eng), (e_orc, c_orc), (e_tch, c_tch) = rows[-1]
+        print(f"[resnet50 bf16, FB_C1G={c1g}, bn3 gamma {bn3_gamma}] chunk {g}: engine {e_eng:.3f} / cos {c_eng:.4f}; rounding-emulating oracle {e_orc:.3f} / {c_orc:.4f}; "
+              f"torch autocast(bf16) {e_tch:.3f} / {c_tch:.4f}; loss {float(eng.loss[g]):.5f} vs {ref[g][1]:.5f} (truth {truth[g][1]:.5f}, torch {yard[g][1]:.5f}); "
+              f"classifier gradient {rel_err(got[g][-2].numpy(), truth[g][0][-2].numpy()):.2e} (torch {rel_err(yard[g][0][-2].numpy(), truth[g][0][-2].numpy()):.2e})")
+    # Measured (MI355X): at random initialisation a 32-image bf16 chunk gradient of this 53-layer net is mostly ReLU-mask noise in EVERY bf16 evaluation -- engine 1.25-1.29
+    # from the float64 truth (cosine 0.17-0.22), the float64 oracle that only rounds at the engine's storage points 1.26-1.27 (0.19-0.21), torch's own autocast 1.24-1.28
+    # (0.18-0.21); losses scatter by 0.2-1.3 % around the truth in all three, the classifier gradient is 0.21-0.23 off in engine and torch alike.  So the assertions are
+    # the yardstick ones (no noisier than torch's bf16, chunk by chunk) plus sanity bounds; what pins the kernels is tests/test_gpu_bf16_structural.py (2 ulp per tensor).
+    for g in range(G):
+        (e_eng, c_eng), (e_orc, c_orc), (e_tch, c_tch) = rows[g]
+        assert abs(float(eng.loss[g]) - truth[g][1]) < 3e-2 * abs(truth[g][1]), (g, float(eng.loss[g]), truth[g][1])
+        assert abs(float(eng.loss[g]) - ref[g][1]) < 1e-2 * abs(ref[g][1]) and abs(float(eng.loss[g]) - yard[g][1]) < 2e-2 * abs(yard[g][1])
+        assert e_eng <= 1.15 * e_tch and e_eng <= 1.15 * e_orc, (g, e_eng, e_tch, e_orc)
+        assert c_eng >= c_tch - 0.01, (g, c_eng, c_tch)
+        cls_eng, cls_tch = (rel_err(t[g][-2].numpy() if t is got else t[g][0][-2].numpy(), truth[g][0][-2].numpy()) for t in (got, yard))
+        assert cls_eng <= 1.15 * cls_tch, (g, cls_eng, cls_tch)                       # classifier gradient: as close as torch's
+        if bn3_gamma is not None:
+            # the better-conditioned point (measured: engine 0.415-0.428 / cosine 0.909-0.914, the rounding-emulating oracle 0.416-0.426 / 0.909-0.913, torch autocast
+            # 0.416-0.430 / 0.907-0.914; loss 5e-4 from the emulating oracle; classifier gradient 2.4e-2 - 3.0e-2, torch 2.5e-2 - 3.2e-2): the ResNet-18 bounds hold
+            assert abs(float(eng.loss[g]) - ref[g][1]) < 2e-3 * abs(ref[g][1]) and cls_eng < 5e-2 and c_eng > 0.88 and e_eng < 0.5, (g, e_eng, c_eng, cls_eng)
+    # the stem: batch statistics of chunk 0 and the MaxPool output of the whole group against torch on the oracle's (bf16-rounded) tensors
+    L = eng.plan.stem
+    q = lambda t: t.to(torch.bfloat16).to(t.dtype)          # noqa: E731
+    w0 = q(params["stem.0.weight"].double())
+    raw = torch.nn.functional.conv2d(q(x[:chunk].double()), w0.cpu(), None, 2, 3)
+    assert rel_err(eng.mean_tab[0, 0, L.ch_off:L.ch_off + 64].cpu().numpy(), raw.mean((0, 2, 3)).numpy()) < 1e-3
+    assert rel_err(eng.var_tab[0, 0, L.ch_off:L.ch_off + 64].cpu().numpy(), raw.var((0, 2, 3), unbiased=False).numpy()) < 1e-3
+    pooled = torch.nn.functional.max_pool2d(eng.stem_out.float().permute(0, 3, 1, 2), 3, 2, 1)
+    assert torch.equal(pooled.permute(0, 2, 3, 1).contiguous(), eng.stem_pooled.float())
+    # the remembered argmax addresses a maximum of its window (ties: any maximal element gives the same gradient VALUE only if it is the first -- fb_maxpool3s2_bwd_idx
+    # against the recomputing form is a bit-identity test in test_gpu_ops.py; here: the byte of every pooled element points at an element equal to the pooled value)
+    if eng.stem_pool_idx is not None:
+        so = eng.stem_out.float()
+        n_, hp = so.shape[0], eng.stem_pooled.shape[1]
+        idx = eng.stem_pool_idx.long()
+        dy_, dx_ = idx // 3, idx % 3
+        oy = torch.arange(hp, device=so.device)[None, :, None, None] * 2 - 1 + dy_
+        ox = torch.arange(hp, device=so.device)[None, None, :, None] * 2 - 1 + dx_
+        assert int(oy.min()) >= 0 and int(ox.min()) >= 0 and int(oy.max()) < so.shape[1] and int(ox.max()) < so.shape[2]
+        ni = torch.arange(n_, device=so.device)[:, None, None, None].expand_as(idx)
+        ci = torch.arange(64, device=so.device)[None, None, None, :].expand_as(idx)
+        assert torch.equal(so[ni, oy, ox, ci], eng.stem_pooled.float())
+
+
+@pytest.mark.parametrize("dtype,wsets", [(torch.bfloat16, 1), (torch.float32, 1), (torch.float32, 2)])
+def test_on_block_done_path_gives_the_bits_of_the_replayed_path_on_a_bottleneck_plan(dtype, wsets):
+    """A rank's LAST chunk group of a multi-GPU step is issued launch by launch (``group_gradient(on_block_done=...)`` bypasses the command lists: the callback that
+    starts the late bucket's exchange sits inside the backward pass, reference training/utils.py:31-41 for resnets.py:271-316) -- every other group is a replayed
+    list.  Both must give the same bits on a Bottleneck plan (masked addends of the identity blocks, remembered MaxPool argmax, per-chunk weight sets of the
+    finite-difference pass), and the callback fires once per block, last block first, the late block among them."""
+    pixels, chunk, G = 64, 32, 3
+    cfg, model, eng, stem_patches = _build(50, pixels, chunk, G, dtype, stem="standard", fd_sets=1 if wsets > 1 else 0)
+    x, y = make_data(chunk * G, pixels)
+    patches, yd = stem_patches(x.cuda(), eng.plan.stem, dtype), y.cuda()
+    theta, gout, pidx = eng.theta, eng.g, 0
+    if wsets > 1:                                     # the finite-difference pass: one perturbed parameter set per chunk
+        eng.theta_k.copy_(eng.theta[None, :] * (1 + 1e-3 * torch.arange(1, G + 1, device="cuda", dtype=torch.float32)[:, None]))
+        theta, gout, pidx = eng.theta_k, eng.g_fd[0], 1
+    prep = (lambda: eng.prep_weights(theta, G, per_chunk=True)) if wsets > 1 else (lambda: eng.prep_weights(theta, 1))
+    out = []
+    for rep in range(2):                              # (recorded, then replayed)
+        prep()
+        eng.group_gradient(patches, yd, G, gout, wsets, theta, pidx)
+        torch.cuda.synchronize()
+        out.append((gout[:G].clone(), eng.loss[:G].clone(), eng.mean_tab[pidx].clone()))
+    assert eng.replays > 0
+    seen = []
+    prep()
+    eng.group_gradient(patches, yd, G, gout, wsets, theta, pidx, on_block_done=seen.append)
+    torch.cuda.synchronize()
+    assert seen == list(range(len(eng.plan.blocks) - 1, -1, -1)) and eng.plan.late_block == 13 and eng.plan.late_block in seen
+    for ref in out:
+        assert torch.equal(ref[0], gout[:G]) and torch.equal(ref[1], eng.loss[:G]) and torch.equal(ref[2], eng.mean_tab[pidx])
+    assert bool(torch.isfinite(gout[:G]).all()) and float(gout[:G].abs().max()) > 0
+
+
 def test_resnet152_at_224_directional_derivative():
     """BASELINE config 5 at its real shape (ResNet-152, 'standard' stem, 224x224 inputs, one chunk of 128 images, fp32 storage with the
     bf16x6 split -- the arithmetic of plain fp32 training; the regulariser's f16x2 arithmetic at this shape is covered by

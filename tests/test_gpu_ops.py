@@ -226,7 +226,8 @@ def test_conv1x1_kernels_agree_at_full_size(cin, cout, hw, n, monkeypatch):
     assert rel(new[0].reshape(-1, cout).float(), ref) < tol(dt)
 
 
-@pytest.mark.parametrize("cin,cout,hw,n", [(1024, 256, 14, 1024), (2048, 512, 7, 1000), (512, 2048, 7, 300), (256, 1024, 14, 700)])
+@pytest.mark.parametrize("cin,cout,hw,n", [(1024, 256, 14, 1024), (2048, 512, 7, 1000), (512, 2048, 7, 300), (256, 1024, 14, 700),
+                                           (128, 512, 28, 300), (128, 512, 28, 37), (192, 768, 14, 500)])   # K = 128 / 192: two / three K-steps per tile (round 2 of the pixel ring is the NEXT tile's)
 def test_conv1x1_gemm_kernel_agrees_with_the_implicit_gemm_at_full_size(cin, cout, hw, n, monkeypatch):
     """The ping-pong GEMM kernel (csrc/conv1x1_gemm.hip; FB_C1G=2: every call it can take) at a ResNet-152 chunk group's size: persistent workgroups walk three or four
     256 x 256 tiles each (784 tiles @14x14; 192 pixel tiles x 2 or 58 x 8 channel tiles @7x7 with a ragged last pixel tile), the two wave groups half a
@@ -257,6 +258,49 @@ def test_conv1x1_gemm_kernel_agrees_with_the_implicit_gemm_at_full_size(cin, cou
     ref = x.reshape(-1, cin).float() @ w.reshape(cout, cin).float().t()
     assert rel(got[0].reshape(-1, cout).float(), ref) < tol(dt)
     assert rel(got[1][0].sum(0), ref.sum(0)) < 2e-3 and rel(got[1][1].sum(0), (ref * ref).sum(0)) < 1e-4
+
+
+@pytest.mark.parametrize("cin,cout,hw,n", [(128, 512, 28, 512), (128, 512, 28, 2048), (256, 1024, 14, 2048), (1024, 256, 14, 2048), (512, 2048, 7, 2048), (2048, 512, 7, 2048),
+                                           (64, 256, 56, 512), (256, 64, 56, 512), (512, 128, 28, 1024), (256, 512, 4, 12544)])
+def test_conv1x1_default_dispatch_at_group_sizes(cin, cout, hw, n, monkeypatch):
+    """What fb_conv2d's DEFAULT dispatch (no FB_C1G / FB_C1S_* in the environment) selects for the 1x1 layers of a ResNet-50 / -152 chunk group of 512-2048 images
+    (and of the ResNet-18 shortcut at a 98-chunk group) against the kernels it replaces (FB_C1G=0 FB_C1S_PIPE=0: round-3 streaming kernel / implicit GEMM) and against torch's
+    own matmul of the same bf16 operands: forward with statistics, input gradient, input gradient with addend.  Round 5's suite pinned FB_C1G in every full-size test,
+    so the shipped default (the GEMM kernel for large K = 128 / 256 / >= 512 forward calls, several tiles per workgroup) was never compared with anything: its K = 128
+    form multiplied wrong pixel rows in every tile behind a workgroup's first."""
+    lib = _lib()
+    for key in ("FB_C1G", "FB_C1S_PIPE", "FB_C1S_ADD_ASM"):
+        monkeypatch.delenv(key, raising=False)
+    torch.manual_seed(13)
+    dt = torch.bfloat16
+    x = torch.randn(n, hw, hw, cin, device="cuda").to(dt)
+    w = (torch.randn(cout, 1, cin, device="cuda") * 0.05).to(dt)
+    dy = torch.randn(n, hw, hw, cout, device="cuda").to(dt)
+    wt = w.reshape(cout, cin).t().contiguous().reshape(cin, 1, cout)
+    add = torch.randn(n, hw, hw, cin, device="cuda").to(dt)
+    nblk = (n * hw * hw + 127) // 128
+
+    def run():
+        out, stat = torch.empty(n, hw, hw, cout, device="cuda", dtype=dt), torch.zeros(2, nblk, cout, device="cuda")
+        dx0, dx1 = (torch.empty(n, hw, hw, cin, device="cuda", dtype=dt) for _ in range(2))
+        lib.conv2d(x, w, out, 1, 1, 1, 0, 0, stat_partial=stat)
+        lib.conv2d(dy, wt, dx0, 1, 1, 1, 0, 1)
+        lib.conv2d(dy, wt, dx1, 1, 1, 1, 0, 1, addend=add, addend_mode=1)
+        torch.cuda.synchronize()
+        return out, stat, dx0, dx1
+
+    got = run()
+    monkeypatch.setenv("FB_C1G", "0"), monkeypatch.setenv("FB_C1S_PIPE", "0")
+    base = run()
+    assert torch.equal(got[0], base[0]) and torch.equal(got[2], base[2]) and torch.equal(got[3], base[3])
+    assert rel(got[1], base[1]) < 1e-5
+    ref = x.reshape(-1, cin).float() @ w.reshape(cout, cin).float().t()
+    assert rel(got[0].reshape(-1, cout).float(), ref) < tol(dt)
+    assert rel(got[1][0].sum(0), ref.sum(0)) < 2e-3 and rel(got[1][1].sum(0), (ref * ref).sum(0)) < 1e-4
+    del ref
+    refd = dy.reshape(-1, cout).float() @ w.reshape(cout, cin).float()
+    assert rel(got[2].reshape(-1, cin).float(), refd) < tol(dt)
+    assert rel(got[3].reshape(-1, cin).float(), refd + add.reshape(-1, cin).float()) < tol(dt)
 
 
 @pytest.mark.parametrize("magnitude", [1.0, 3e-6, 4e4])
