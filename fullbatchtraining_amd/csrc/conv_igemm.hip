@@ -205,9 +205,21 @@ int fb_try_conv1x1_pipe(const fb_conv_args* a, hipStream_t st);    // conv1x1_pi
 int fb_conv1x1_pipe_takes(const fb_conv_args* a);     // conv1x1_pipe.hip
 int fb_conv3x3_halo4_takes(const fb_conv_args* a);    // conv3x3_halo4.hip
 int fb_conv1x1_gemm_takes(const fb_conv_args* a);     // conv1x1_gemm.hip
+// (round 6: + the implicit GEMM, for every stride-1 input gradient with a same-shape addend that none of the specialised kernels takes -- all Bottleneck identity
+// blocks in fp32 storage, the 512-channel ones in bf16; FB_IGEMM_NO_MASK: the engine materialises d * (out > 0) for those again)
+static int igemm_masked_addend_ok(const fb_conv_args* a) {
+    if (getenv("FB_IGEMM_NO_MASK") != nullptr || a->mode != 1 || a->stride != 1 || a->bst_x) return 0;
+    if (a->Cs % 32 != 0 || a->Cd % 64 != 0) return 0;
+    static const bool v1 = getenv("FB_IGEMM_V1") != nullptr;
+    if (v1) return 0;
+    ConvParams p{};
+    p.n_img = a->n_img; p.Hs = a->Hs; p.Ws = a->Ws; p.Cs = a->Cs; p.Hd = a->Hd; p.Wd = a->Wd; p.Cd = a->Cd; p.R = a->R; p.S = a->S;
+    p.qH = a->Hd; p.qW = a->Wd;
+    return fb_igemm_glds_fits(p, a->dtype);
+}
 extern "C" int32_t fb_conv_masked_addend_supported(const fb_conv_args* a) {
     if (!a || !a->addend || !a->addend_mask || a->addend_mode != 1) return 0;
-    return fb_conv3x3_halo5_takes(a) || fb_conv1x1_pipe_takes(a) || fb_conv3x3_halo4_takes(a) || fb_conv1x1_gemm_takes(a);
+    return fb_conv3x3_halo5_takes(a) || fb_conv1x1_pipe_takes(a) || fb_conv3x3_halo4_takes(a) || fb_conv1x1_gemm_takes(a) || igemm_masked_addend_ok(a);
 }
 
 // 1 if fb_conv2d implements the fused BatchNorm-backward reduction for these arguments: the resident-filter and the persistent halo kernels
@@ -257,6 +269,7 @@ extern "C" int fb_conv2d(const fb_conv_args* a, void* stream) {
     p.imgs_per_wset = a->imgs_per_wset > 0 ? a->imgs_per_wset : a->n_img;
     p.wset_stride_bytes = a->wset_stride * EB;
     p.addend_mode = a->addend ? a->addend_mode : 0;
+    p.addend_mask = a->addend ? (const unsigned char*)a->addend_mask : nullptr;
     p.amax_src = a->dtype == FB_F32 ? a->amax_src : nullptr; p.amax_wgt = a->dtype == FB_F32 ? a->amax_wgt : nullptr;
     if ((p.amax_src == nullptr) != (p.amax_wgt == nullptr)) FB_FAIL(FB_ERR_ARG, "fb_conv2d: amax_src and amax_wgt go together");
     p.amax_imgs = a->amax_imgs > 0 ? a->amax_imgs : a->n_img;
@@ -297,6 +310,7 @@ extern "C" int fb_conv2d(const fb_conv_args* a, void* stream) {
         p.zeros = nullptr;
         kernel = FB_K_IGEMM_GLDS;
         if (v1 || !fb_launch_igemm_glds(p, classes, a->dtype, st)) {
+            if (p.addend_mask) FB_FAIL(FB_ERR_UNSUPPORTED, "fb_conv2d: the register-staged implicit GEMM does not apply addend_mask (tensor beyond 2^31 bytes per tile or FB_IGEMM_V1)");
             if (p.amax_src) FB_FAIL(FB_ERR_UNSUPPORTED, "fb_conv2d: the register-staged implicit GEMM has no fp16x2 path (tensor beyond 2^31 bytes or FB_IGEMM_V1)");
             if (a->dtype == FB_F32) launch_conv<float>(p, classes, st); else launch_conv<bf16_tag>(p, classes, st);
             kernel = FB_K_IGEMM_V1;

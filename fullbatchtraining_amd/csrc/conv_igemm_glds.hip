@@ -257,9 +257,22 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(const ConvParams p, 
                 const long long apix = p.addend_mode == 1 ? pix : ((long long)n * (p.Hd >> 1) + (oy >> 1)) * (p.Wd >> 1) + (ox >> 1);
                 const float sc = p.addend_mode == 1 ? 1.f : 0.25f;
                 const char* ap = p.addend + (apix * p.Cd + co) * EB;
-                if constexpr (EB == 4) { const float4 a = *(const float4*)ap; v[0] += sc * a.x; v[1] += sc * a.y; v[2] += sc * a.z; v[3] += sc * a.w; }
-                else { const uint2 a = *(const uint2*)ap; v[0] += sc * __uint_as_float(a.x << 16); v[1] += sc * __uint_as_float(a.x & 0xffff0000u);
-                       v[2] += sc * __uint_as_float(a.y << 16); v[3] += sc * __uint_as_float(a.y & 0xffff0000u); }
+                // addend_mask (round 6; identity blocks whose input gradient no specialised kernel takes: every Bottleneck block in fp32 storage -- the regulariser's
+                // passes -- and the 512-channel ones in bf16): the addend is the gradient entering the block, counted where the ReLU bit of the block's output is set
+                // (one byte per 16-byte vector of that tensor: 4 fp32 / 8 bf16 channels); d * (out > 0) is never materialised.  Same sums as adding the masked tensor.
+                unsigned mb = 0xffu;
+                if (p.addend_mask != nullptr) {
+                    const long long e = apix * p.Cd + co;
+                    mb = EB == 4 ? p.addend_mask[e >> 2] : (unsigned)p.addend_mask[e >> 3] >> (co & 4);
+                }
+                if constexpr (EB == 4) {
+                    const float4 a = *(const float4*)ap;
+                    v[0] += (mb & 1u) ? sc * a.x : 0.f; v[1] += (mb & 2u) ? sc * a.y : 0.f; v[2] += (mb & 4u) ? sc * a.z : 0.f; v[3] += (mb & 8u) ? sc * a.w : 0.f;
+                } else {
+                    const uint2 a = *(const uint2*)ap;
+                    v[0] += (mb & 1u) ? sc * __uint_as_float(a.x << 16) : 0.f; v[1] += (mb & 2u) ? sc * __uint_as_float(a.x & 0xffff0000u) : 0.f;
+                    v[2] += (mb & 4u) ? sc * __uint_as_float(a.y << 16) : 0.f; v[3] += (mb & 8u) ? sc * __uint_as_float(a.y & 0xffff0000u) : 0.f;
+                }
             }
             if constexpr (EB == 4) {
                 if (valid) *(float4*)(p.dst + (pix * p.Cd + co) * EB) = make_float4(v[0], v[1], v[2], v[3]);
@@ -337,12 +350,16 @@ template <typename T> static void launch(const ConvParams& p, int classes, hipSt
     }
 }
 
-// returns 1 if launched, 0 if the tensors are too large for 32-bit buffer offsets (caller falls back to conv_igemm.hip)
-int fb_launch_igemm_glds(const ConvParams& p, int classes, int dtype, hipStream_t st) {
+int fb_igemm_glds_fits(const ConvParams& p, int dtype) {
     const int EB = dtype == FB_F32 ? 4 : 2;
     // a 128-pixel tile addresses the images it covers (+ the next one) from its own descriptor base
     const long long bytesA = (long long)(128 / (p.qH * p.qW) + 2) * p.Hs * p.Ws * p.Cs * EB, bytesW = (long long)p.Cd * p.R * p.S * p.Cs * EB;
-    if (bytesA >= (1LL << 31) || bytesW >= (1LL << 31) || (long long)p.n_img * p.qH * p.qW >= (1LL << 31)) return 0;
+    return !(bytesA >= (1LL << 31) || bytesW >= (1LL << 31) || (long long)p.n_img * p.qH * p.qW >= (1LL << 31));
+}
+
+// returns 1 if launched, 0 if the tensors are too large for 32-bit buffer offsets (caller falls back to conv_igemm.hip)
+int fb_launch_igemm_glds(const ConvParams& p, int classes, int dtype, hipStream_t st) {
+    if (!fb_igemm_glds_fits(p, dtype)) return 0;
     if (dtype == FB_F32) {
         if (p.amax_src && p.amax_wgt) launch<f32h_tag>(p, classes, st);
         else if (fb_f32_split_enabled()) launch<f32s_tag>(p, classes, st);

@@ -10,6 +10,8 @@ struct ConvParams {
     const char* zeros;   // >= 128 bytes of zeros in device memory (source of padding rows for LDS-direct loads)
     const float* amax_src; const float* amax_wgt;   // f32h (fp16x2 split): largest magnitudes per chunk of src / per weight set (fb_absmax)
     int amax_imgs;                                   // images per entry of amax_src
+    const unsigned char* addend_mask;                // addend_mode 1: the addend counts only where its ReLU bit is set (fb_conv_args.addend_mask; 1 byte per 16-byte vector)
 };
 const void* fb_zero_page();                                                   // runtime.cpp
 int fb_launch_igemm_glds(const ConvParams& p, int classes, int dtype, hipStream_t st);   // conv_igemm_glds.hip
+int fb_igemm_glds_fits(const ConvParams& p, int dtype);                                  // conv_igemm_glds.hip: would fb_launch_igemm_glds take these sizes?

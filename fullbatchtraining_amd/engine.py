@@ -60,12 +60,15 @@ class Block:
         self.convs, self.shortcut, self.stride, self.cin, self.hin, self.win = convs, shortcut, stride, cin, hin, win
 
 
-def max_group(plan, chunk, dtype, device=None, reserve_bytes=0, use_free=True):
-    """Largest chunk group the fast kernels take.  fp32 storage: the biggest activation tensor (NHWC) stays below 2^31 bytes -- the fp32 LDS-DMA
-    kernels address whole tensors with 32-bit buffer offsets and hand larger ones to the slower pointer-based kernels.  bf16: every kernel
-    bases its descriptors at its own tile / K slice (round 3), so only a sanity limit of 2^35 bytes per tensor remains (the persistent
-    kernels' tile counts are 32-bit) -- and the device's memory: ``reserve_bytes`` = what the caller will allocate beside the engine (the stem's
-    pre-gathered patches of the rank's whole shard, resident images).  ``use_free=False``: a DETERMINISTIC cap -- the device's total memory only, never what happens
+def max_group(plan, chunk, dtype, device=None, reserve_bytes=0, use_free=True, fd_sets=0):
+    """Largest chunk group: as many chunks as the device's memory holds the resident activations of (and a sanity limit of 2^35 bytes per tensor: the persistent
+    kernels' tile counts are 32-bit), never less than the group whose biggest activation tensor (NHWC) stays below 2^31 bytes.  Every kernel bases its buffer
+    descriptors at its own tile / K slice or addresses with 64-bit pointers -- bf16 since round 3, and the fp32 kernels as well (round 6: the limit that used to hold
+    fp32 storage at 2^31 bytes per tensor was a leftover; ResNet-152 @224 with the regulariser: 8 chunks in one group, 3.06 GiB tensors, same losses bit for bit,
+    +2.5 %; tests/test_gpu_engine.py::test_f32_chunk_group_beyond_2g_byte_tensors_equals_smaller_groups).  FB_BIG_GROUPS=0 keeps the 2^31 rule.
+    ``reserve_bytes`` = what the caller will allocate beside the engine (the stem's pre-gathered patches of the rank's whole shard, resident images); ``fd_sets``: the
+    finite-difference passes' per-chunk arenas (gradient sets, perturbed parameters, per-chunk weight copies) count per chunk too.
+    ``use_free=False``: a DETERMINISTIC cap -- the device's total memory only, never what happens
     to be free of it now (other processes, allocator state): the caller derives the NOMINAL group from it, the number the weight gradients' K-slice counts are sized
     for, which has to be the same on every rank of a job and in every run (``FullBatchTrainer``: whole-problem reserve, MIN over the ranks)."""
     # (the stem's pre-gathered patches -- 7x7x3 -> 160 values per pixel for the ImageNet stem, the largest tensor by far -- do not count: the two
@@ -73,15 +76,17 @@ def max_group(plan, chunk, dtype, device=None, reserve_bytes=0, use_free=True):
     per_image = max(max(L.hout * L.wout * L.cout, L.hin * L.win * (L.cin_pad if L is not plan.stem else 0)) for L in plan.layers)
     es = torch.empty((), dtype=dtype).element_size()
     cap31 = max(1, ((1 << 31) - 1) // (chunk * per_image * es))
-    if dtype != torch.bfloat16 or os.environ.get("FB_BIG_GROUPS", "1") == "0":
+    if os.environ.get("FB_BIG_GROUPS", "1") == "0":
         return cap31
     # beyond the old limit as far as the resident activations of a group fit: every layer's conv output and post-BN activation (a block's last
     # BatchNorm writes the block output: counted once) with their ReLU masks, ~8 gradient buffers of the largest tensor -- against 90 % of the device
     # or what is free of it, less the caller's own tensors.  Round 5 measured ResNet-152 @224: 108.8 GB at 8 chunks of 128 images, 207.9 GB at 16
     # (12.4 GB per chunk + 9.5 GB; this estimate: 13.9 GB per chunk) -- and 16 chunks in ONE group are 2.5 % faster than two groups of 8 (half as many launches
-    # for the same work; the old rule, a third of the device, stopped at 10).  FB_GROUP_MEM_FRAC overrides the 0.9.
+    # for the same work; the old rule, a third of the device, stopped at 10).  fp32 storage with the regulariser (round 6): 211.4 GiB at 8 chunks (estimate 28.9 GB
+    # per chunk).  FB_GROUP_MEM_FRAC overrides the 0.9.
     acts = sum(2 * L.hout * L.wout * L.cout for L in plan.layers)
     per_image_bytes = (acts * 17 // 16 + 8 * per_image) * es
+    per_chunk_arenas = (1 + (fd_sets + 1 if fd_sets else 0)) * plan.P * 4 + (2 * plan.wc_total * es if fd_sets else 0)
     dev = torch.device(device if device is not None else "cuda")
     if torch.cuda.is_available():
         total = torch.cuda.get_device_properties(dev).total_memory          # (the engine's OWN device: ranks other than local rank 0, heterogeneous boxes)
@@ -90,7 +95,7 @@ def max_group(plan, chunk, dtype, device=None, reserve_bytes=0, use_free=True):
         total = free = 288 << 30
     frac = float(os.environ.get("FB_GROUP_MEM_FRAC", "0.9"))
     budget = max(0, (min(int(total * frac), free) if use_free else int(total * frac)) - int(reserve_bytes))
-    return max(cap31, min((1 << 35) // (chunk * per_image * es), budget // (chunk * per_image_bytes)))
+    return max(cap31, min((1 << 35) // (chunk * per_image * es), budget // (chunk * per_image_bytes + per_chunk_arenas)))
 
 
 def padded_chunk(plan, chunk):

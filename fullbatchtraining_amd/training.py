@@ -450,13 +450,13 @@ class FullBatchTrainer:
         # what this trainer keeps on the device beside the engine: the stem's patches of the rank's whole shard (and the base images where they are re-augmented)
         es = torch.empty((), dtype=self.dtype).element_size()
         own = self.shard.count * self.chunk_pad * plan.stem.hout * plan.stem.wout * plan.stem.cin_pad * es + self.shard.count * self.chunk * X[0].numel() * 4
-        want, cap = int(cfg.impl.get("engine", {}).get("chunk_group", 98)), max_group(plan, self.chunk_pad, self.dtype, self.device, reserve_bytes=own)
+        want, cap = int(cfg.impl.get("engine", {}).get("chunk_group", 98)), max_group(plan, self.chunk_pad, self.dtype, self.device, reserve_bytes=own, fd_sets=fd_sets)
         # K-slice counts of the weight gradients are sized for the group of the WHOLE problem on one GPU -- the same number on every rank and in every run, so
         # that a chunk's summation order (hence its gradient, bit for bit) does not depend on the number of GPUs, on what else runs on the device or on the
         # allocator's state: the nominal cap comes from the device's TOTAL memory less what the 1-process run would keep resident (not from free memory, not from
         # this rank's share), and a job of several ranks takes the smallest of its ranks' values
         own_whole = self.n_chunks * self.chunk_pad * plan.stem.hout * plan.stem.wout * plan.stem.cin_pad * es + self.n_chunks * self.chunk * X[0].numel() * 4
-        cap_nominal = max_group(plan, self.chunk_pad, self.dtype, self.device, reserve_bytes=own_whole, use_free=False)
+        cap_nominal = max_group(plan, self.chunk_pad, self.dtype, self.device, reserve_bytes=own_whole, use_free=False, fd_sets=fd_sets)
         if self.world > 1:
             t = torch.tensor([cap_nominal], dtype=torch.int64, device=self.device if torch.distributed.get_backend() == "nccl" else "cpu")
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)

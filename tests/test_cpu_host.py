@@ -190,27 +190,34 @@ def test_padded_chunk_sizes():
 
 
 def test_group_cap_keeps_activations_in_32bit_range(monkeypatch):
-    """fp32 storage: the largest activation tensor of a chunk group stays below 2^31 bytes (32-bit buffer offsets of the fp32 LDS-DMA kernels).
-    bf16: the kernels base their descriptors at their own tile / K slice, so a group may be larger -- as far as 90 % of the device (less what the caller
-    keeps there: ``reserve_bytes``) holds its activations (288 GB assumed without a GPU); FB_BIG_GROUPS=0 keeps the 2^31 rule."""
+    """A chunk group may be as large as 90 % of the device (less what the caller keeps there: ``reserve_bytes``; 288 GB assumed without a GPU) holds its activations
+    and per-chunk arenas of -- in both storage types: every kernel bases its descriptors at its own tile / K slice or uses 64-bit pointers (the fp32 rule "largest
+    tensor below 2^31 bytes" was lifted in round 6).  FB_BIG_GROUPS=0 keeps the 2^31 rule; it stays the floor."""
     from fullbatchtraining_amd.cfg import compose
     from fullbatchtraining_amd.engine import Plan, max_group
     from fullbatchtraining_amd.models import construct_model
 
     plan = Plan(construct_model(compose([]).model, 3, 10), 32)
-    assert max_group(plan, 128, torch.float32) == 63 and max_group(plan, 32, torch.float32) == 255
     big = max_group(plan, 128, torch.bfloat16)
     assert 127 < big <= 1024 and big * 128 * 4_000_000 < 288 << 30         # (~3.2 MB of activations per image + gradient buffers)
+    big32 = max_group(plan, 128, torch.float32)
+    assert 63 < big32 < big and max_group(plan, 128, torch.float32, fd_sets=1) < big32      # fp32: twice the bytes; the regulariser's per-chunk arenas count
     monkeypatch.setenv("FB_BIG_GROUPS", "0")
     assert max_group(plan, 128, torch.bfloat16) == 127
+    assert max_group(plan, 128, torch.float32) == 63 and max_group(plan, 32, torch.float32) == 255
     deep = Plan(construct_model(compose(["model=resnet152", "model.stem=standard"]).model, 3, 10), 224)
+    assert max_group(deep, 128, torch.float32) == 5
     monkeypatch.delenv("FB_BIG_GROUPS")
     # ResNet-152 @224: ~13.9 GB per chunk of 128 images by the estimate (round 5 measured 12.4 GiB per chunk + 9.5 GiB: 207.9 GiB at 16 chunks) -- the 16
-    # chunks of a 2048-image step run as ONE group beside 10 GB of patches and images, 20 would not
-    assert max_group(deep, 128, torch.bfloat16, reserve_bytes=10 << 30) == 19 and max_group(deep, 128, torch.float32) == 5
+    # chunks of a 2048-image step run as ONE group beside 10 GB of patches and images, 20 would not; with fp32 storage and the regulariser (config 5 as BASELINE
+    # states it; measured 211.4 GiB at 8 chunks) the 8 chunks of a 1024-image step are one group
+    assert max_group(deep, 128, torch.bfloat16, reserve_bytes=10 << 30) == 18
+    assert max_group(deep, 128, torch.float32, reserve_bytes=9 << 30, fd_sets=1) == 9
     assert max_group(deep, 128, torch.bfloat16, reserve_bytes=200 << 30) == 10                    # (little room left: the 2^31 rule is the floor)
     monkeypatch.setenv("FB_GROUP_MEM_FRAC", "0.3333")
     assert max_group(deep, 128, torch.bfloat16) == 10
+    # the deterministic form (nominal group: total memory only) never depends on what is free
+    assert max_group(deep, 128, torch.bfloat16, use_free=False) == max_group(deep, 128, torch.bfloat16)
 
 
 def test_optimizer_wrappers_have_the_reference_surface():

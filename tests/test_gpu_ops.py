@@ -926,11 +926,52 @@ def test_conv_masked_addend_equals_materialised_mask():
         lib.conv2d(dy3, w3, b3, 3, 3, 1, 1, 1, addend=d3, addend_mode=1, addend_mask=bits3)
         torch.cuda.synchronize()
         assert torch.equal(a3, b3), (C, hw2)
-    # a layer no kernel takes the mask for says so instead of ignoring it: a 1x1 layer with K >= 512
+    # a call no kernel takes the mask for says so instead of ignoring it: a pooled addend (addend_mode 2), or the implicit GEMM's mask path switched off for a 1x1 layer with K >= 512
     d4 = torch.randn(n, 8, 8, 256, device="cuda").bfloat16()
+    bits4 = ((torch.randn(n, 8, 8, 256, device="cuda").reshape(-1, 8) > 0).to(torch.int32) << torch.arange(8, device="cuda")).sum(1).to(torch.uint8)
+    dy4, w4 = torch.randn(n, 8, 8, 1024, device="cuda").bfloat16(), torch.randn(256, 1, 1024, device="cuda").bfloat16()
+    os.environ["FB_IGEMM_NO_MASK"] = "1"
+    try:
+        with pytest.raises(lib.EngineError):
+            lib.conv2d(dy4, w4, torch.empty_like(d4), 1, 1, 1, 0, 1, addend=d4, addend_mode=1, addend_mask=bits4)
+    finally:
+        del os.environ["FB_IGEMM_NO_MASK"]
     with pytest.raises(lib.EngineError):
-        lib.conv2d(torch.randn(n, 8, 8, 1024, device="cuda").bfloat16(), torch.randn(256, 1, 1024, device="cuda").bfloat16(), torch.empty_like(d4), 1, 1, 1, 0, 1,
-                   addend=d4, addend_mode=1, addend_mask=bits)
+        lib.conv2d(dy, w, torch.empty_like(d), 3, 3, 1, 1, 1, addend=d[:, ::2, ::2].contiguous(), addend_mode=2, addend_mask=bits)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k,cd,r,hw,n", [(512, 2048, 1, 7, 9), (1024, 256, 1, 14, 3), (64, 256, 1, 56, 2), (256, 1024, 1, 14, 5), (128, 512, 1, 28, 3),
+                                         (256, 256, 3, 14, 4), (64, 64, 3, 56, 1), (128, 128, 3, 28, 2), (512, 512, 3, 7, 6), (96, 64, 3, 6, 3)])
+def test_implicit_gemm_masked_addend_equals_materialised_mask(dtype, k, cd, r, hw, n, monkeypatch):
+    """fb_conv_args.addend_mask in the implicit GEMM's epilogue (round 6): the input gradients of identity blocks that no specialised kernel serves -- every
+    Bottleneck identity block with fp32 storage (the regulariser's passes of BASELINE config 5: 1x1 convolutions with K = 64 ... 512 on 56 / 28 / 14 / 7 maps), the
+    512-channel ones in bf16, 3x3 layers on ImageNet-shaped maps.  Taking `d` through the ReLU bitmask of the block output (one byte per 16-byte vector: 4 fp32 or 8
+    bf16 channels) gives bit for bit what adding the materialised d * (out > 0) gives."""
+    lib = _lib()
+    for key in ("FB_C1G", "FB_C1S_PIPE"):
+        monkeypatch.setenv(key, "0")                     # (bf16: the streaming kernels take K <= 256 themselves; here the implicit GEMM is under test for every shape)
+    torch.manual_seed(k + hw + r)
+    pad = r // 2
+    dy = (torch.randn(n, hw, hw, k, device="cuda") * 0.1).to(dtype)
+    wt = (torch.randn(cd, r * r, k, device="cuda") * 0.05).to(dtype)
+    d = torch.randn(n, hw, hw, cd, device="cuda").to(dtype)
+    out_act = torch.randn(n, hw, hw, cd, device="cuda")
+    vec = 16 // d.element_size()
+    bits = ((out_act.reshape(-1, vec) > 0).to(torch.int32) << torch.arange(vec, device="cuda")).sum(1).to(torch.uint8)
+    masked = torch.where(out_act > 0, d, torch.zeros_like(d))
+    a, b, plain = torch.empty_like(d), torch.full_like(d, float("nan")), torch.empty_like(d)
+    args = lib.ConvArgs(dy.data_ptr(), wt.data_ptr(), b.data_ptr(), d.data_ptr(), None, n, hw, hw, k, hw, hw, cd, r, r, 1, pad, 1, 0, 0, 1, lib.dtype_code(dtype),
+                        bits.data_ptr(), None, None, None, None, 0)
+    assert lib.load().fb_conv_masked_addend_supported(lib.C.byref(args))
+    lib.conv2d(dy, wt, a, r, r, 1, pad, 1, addend=masked, addend_mode=1)
+    lib.conv2d(dy, wt, b, r, r, 1, pad, 1, addend=d, addend_mode=1, addend_mask=bits)
+    lib.conv2d(dy, wt, plain, r, r, 1, pad, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and not torch.equal(a, plain)
+    assert rel((a.float() - plain.float()).cpu(), masked.float().cpu()) < (1e-5 if dtype == torch.float32 else 5e-2)     # the difference IS the masked addend
+    monkeypatch.setenv("FB_IGEMM_NO_MASK", "1")
+    assert not lib.load().fb_conv_masked_addend_supported(lib.C.byref(args))
 
 
 @pytest.mark.parametrize("k,cd,hw,n", [(256, 1024, 14, 64), (256, 1024, 14, 3), (128, 512, 28, 5), (64, 256, 56, 2), (256, 512, 7, 9), (256, 128, 8, 4)])
@@ -967,8 +1008,14 @@ def test_conv1x1_masked_addend_equals_materialised_mask(k, cd, hw, n, monkeypatc
     lib.conv2d(dy, wt, f, 1, 1, 1, 0, 1)
     torch.cuda.synchronize()
     assert torch.equal(a, c) and torch.equal(a, e) and torch.equal(plain, f)
+    # with both switched off the call falls to the implicit GEMM, which applies the mask in its epilogue (round 6): same bits again; with that off too it says so
     monkeypatch.setenv("FB_C1G", "0")
     monkeypatch.setenv("FB_C1S_PIPE", "0")
+    g = torch.full_like(d, float("nan"))
+    lib.conv2d(dy, wt, g, 1, 1, 1, 0, 1, addend=d, addend_mode=1, addend_mask=bits)
+    torch.cuda.synchronize()
+    assert torch.equal(a, g)
+    monkeypatch.setenv("FB_IGEMM_NO_MASK", "1")
     assert not lib.load().fb_conv_masked_addend_supported(lib.C.byref(args))
     with pytest.raises(lib.EngineError):
         lib.conv2d(dy, wt, b, 1, 1, 1, 0, 1, addend=d, addend_mode=1, addend_mask=bits)
