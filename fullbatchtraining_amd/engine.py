@@ -78,6 +78,11 @@ def max_group(plan, chunk, dtype, device=None, reserve_bytes=0, use_free=True, f
     cap31 = max(1, ((1 << 31) - 1) // (chunk * per_image * es))
     if os.environ.get("FB_BIG_GROUPS", "1") == "0":
         return cap31
+    if dtype == torch.float32 and plan.kind == "basic" and os.environ.get("FB_BIG_GROUPS") != "2":
+        # BasicBlock nets with fp32 storage keep the old size: measured (round 6, same box, BASELINE config 3: ResNet-18 with the regulariser) 2252 / 2263 ms per step with
+        # groups of 56 chunks against 2278 / 2290 with groups of 98 -- the larger tensors buy nothing there (the launches are long already) and cost 1 %;
+        # the Bottleneck nets' 4 -> 8 chunks are worth +2.5 %.  FB_BIG_GROUPS=2: the memory rule for every net (tests)
+        return cap31
     # beyond the old limit as far as the resident activations of a group fit: every layer's conv output and post-BN activation (a block's last
     # BatchNorm writes the block output: counted once) with their ReLU masks, ~8 gradient buffers of the largest tensor -- against 90 % of the device
     # or what is free of it, less the caller's own tensors.  Round 5 measured ResNet-152 @224: 108.8 GB at 8 chunks of 128 images, 207.9 GB at 16

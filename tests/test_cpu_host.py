@@ -200,6 +200,8 @@ def test_group_cap_keeps_activations_in_32bit_range(monkeypatch):
     plan = Plan(construct_model(compose([]).model, 3, 10), 32)
     big = max_group(plan, 128, torch.bfloat16)
     assert 127 < big <= 1024 and big * 128 * 4_000_000 < 288 << 30         # (~3.2 MB of activations per image + gradient buffers)
+    assert max_group(plan, 128, torch.float32) == 63            # BasicBlock nets with fp32 storage keep the 2^31 size (measured: larger groups cost 1 % there)
+    monkeypatch.setenv("FB_BIG_GROUPS", "2")
     big32 = max_group(plan, 128, torch.float32)
     assert 63 < big32 < big and max_group(plan, 128, torch.float32, fd_sets=1) < big32      # fp32: twice the bytes; the regulariser's per-chunk arenas count
     monkeypatch.setenv("FB_BIG_GROUPS", "0")
