@@ -331,7 +331,7 @@ extern "C" int fb_bn_bwd_fused(const void* dout, const void* mask, const void* x
     p.n_groups = n_groups; p.C = C; p.ch_total = ch_total; p.ch_off = ch_off; p.ncw = ncw;
     p.n_clusters = slots / ncw < n_groups ? slots / ncw : n_groups;
     p.trace = g_bnf_trace;
-    static const int poll = getenv("FB_BNF_POLL") ? atoi(getenv("FB_BNF_POLL")) : 2;
+    static const int poll = fb_getenv_experimental("FB_BNF_POLL") ? atoi(fb_getenv_experimental("FB_BNF_POLL")) : 2;
     p.poll = poll != 0 ? poll : 1;
     // arrival counters and flags start at zero; the error word is sticky (the caller reads and clears it: fb_bn_bwd_fused_error)
     if (hipMemsetAsync(sync, 0, sizeof(int32_t) * (size_t)n_groups * BF_SYNC, (hipStream_t)stream) != hipSuccess)

@@ -315,6 +315,9 @@ __device__ __forceinline__ f32x4_t mma_planes3h(const uint4 (&a)[2], const uint4
 }
 // FB_F32_EXACT=1 (environment, read once): fp32 convolutions on the exact-f32 MFMA instead of the split path (A/B and reference)
 bool fb_f32_split_enabled();
+// the value of an environment switch that selects an EXPERIMENTAL kernel form (one that lost its A/B): nullptr unless FB_EXPERIMENTAL=1 is set as well (runtime.cpp)
+bool fb_experimental();
+const char* fb_getenv_experimental(const char* name);
 // CUs the persistent kernels size their grids for (runtime.cpp: the device's CU count minus FB_CU_RESERVE)
 int fb_persistent_cus();
 

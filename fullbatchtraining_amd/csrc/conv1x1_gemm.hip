@@ -382,7 +382,7 @@ int fb_conv1x1_gemm_takes(const fb_conv_args* a) {
     // input gradients only with FB_C1G=2: without an addend (K >= 512) no step-level gain; with the same-shape addend of an identity block (plain or through its ReLU
     // bitmask, K >= 128) the epilogue's 8-byte loads in the accumulators' layout are waited for with vmcnt(0) and the kernel spills: ResNet-152 @224 6082-6092
     // images/s with it against 6421-6442 on the streaming kernel (round 5) -- built, bit-identical, off
-    if (a->mode == 1 && !(sw != nullptr && atoi(sw) == 2)) return 0;
+    if (a->mode == 1 && !(sw != nullptr && atoi(sw) == 2 && fb_experimental())) return 0;      // (FB_C1G=2 acts only with FB_EXPERIMENTAL=1: the input-gradient forms lost their A/B)
     const long long M = (long long)a->n_img * a->Hd * a->Wd;
     if ((M + G1_BM - 1) / G1_BM * (a->Cd / G1_BN) >= (1LL << 31) || (M / 128 + 2) * a->Cd * 8 >= (1LL << 31)) return 0;
     const long long n_tiles = (M + G1_BM - 1) / G1_BM * (a->Cd / G1_BN);

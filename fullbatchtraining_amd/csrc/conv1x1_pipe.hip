@@ -487,7 +487,7 @@ int fb_try_conv1x1_pipe(const fb_conv_args* a, hipStream_t st) {
     if (!fb_conv1x1_pipe_takes(a)) return 0;
     const long long M = (long long)a->n_img * a->Hd * a->Wd;
     // 8-wave workgroups (one per CU, 256 channels) where the layer has them, else 4-wave ones (two per CU, 128 channels); FB_C1P_NW overrides
-    static const int nw_env = getenv("FB_C1P_NW") ? atoi(getenv("FB_C1P_NW")) : 0;
+    static const int nw_env = fb_getenv_experimental("FB_C1P_NW") ? atoi(fb_getenv_experimental("FB_C1P_NW")) : 0;
     int nw = nw_env ? nw_env : 8;
     const int ch_per_wg8 = a->Cs == 64 ? 128 : 256;
     if (nw == 8 && a->Cd % ch_per_wg8 != 0) nw = 4;

@@ -288,7 +288,7 @@ int fb_try_conv1x1_stream(const fb_conv_args* a, hipStream_t st) {
     // wave reads the whole sub-tile; K = 64 (sub-tiles of 256 pixels, output-dominated traffic): 2 channel waves x 2 pixel halves
     // measured (tools/conv_microbench.py, profiles/r3_notes.md): 8-wave workgroups (one per CU) are 5-10 % faster for the forward shapes, 4-wave
     // ones (two per CU: one computes while the other waits for its loads and store acknowledgements) for most input gradients
-    static const int nw_env = getenv("FB_C1S_NW") ? atoi(getenv("FB_C1S_NW")) : 0;
+    static const int nw_env = fb_getenv_experimental("FB_C1S_NW") ? atoi(fb_getenv_experimental("FB_C1S_NW")) : 0;
     const bool add_asm = !(getenv("FB_C1S_ADD_ASM") && atoi(getenv("FB_C1S_ADD_ASM")) == 0);      // A/B (read per call): the addend by in-place 8-byte loads
     const bool add = a->addend != nullptr && add_asm;
     const int nw = add ? 4 : (nw_env ? nw_env : (a->mode == 0 ? 8 : 4));

@@ -778,7 +778,7 @@ static int h4_variant(const fb_conv_args* a) {
     if (a->n_img % imgs_per_tile != 0 || imgs_per_wset % imgs_per_tile != 0) return 0;
     // 128-channel tiles (one workgroup per CU, FI = 8): bf16; always for the 4x4 maps (which have no 64-channel variant), elsewhere only
     // with FB_H4_WIDE (A/B switch: a list of map widths, e.g. "8,16")
-    static const char* wide_env = getenv("FB_H4_WIDE");
+    static const char* wide_env = fb_getenv_experimental("FB_H4_WIDE");
     char wtag[8];
     snprintf(wtag, sizeof(wtag), "%d", W);
     // 4x4 maps (bf16): the compact layout with 64-channel tiles, two workgroups per CU (FB_H4_COMPACT=0: the padded layout, which only fits
@@ -825,7 +825,7 @@ int fb_try_conv3x3_halo4(const fb_conv_args* a, hipStream_t st) {
     p.magic_ct = h4_magic(p.n_ct);
     p.magic_wset = h4_magic(imgs_per_wset);
     {
-        static const char* ph = getenv("FB_H4_PHASE");      // "mode,sleeps"
+        static const char* ph = fb_getenv_experimental("FB_H4_PHASE");      // "mode,sleeps"
         p.phase_mode = ph ? atoi(ph) : 0;
         p.phase_sleeps = ph && strchr(ph, ',') ? atoi(strchr(ph, ',') + 1) : 2;
     }
@@ -835,7 +835,7 @@ int fb_try_conv3x3_halo4(const fb_conv_args* a, hipStream_t st) {
 #endif
     // (FB_H4_WG_PER_CU=1: one resident workgroup per CU instead of two -- leaves half of every CU's registers and LDS to a kernel of another
     // stream; A/B switch of the co-scheduling experiments, profiles/r4_notes.md)
-    static const int wg_per_cu = getenv("FB_H4_WG_PER_CU") ? atoi(getenv("FB_H4_WG_PER_CU")) : 2;
+    static const int wg_per_cu = fb_getenv_experimental("FB_H4_WG_PER_CU") ? atoi(fb_getenv_experimental("FB_H4_WG_PER_CU")) : 2;
     const int slots = (wg_per_cu == 1 ? 1 : 2) * n_cu;
     dim3 grid(p.n_tiles < slots ? p.n_tiles : slots);
     if (variant == 3) {

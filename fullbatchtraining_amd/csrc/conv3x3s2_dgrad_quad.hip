@@ -242,7 +242,7 @@ int fb_try_conv3x3s2_dgrad_quad(const fb_conv_args* a, hipStream_t st) {
     // a full-resolution addend: dY 16x16 (128->64 ch) 1010 / 1707 -> 793 / 1227, 8x8 (256->128) 776 / 1117 -> 589 / 790, 4x4 (512->256)
     // 678 / 839 -> 506 / 612 (implicit GEMM: 649 / 778).  The tile's life is staging latency + a 128 KiB epilogue around 4-9 us of MFMA work:
     // a second resident workgroup covers both, a second stage covers neither.  FB_S2Q_STAGES=2 selects the round-3 form.
-    const char* st_env = getenv("FB_S2Q_STAGES");              // read per call: the tests compare the two forms in one process
+    const char* st_env = fb_getenv_experimental("FB_S2Q_STAGES");              // read per call: the tests compare the two forms in one process
     const int stages = st_env ? atoi(st_env) : 1;
     if (stages == 1) {
         if (WQ == 16) hipLaunchKernelGGL((conv3x3s2_dgrad_quad_kernel<16, 1>), grid, dim3(256), 0, st, p);

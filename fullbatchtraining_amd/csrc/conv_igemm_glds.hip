@@ -329,7 +329,7 @@ template <typename T> static void launch(const ConvParams& p, int classes, hipSt
     if constexpr (std::is_same<T, bf16_tag>::value) {
         // bf16: one stage, three workgroups per CU (12 544 images, stride-2 forward 64->128 / 128->256 / 256->512: 936 / 587 / 493 us against
         // 1001 / 669 / 561 with two stages and two workgroups); FB_IGEMM_STAGES=2 selects the double-buffered form (read per call: tests compare)
-        const char* e = getenv("FB_IGEMM_STAGES");
+        const char* e = fb_getenv_experimental("FB_IGEMM_STAGES");
         if (!(e && atoi(e) == 2)) {
             if (p.Cd % 128 == 0 && (long long)mblocks * (p.Cd / 128) * classes >= 512) {
                 const int n_co = p.Cd / 128;

@@ -196,7 +196,7 @@ int fb_try_wgrad1x1(const fb_wgrad_args* a, hipStream_t st) {
     // ... capped at 128 x 128 per workgroup (two workgroups per CU, 64 KiB of LDS each) since the end of round 5: the 256 x 256 tile (one wave per SIMD, 128 KiB) halves the
     // L2 -> LDS bytes per FLOP and is no slower alone, but inside the ResNet-152 @224 step the small tile wins (6514 against 6453-6473 images/s; ResNet-50 @224
     // +0.25 %, the ResNet-18 headline unchanged, ResNet-50 @32 beside the weight-gradient stream -0.3 %).  FB_W1_CAP_M / FB_W1_CAP_N = 8 bring the big tile back.
-    const int cap_m = getenv("FB_W1_CAP_M") ? atoi(getenv("FB_W1_CAP_M")) : 4, cap_n = getenv("FB_W1_CAP_N") ? atoi(getenv("FB_W1_CAP_N")) : 4;      // (read per call: the tests compare)
+    const int cap_m = fb_getenv_experimental("FB_W1_CAP_M") ? atoi(fb_getenv_experimental("FB_W1_CAP_M")) : 4, cap_n = fb_getenv_experimental("FB_W1_CAP_N") ? atoi(fb_getenv_experimental("FB_W1_CAP_N")) : 4;      // (read per call: the tests compare)
     if (mi > cap_m) mi = cap_m;
     if (nj > cap_n) nj = cap_n;
     if (mi == 8 && nj == 8) w1_launch<8, 8>(p, st);

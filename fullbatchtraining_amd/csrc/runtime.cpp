@@ -24,6 +24,15 @@ extern "C" int64_t fb_ws_mt_floats(int32_t n_groups) { return (int64_t)(n_groups
 // CUs the persistent kernels size their grids for: the device's, minus FB_CU_RESERVE (default 0).  With one or two resident workgroups of a
 // persistent convolution on EVERY CU a kernel of another stream (the gradient exchange's RCCL kernels under the last backward pass) only gets
 // a slot when a whole launch ends; a reserve leaves that many CUs' worth of slots open (measured: bench.py `exchange`).
+// FB_EXPERIMENTAL=1 (read once): the switches that turn ON a kernel form which lost its same-box A/B (profiles/r*_notes.md) only act together with it -- the
+// default dispatch documented in DESIGN.md section 4 is what runs otherwise.  (Switches that fall BACK to an older established kernel -- FB_DISABLE_*, FB_C1S_PIPE=0,
+// FB_C1G=0, FB_H4_COMPACT=0 ... -- are A/B switches between shipped forms and act on their own.)
+bool fb_experimental() {
+    static const bool on = getenv("FB_EXPERIMENTAL") != nullptr && atoi(getenv("FB_EXPERIMENTAL")) != 0;
+    return on;
+}
+static const char* fb_exp_getenv(const char* name) { return fb_experimental() ? getenv(name) : nullptr; }
+const char* fb_getenv_experimental(const char* name) { return fb_exp_getenv(name); }
 int fb_persistent_cus() {
     // per DEVICE (a process may drive several: the first caller's device must not size the grids of all of them); hipGetDevice is a
     // thread-local read, so the lookup stays out of the launch path's cost

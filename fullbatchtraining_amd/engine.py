@@ -349,13 +349,15 @@ class Engine:
         self.cmdlists, self.replays, self.MAX_CMDLISTS = {}, 0, int(os.environ.get("FB_MAX_CMDLISTS", "256"))
         self.cmd_evictions, self.record_new, self.unrecorded_runs, self._warned_record_off, self._off_misses = 0, True, 0, False, 0
         self.masks = {}
-        self.fuse_bwd_stat = os.environ.get("FB_FUSED_BWD_STAT", "0") != "0"     # BN-backward reduction in the input-gradient epilogues: built, parity-tested,
+        # FB_EXPERIMENTAL=1: the switches below that turn ON a form which lost its same-box A/B act only together with it (the library's do the same: csrc/runtime.cpp)
+        exp = os.environ.get("FB_EXPERIMENTAL", "0") not in ("", "0")
+        self.fuse_bwd_stat = exp and os.environ.get("FB_FUSED_BWD_STAT", "0") != "0"     # BN-backward reduction in the input-gradient epilogues: built, parity-tested,
         # measured SLOWER at step level (profiles/r2_notes.md: the separate HBM-bound reduction overlaps the weight-gradient stream) -> off
         self.bst_done = False
         # BatchNorm backward in one pass over (dout, x) with a chunk's operands held in registers by a resident cluster of workgroups
         # (csrc/bn_bwd_fused.hip): built, parity-tested, and measured SLOWER than reduce -> finalize -> apply (2.1 vs 1.27 ms on the 64-channel layer:
         # eight waves per CU pulling 128 KiB bursts reach 2.8 TB/s even without the waits -- profiles/r4_notes.md) -> off; FB_BN_BWD_FUSED=1 selects it
-        self.bn_fused = os.environ.get("FB_BN_BWD_FUSED", "0") == "1"
+        self.bn_fused = exp and os.environ.get("FB_BN_BWD_FUSED", "0") == "1"
         # partial rows: (vectors of the tensor / 4096) x 2C floats, whatever the grouping -- sized for the largest layer of a full group
         es = torch.empty((), dtype=self.dt).element_size()
         self.bnf_ws = torch.empty(max((self.G * chunk * L.hout * L.wout * L.cout * es // 16 // 4096 * 2 + 4 * self.G) * L.cout for L in self.plan.layers) + 64,
@@ -414,7 +416,7 @@ class Engine:
         self.chain_layers, self.chain_on = [], False
         # OPT-IN (FB_WGRAD_CHAIN=1): the running-mean pass drops from 4.0 to 1.7 ms/step, but the chained kernel -- one 8-wave workgroup per CU with
         # two accumulator sets -- takes 840 us where the per-chunk kernel with two independent 4-wave workgroups takes 692 (profiles/r4_notes.md)
-        if dt == torch.bfloat16 and os.environ.get("FB_WGRAD_CHAIN", "0") == "1":
+        if dt == torch.bfloat16 and os.environ.get("FB_WGRAD_CHAIN", "0") == "1" and os.environ.get("FB_EXPERIMENTAL", "0") not in ("", "0"):
             for L in self.plan.layers:
                 a = lib.WgradArgs(None, None, None, n, L.hin, L.win, L.cin_pad, L.hout, L.wout, L.cout, L.R, L.S, L.stride, L.pad, self.chunk, 1, self.dtc, 0)
                 # (at most four: fb_mt_accumulate_skip leaves four ranges of the arena alone)

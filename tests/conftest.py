@@ -14,6 +14,11 @@ if REPO not in sys.path:
 #    watchdog re-armed per test dumps every thread's traceback and ends the process with a non-zero code instead of hanging the box;
 #  * multi-process tests start their ranks through tests/helpers.spawn_bounded (wall-clock cap, children killed, test failed) and create
 #    process groups with a 120 s timeout.
+# The tests also hold the EXPERIMENTAL kernel forms (built, bit-identical, off by default because they lost their same-box A/B) to the forms that ship: their
+# switches act only together with FB_EXPERIMENTAL=1 (csrc/runtime.cpp fb_experimental, engine.py) -- set for every test process and the ranks it spawns.  On its
+# own FB_EXPERIMENTAL selects nothing: the default dispatch is what the suite runs wherever a test does not name a switch.
+os.environ.setdefault("FB_EXPERIMENTAL", "1")
+
 TEST_TIMEOUT_S = int(os.environ.get("FB_TEST_TIMEOUT_S", "240"))
 WATCHDOG_S = int(os.environ.get("FB_TEST_WATCHDOG_S", "420"))
 

@@ -54,6 +54,55 @@ def test_built_kernels_keep_wide_buffer_store_data_alive():
     assert not hs.scan(demo)[0]
 
 
+def test_asm_prefetched_loads_of_the_1x1_kernels_are_not_touched_before_a_wait():
+    """The streaming / pipelined 1x1 kernels prefetch their addend (and its mask bytes) with inline-asm buffer loads that hipcc neither counts nor waits for; the
+    consumer waits with a hand-counted ``s_waitcnt vmcnt(N)`` (csrc/conv1x1_pipe.hip p1_load16 / p1_wait_loads4, csrc/conv1x1_stream.hip).  To the compiler the
+    destination registers are defined at the asm, so under register pressure it could copy or spill them between the load and the wait -- stale data, silently.
+    Static check of the built code: these kernels use no scratch memory (no spills at all: the hand counts also assume no compiler-inserted VMEM traffic), and no
+    instruction reads or writes the destination registers of such a load before the next ``s_waitcnt`` that names vmcnt."""
+    import importlib.util
+    import re
+    import subprocess
+    import tempfile
+
+    import __graft_entry__ as entry
+    from fullbatchtraining_amd import lib
+
+    entry.build()
+    spec = importlib.util.spec_from_file_location("hazard_scan", os.path.join(REPO, "tools", "hazard_scan.py"))
+    hs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hs)
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(REPO, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    bdir = os.path.join(REPO, "fullbatchtraining_amd", "csrc", "build")
+    with tempfile.TemporaryDirectory() as tmp:
+        rows = [k for f in ("conv1x1_pipe.o", "conv1x1_stream.o") for k in kr.kernels_of(os.path.join(bdir, f), tmp)]
+    assert len(rows) >= 20 and all(k["scratch"] == 0 for k in rows), [(k["name"], k["scratch"]) for k in rows if k["scratch"]]
+    ins = [(k, t) for k, t in hs.disassemble(lib._LIB_PATH) if "conv1x1_pipe_kernel" in k or "conv1x1_stream_kernel" in k]
+    assert not any(t.startswith("scratch_") for _, t in ins)
+    loads = checked = 0
+    pending, kern = {}, None                       # destination register -> index of its load
+    for idx, (k, t) in enumerate(ins):
+        if k != kern:
+            kern, pending = k, {}
+        mn = t.split()[0]
+        if mn == "s_waitcnt" and "vmcnt" in t:
+            checked += len(pending)
+            pending = {}
+            continue
+        regs = set()
+        for tok in re.findall(r"v\[\d+:\d+\]|v\d+", t):
+            regs |= hs._regs(tok)
+        hit = regs & set(pending)
+        assert not hit, (k, ins[min(pending[r] for r in hit)][1], t)
+        if mn in ("buffer_load_dwordx4", "buffer_load_ubyte") and " lds" not in t and "offen" in t:
+            loads += 1
+            for r in hs._regs(t[len(mn):].split(",")[0]):
+                pending[r] = idx
+    assert loads > 50 and checked > 50, (loads, checked)
+
+
 def test_workspace_size_queries():
     """Host-side arithmetic of the C ABI (no launch): scratch sizes the caller has to provide."""
     from fullbatchtraining_amd import lib

@@ -335,6 +335,20 @@ def test_on_block_done_path_gives_the_bits_of_the_replayed_path_on_a_bottleneck_
     assert bool(torch.isfinite(gout[:G]).all()) and float(gout[:G].abs().max()) > 0
 
 
+def test_experimental_switches_need_fb_experimental(monkeypatch):
+    """The switches that turn ON a kernel form which lost its same-box A/B (one-pass BatchNorm backward, fused BatchNorm-backward statistics, chunk-chained weight
+    gradients; in the library: FB_C1G=2, FB_H4_WIDE, ...) act only together with FB_EXPERIMENTAL=1 -- without it the engine runs the default dispatch whatever else
+    the environment says (DESIGN.md section 4 is then the whole truth)."""
+    for key in ("FB_BN_BWD_FUSED", "FB_FUSED_BWD_STAT", "FB_WGRAD_CHAIN"):
+        monkeypatch.setenv(key, "1")
+    monkeypatch.setenv("FB_EXPERIMENTAL", "0")
+    _, _, eng, _ = _build(18, 32, 128, 2, torch.bfloat16)
+    assert not eng.bn_fused and not eng.fuse_bwd_stat and not eng.chain_layers
+    monkeypatch.setenv("FB_EXPERIMENTAL", "1")
+    _, _, eng, _ = _build(18, 32, 128, 2, torch.bfloat16)
+    assert eng.bn_fused and eng.fuse_bwd_stat and eng.chain_layers
+
+
 def test_resnet152_at_224_directional_derivative():
     """BASELINE config 5 at its real shape (ResNet-152, 'standard' stem, 224x224 inputs, one chunk of 128 images, fp32 storage with the
     bf16x6 split -- the arithmetic of plain fp32 training; the regulariser's f16x2 arithmetic at this shape is covered by
