@@ -494,6 +494,24 @@ class Engine:
         split = max(1, min(want, px // (kstep * 4)))
         while split > 1 and (split - 1) * (_round_up(-(-px // split), kstep)) >= px:
             split -= 1
+        if self.dt == torch.float32 and L is not self.plan.stem and os.environ.get("FB_WGRAD_ROUNDS", "1") != "0":
+            # fp32 storage (six MFMAs per product: these launches are a quarter of the regularised ResNet-152 step): all workgroups of a launch take the same time, so
+            # a launch costs ceil(workgroups / resident slots) rounds -- "about 1000 workgroups" left the 256 -> 256 3x3 layers @14x14 of an 8-chunk group at 864 of
+            # 2 x 512 slots (0.84).  Take the smallest K-slice count whose last round is (nearly) full.  (Round 6; conv_wgrad_kernel<f32s_tag, 2, 2, 1, 1, 4>: two
+            # workgroups per CU by registers, the 64 x 64-tile form one by LDS.)
+            slots = (2 if big else 1) * 256
+            unit = max(tiles * G, 1)
+
+            def ok(sp):
+                return sp == 1 or (sp - 1) * (_round_up(-(-px // sp), kstep)) < px
+
+            def eff(sp):
+                n = unit * sp
+                return n / (-(-n // slots) * slots)
+
+            cands = [sp for sp in range(1, max(1, min(px // (kstep * 4), 4 * max(want, 1))) + 1) if ok(sp)]
+            top = max(eff(sp) for sp in cands)
+            split = min(sp for sp in cands if eff(sp) >= top - 0.02)
         return split
 
     # ------------------------------------------------------------------------------------------- parameter exchange --

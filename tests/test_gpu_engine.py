@@ -341,11 +341,19 @@ def test_experimental_switches_need_fb_experimental(monkeypatch):
     the environment says (DESIGN.md section 4 is then the whole truth)."""
     for key in ("FB_BN_BWD_FUSED", "FB_FUSED_BWD_STAT", "FB_WGRAD_CHAIN"):
         monkeypatch.setenv(key, "1")
+    from fullbatchtraining_amd.cfg import compose
+    from fullbatchtraining_amd.engine import Engine
+    from fullbatchtraining_amd.models import construct_model
+    model = construct_model(compose([]).model, 3, 10)
+
+    def build():                                       # (K-slice counts sized for the benchmark's group: the 4x4 layers then run one slice, the chained form's condition)
+        return Engine(model, 32, 128, 2, compute_dtype=torch.bfloat16, nominal_group=98)
+
     monkeypatch.setenv("FB_EXPERIMENTAL", "0")
-    _, _, eng, _ = _build(18, 32, 128, 2, torch.bfloat16)
+    eng = build()
     assert not eng.bn_fused and not eng.fuse_bwd_stat and not eng.chain_layers
     monkeypatch.setenv("FB_EXPERIMENTAL", "1")
-    _, _, eng, _ = _build(18, 32, 128, 2, torch.bfloat16)
+    eng = build()
     assert eng.bn_fused and eng.fuse_bwd_stat and eng.chain_layers
 
 
