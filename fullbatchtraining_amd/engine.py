@@ -498,8 +498,8 @@ class Engine:
             # fp32 storage (six MFMAs per product: these launches are a quarter of the regularised ResNet-152 step): all workgroups of a launch take the same time, so
             # a launch costs ceil(workgroups / resident slots) rounds -- "about 1000 workgroups" left the 256 -> 256 3x3 layers @14x14 of an 8-chunk group at 864 of
             # 2 x 512 slots (0.84).  Take the smallest K-slice count whose last round is (nearly) full.  (Round 6; conv_wgrad_kernel<f32s_tag, 2, 2, 1, 1, 4>: two
-            # workgroups per CU by registers, the 64 x 64-tile form one by LDS.)
-            slots = (2 if big else 1) * 256
+            # workgroups per CU by registers, and so has the 64 x 64-tile form since its waves are arranged 2 x 2.)
+            slots = 2 * 256
             unit = max(tiles * G, 1)
 
             def ok(sp):
