@@ -549,6 +549,23 @@ def test_bench_line_stays_below_4k_on_a_canned_run():
         bench.assemble_line(dict(base, padding="x" * 4096), {}, (line_part, detail_part), side, cpu)
 
 
+def test_bench_line_reports_a_failed_resnet152_child_inside_the_line():
+    """`bench.py` times BASELINE config 5's model in a child process; if that child fails (out of memory on a smaller device, a timeout) the headline line must still be
+    printed, with the failure reported in `configs.r152_error` -- the compact form keeps the message and stays parseable."""
+    import json
+
+    import bench
+
+    side = {"configs": {"k400": {"value": 1.0, "unit": "images/s", "ms_per_step": 2.0, "dtype": "bf16", "steps": 5, "workload": "x" * 300},
+                        "r152_error": {"value": None, "unit": "images/s", "ms_per_step": None, "dtype": "bf16", "steps": 0, "error": "RuntimeError: exit code 1: HIP out of memory"}},
+            "parity": {"two_streams_vs_one": {"bit_identical": True}}}
+    out = bench.compact_side(side)
+    assert out["configs"]["r152_error"]["error"].startswith("RuntimeError") and out["configs"]["r152_error"]["value"] is None
+    assert "workload" not in out["configs"]["k400"] and out["parity"]["two_streams_vs_one"] is True
+    line, _ = bench.assemble_line({"metric": "m", "value": 1.0, "config": {}}, {}, None, side, None)
+    assert json.loads(line)["configs"]["r152_error"]["steps"] == 0
+
+
 def test_power_sampler_without_a_gpu_reports_nothing(tmp_path):
     """bench.PowerSampler reads the amdgpu hwmon files of the process's GPU from a host thread; where there is no such device (this container) or the
     files are unreadable it must stay out of the way: start() is a no-op and result() is None (the line then carries ``"power": null``).  With a
