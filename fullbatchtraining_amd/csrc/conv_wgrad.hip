@@ -334,7 +334,11 @@ extern "C" int fb_conv2d_wgrad(const fb_wgrad_args* a, void* stream) {
         else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_tag, 2, 2, 1, 2, 4>), grid, dim3(256), 0, st, p);
     } else if (a->Cs % 64 == 0) {
         dim3 grid((a->Cd / 64) * (a->Cs / 64), taps, n_groups * a->split_k);
-        if (hsplit) hipLaunchKernelGGL((conv_wgrad_kernel<f32h_tag, 1, 1, 4, 1, 4>), grid, dim3(256), 0, st, p);
+        if (hsplit) {
+            static const bool k4h = getenv("FB_WGRAD_F32S_K4") != nullptr;
+            if (k4h) hipLaunchKernelGGL((conv_wgrad_kernel<f32h_tag, 1, 1, 4, 1, 4>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((conv_wgrad_kernel<f32h_tag, 1, 2, 2, 1, 2>), grid, dim3(256), 0, st, p);      // (the 2 x 2 wave arrangement of the bf16x6 form below)
+        }
         else if (a->dtype == FB_F32 && split) {
             // bf16x6 (three planes per operand in LDS): two waves across the 64 input channels and two across K, 64 pixels per K-step -- 54 KiB and two workgroups per CU
             // instead of four waves across K on 128-pixel steps (108 KiB, one workgroup per CU: 58 fp32-TFLOP/s on the 64-channel layers of ResNet-152 @224, 47 ms of
