@@ -294,11 +294,13 @@ def test_config5_two_rank_run_equals_single_process(tmp_path, mode):
         for k in range(3):
             # (|g_k|^2: two partial sums with an early late bucket; bf16: the BatchNorm-backward partial rows cover 128-1024 pixels depending on the LAUNCH's pixel count,
             # fb_bn_bwd_reduce_rows, and another fp32 sum order moves a few bf16 roundings of dx: test_chunk_group_beyond_2g_byte_tensors_equals_smaller_groups)
-            assert np.allclose(got["stats"][f"grad_norm_train_{k}"], ref["stats"][f"grad_norm_train_{k}"], rtol=2e-3 if mode.endswith("bf16") else 1e-6), k
+            assert np.allclose(got["stats"][f"grad_norm_train_{k}"], ref["stats"][f"grad_norm_train_{k}"], rtol=3e-4 if mode.endswith("bf16") else 1e-6), k       # (measured: 0 / 2.9e-5)
         # (the norm of the exchanged mean gradient: the ranks' partial means are summed in another order than the 1-process running mean -- 1.4e-7 at step 1; at step 2 the
         # finite-difference term is thousands of times the gradient at random initialisation (profiles/r3_fd_conditioning.md) and carries that order at 8e-5)
         for key in ("grad_norm", "full_loss", "preclip_gradnorm", "clipped_step", "train_acc"):
             assert np.allclose(got["stats"][key], ref["stats"][key], rtol=2e-3 if mode.endswith("bf16") else 1e-3, atol=1e-6), (key, got["stats"][key], ref["stats"][key])
+        norms = max(abs(a / b - 1.0) for k in range(3) for a, b in zip(got["stats"][f"grad_norm_train_{k}"], ref["stats"][f"grad_norm_train_{k}"]))
+        print(f"{mode}, rank {r}: chunk gradient norms: worst relative difference {norms:.2e}; preclip norm {got['stats']['preclip_gradnorm']} vs {ref['stats']['preclip_gradnorm']}")
         worst = 0.0
         for name, t in ref["state"].items():
             if t.is_floating_point():
