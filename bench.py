@@ -213,7 +213,8 @@ def _rel(a, b, chunks=None):
 
 def side_configs(args, device, X, Y, main_trainer):
     """Timed in the same run as the headline line (N = 1), on the same resident dataset:
-      configs.k400            all 50 000 images as 400 chunks of 125 (data.batch_size = 125: the number BASELINE's metric is quoted on)
+      configs.k400            all 50 000 images as 400 chunks of 125 (data.batch_size = 125: the number BASELINE's metric is quoted on; stored padded to 128 images per chunk)
+      configs.k250            all 50 000 images as 250 chunks of 200 (data.batch_size = 200: the smallest-padding form of "bs = 50 000" -- none at all)
       configs.gradreg         BASELINE config 3 (GradRegularizer block_strength 0.5, forward differences) at REFERENCE precision: fp32 storage,
                               every convolution product exact to 2^-23 (three bf16 pieces per operand, six MFMAs: "bf16x6")
       configs.gradreg_f16x2   the same step in the arithmetic the engine uses by default for the regulariser: operands carried as two scaled
@@ -231,6 +232,16 @@ def side_configs(args, device, X, Y, main_trainer):
                                           f"{tr.chunk_pad} images per chunk), bf16, grad_reg off", "ms_per_step": round(1000 * dt, 2), "value": round(tr.datapoints / dt, 1),
                               "unit": "images/s", "steps": 5, "warmup": 2, "dtype": "bf16", "step_mfma_frac": round(flop_img * tr.datapoints / dt / (PEAK_BF16_TFLOPS * 1e12), 4),
                               "train_loss_last": tr.stats["train_loss"][-1]}
+    del tr
+    gc.collect(), torch.cuda.empty_cache()
+    # ---- all 50 000 images WITHOUT padding: 250 chunks of 200 (a chunk size whose pixels fill whole 128-pixel statistics blocks on every map: 200 x 16 = 25 blocks at 4x4) ----
+    tr = _side_trainer(args, device, X, Y, ["hyp=fb1", "hyp.warmup=0", "hyp.steps=12", "impl.mixed_precision=True", "data.batch_size=200", "hyp.sub_batch=200"], "bench_k250")
+    dt = _timed_steps(tr, 5, 2)
+    out["configs"]["k250"] = {"workload": f"ResNet-18 CIFAR-10 full-batch GD step over ALL {tr.datapoints} images: {tr.n_chunks} chunks x {tr.chunk} (data.batch_size = 200: no padding, "
+                                          f"stored chunk {tr.chunk_pad}), bf16, grad_reg off", "ms_per_step": round(1000 * dt, 2), "value": round(tr.datapoints / dt, 1),
+                              "unit": "images/s", "steps": 5, "warmup": 2, "dtype": "bf16", "step_mfma_frac": round(flop_img * tr.datapoints / dt / (PEAK_BF16_TFLOPS * 1e12), 4),
+                              "chunk_group": tr.engine.G, "train_loss_last": tr.stats["train_loss"][-1]}
+    assert tr.chunk_pad == tr.chunk                         # (no padding images)
     del tr
     gc.collect(), torch.cuda.empty_cache()
     # ---- the headline workload with the stem's patch gather INSIDE the step: on-device RandomCrop(32, 4) + RandomHorizontalFlip of the resident
